@@ -1,0 +1,153 @@
+/*
+ * nrgbd.h — C-ABI of libnrgbd_hip.so: the MI355X (gfx950) plane-sweep depth path.
+ *
+ * This is the drop-in boundary for the hot path of NVlabs/neuralrgbd
+ * (homography warp -> D-candidate cost volume -> D-Net -> K-Net DPV predict/update).
+ * The reference has no FFI of its own: its seam is the Python operator surface of
+ * code/warping/homography.py and the ATen ops composed under code/models/.  Each entry
+ * point below names the reference interface (file:line, relative to /root/reference)
+ * that it replaces.  The Python host (neuralrgbd_amd/) binds these with ctypes and keeps
+ * the reference signatures; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are
+ *     launched on the CURRENT device, are re-entrant and keep no global mutable state;
+ *   - inputs are never written; outputs are fully overwritten;
+ *   - return value: 0 = success, <0 = NRGBD_E_* argument error, >0 = hipError_t;
+ *   - no host synchronisation, no allocation: every call is hipGraph-capturable.
+ *
+ * Layouts
+ *   NCHW  [N][C][h][w]   what torch convolutions produce / consume
+ *   NHWC  [N][h][w][Cp]  "texel" layout used by the sampling kernels; Cp = C rounded up to
+ *                        a multiple of 4 so that one texel is a whole number of 16-byte
+ *                        words (67 -> 68 channels = 272 B, conflict-free for ds_read_b128)
+ */
+#ifndef NRGBD_H
+#define NRGBD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRGBD_OK             0
+#define NRGBD_E_NULL        -1   /* a required pointer is NULL                      */
+#define NRGBD_E_SHAPE       -2   /* a dimension is <=0 or exceeds a kernel limit    */
+#define NRGBD_E_ALIGN       -3   /* Cp not a multiple of 4 / pointer not 16-B aligned */
+#define NRGBD_E_ARG         -4   /* an enum / flag argument is out of range         */
+
+#define NRGBD_DIST_L2        0   /* homography.py:81-83  img_dis_L2_pard */
+#define NRGBD_DIST_L1        1   /* homography.py:85-87  img_dis_L1_pard */
+
+#define NRGBD_MAX_D        256   /* depth candidates per volume */
+#define NRGBD_MAX_V         16   /* source views per window     */
+
+/* Library / build identification ("gfx950"), and error text for a return code. */
+const char* nrgbd_version(void);
+const char* nrgbd_strerror(int code);
+
+/*
+ * nrgbd_pack_nhwc — feature packing for the sampling kernels.
+ * Replaces: models/basic.py:254-263 (F.avg_pool2d of the RGB frames + torch.cat onto the
+ * CNN features) and the implicit NCHW layout handed to homography.py:293.
+ *   feat [N][Cf][h][w]            CNN features (NCHW)
+ *   rgb  [N][3][h*pool][w*pool]   full-resolution frames, or NULL (then only a transpose)
+ *   out  [N][h][w][Cp]            out[..,c] = feat[c] (c<Cf); mean of the pool x pool RGB
+ *                                 window (c = Cf..Cf+2, rgb != NULL); 0 for padding
+ * Requires Cp % 4 == 0 and Cp >= Cf (+3 if rgb).
+ */
+int nrgbd_pack_nhwc(const float* feat, const float* rgb, float* out,
+                    int N, int Cf, int h, int w, int pool, int Cp, void* stream);
+
+/*
+ * nrgbd_costvol_fwd — fused homography warp + bilinear sample + cost accumulate
+ * (+ optional log-softmax over the depth axis).
+ * Replaces: warping/homography.py:293-331 est_swp_volume_v4, :421-448
+ * _back_warp_homo_parallel (F.grid_sample bilinear / zeros), :81-87 img_dis_L2/L1_pard,
+ * and models/basic.py:299-300 (log_softmax(-costV, dim=1)) when out_logp != NULL.
+ *   ref_nhwc [h][w][Cp], src_nhwc [V][h][w][Cp]   packed features (channels >= C ignored)
+ *   KR [V][9]   row-major K·R_v          (the matmul of homography.py:317, left factor)
+ *   Kt [V][3]   K·t_v                    (homography.py:315, term1)
+ *   rays [3][h*w]                        cam_intrinsic['unit_ray_array_2D']
+ *   d_candi [D]                          candidate depths (fp32 cast of the float64 array)
+ *   cx, cy                               cam_intrinsic['intrinsic_M'][0,2], [1,2]
+ *   sigma                                costV_sigma
+ *   dist                                 NRGBD_DIST_L2 | NRGBD_DIST_L1
+ *   align_corners                        0 = torch>=1.3 default (what the reference runs
+ *                                        today), 1 = legacy grid_sample behaviour
+ *   out_cost [D][h][w] or NULL, out_logp [D][h][w] or NULL (at least one non-NULL)
+ * Views are accumulated in the order v = 0..V-1: cost += sum_c(.)/sigma.
+ */
+int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc,
+                      const float* KR, const float* Kt, const float* rays,
+                      const float* d_candi, float cx, float cy, float sigma,
+                      int dist, int align_corners,
+                      float* out_cost, float* out_logp,
+                      int V, int C, int Cp, int D, int h, int w, void* stream);
+
+/*
+ * nrgbd_warp_volume — plane-sweep warp of low-channel maps with the samples kept, plus
+ * the K-Net input-volume assembly.
+ * Replaces: warping/homography.py:234-280 warp_img_feats_v3 / :183-232 warp_img_feats_mgpu
+ * (C=3, output transposed to [C][D][h][w]) and models/KVNET.py:163-166 (torch.cat of the
+ * warped sources, the reference RGB repeated over D, and BV_cur - BV_predict).
+ *   src: V maps of Cs channels addressed as src + v*sv + c*sc + y*sy + x*sx (elements),
+ *        so both planar [V][Cs][h][w] and NHWC slices are accepted
+ *   ref: one map of Cs channels with strides rc, ry, rx, or NULL
+ *   bv_cur, bv_pred [D][h][w] or NULL (both or neither)
+ *   out [V*Cs (+Cs if ref) (+1 if bv_cur)][D][h][w]:
+ *        channel v*Cs+c   = warped source v, channel c, at depth k
+ *        next Cs channels = ref[c] repeated over D
+ *        last channel     = bv_cur - bv_pred
+ */
+int nrgbd_warp_volume(const float* src, long sv, long sc, long sy, long sx,
+                      const float* ref, long rc, long ry, long rx,
+                      const float* KR, const float* Kt, const float* rays,
+                      const float* d_candi, float cx, float cy, int align_corners,
+                      const float* bv_cur, const float* bv_pred,
+                      float* out, int V, int Cs, int D, int h, int w, void* stream);
+
+/*
+ * nrgbd_dpv_resample — PREDICT step: rigid 3-D resample of the DPV into the next frame.
+ * Replaces: warping/homography.py:654-723 resample_vol_cuda (d_candi_new=None),
+ * :873-887 _set_vol_border and the .clamp(max=0,min=-1000) of
+ * test_utils/test_KVNet.py:54-59.  The [1,D,h,w,3] point grid the reference builds on the
+ * host and copies to the device every frame (homography.py:673-682) is generated in-kernel.
+ *   dpv [D][h][w]     log-probability volume
+ *   T [16]            row-major 4x4 rel_extM (DEVICE pointer: no host read, no sync)
+ *   rays [3][h*w]     unit_ray_array_2D (fp32 of cam_intrinsic['unit_ray_array'])
+ *   d_candi [D]
+ *   tan_hh, tan_hv    tan(radians(hfov)/2), tan(radians(vfov)/2)
+ *   z_half, z_radius  (z_max+z_min)/2, (z_max-z_min)/2 of fp32(d_candi)  (:689-693)
+ *   pad_value         border value written on the 6 faces (log(1/D))
+ *   do_clamp          clamp the result to [clamp_lo, clamp_hi]
+ *   out [D][h][w]
+ */
+int nrgbd_dpv_resample(const float* dpv, const float* T, const float* rays,
+                       const float* d_candi, float tan_hh, float tan_hv,
+                       float z_half, float z_radius, float pad_value,
+                       int do_clamp, float clamp_lo, float clamp_hi,
+                       float* out, int D, int h, int w, void* stream);
+
+/*
+ * nrgbd_logsoftmax_d — log-softmax over the depth axis of scale*a (+ b).
+ * Replaces: models/basic.py:299-300 (scale=-1, b=NULL) and the UPDATE step
+ * models/KVNET.py:172-173 (scale=1, a = K-Net gain, b = BV_predict).
+ *   a, b, out [D][n]   (n = h*w; b may be NULL; out may alias a)
+ */
+int nrgbd_logsoftmax_d(const float* a, const float* b, float scale, float* out,
+                       int D, long n, void* stream);
+
+/*
+ * nrgbd_depth_regress — expected depth and confidence of a log-DPV.
+ * Replaces: mutils/misc.py:532-548 depth_val_regression (BV_log=True; a Python loop over
+ * D) and the max_d of test_utils/export_res.py:58-59.
+ *   logp [D][n]; d_candi [D]; depth [n] or NULL; conf [n] or NULL (max_k logp)
+ */
+int nrgbd_depth_regress(const float* logp, const float* d_candi,
+                        float* depth, float* conf, int D, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRGBD_H */

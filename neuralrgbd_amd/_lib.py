@@ -1,0 +1,62 @@
+"""ctypes loader of libnrgbd_hip.so — the C-ABI declared in include/nrgbd.h.
+
+There is deliberately NO fallback: if the HIP library is missing or does not export every
+symbol of the header, importing the product path raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnrgbd_hip.so")
+
+_c = ctypes
+_P = _c.c_void_p
+_F = _c.c_float
+_I = _c.c_int
+_L = _c.c_long
+
+# name -> (restype, argtypes); one entry per function of include/nrgbd.h
+SIGNATURES = {
+    "nrgbd_version": (_c.c_char_p, []),
+    "nrgbd_strerror": (_c.c_char_p, [_I]),
+    "nrgbd_pack_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_costvol_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P,
+                               _I, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_warp_volume": (_I, [_P, _L, _L, _L, _L, _P, _L, _L, _L, _P, _P, _P, _P, _F, _F, _I,
+                               _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_dpv_resample": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _I, _I, _P]),
+    "nrgbd_logsoftmax_d": (_I, [_P, _P, _F, _P, _I, _L, _P]),
+    "nrgbd_depth_regress": (_I, [_P, _P, _P, _P, _I, _L, _P]),
+}
+
+_lib = None
+
+
+class NrgbdError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise NrgbdError(
+            "libnrgbd_hip.so not found at %s — build it with `python -m neuralrgbd_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback for this path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise NrgbdError("libnrgbd_hip.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().nrgbd_strerror(int(code)).decode()
+        raise NrgbdError("%s failed: %s (code %d)" % (what, msg, code))

@@ -1,0 +1,111 @@
+// common.hpp — device helpers shared by the gfx950 kernels of libnrgbd_hip.so.
+//
+// Arithmetic contract (DESIGN.md §"Numerics"): the sampling coordinates are computed with the
+// same operation sequence as the reference's torch code so that tap selection (floor) and
+// weights agree with it to the last ulp wherever the reference itself is deterministic:
+//   P = term1 + term2*d (separate mul and add; warping/homography.py:433), P /= (P_z + 1e-10)
+//   (:434), g = (u - c)/c (:441-445, IEEE division), grid_sample un-normalisation
+//   ((g+1)*size - 1)/2 (ATen GridSampler.h grid_sampler_unnormalize).
+// The library is compiled with -ffp-contract=off; every fused multiply-add below is explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nrgbd.h"
+
+#define NRGBD_CHECK_LAUNCH()                         \
+    do {                                             \
+        hipError_t e__ = hipGetLastError();          \
+        if (e__ != hipSuccess) return (int)e__;      \
+    } while (0)
+
+namespace nrgbd {
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+// term2 for one (pixel, view): (K R_v) * ray_p  — homography.py:317 (matmul, K=3 chain).
+struct SweepTerm {
+    float t1x, t1y, t1z;  // K t_v          (term1)
+    float t2x, t2y, t2z;  // (K R_v) ray_p  (term2)
+};
+
+__device__ __forceinline__ SweepTerm make_sweep_term(const float* __restrict__ KR,
+                                                      const float* __restrict__ Kt, float rx,
+                                                      float ry, float rz) {
+    SweepTerm s;
+    s.t1x = Kt[0]; s.t1y = Kt[1]; s.t1z = Kt[2];
+    s.t2x = __builtin_fmaf(KR[2], rz, __builtin_fmaf(KR[1], ry, KR[0] * rx));
+    s.t2y = __builtin_fmaf(KR[5], rz, __builtin_fmaf(KR[4], ry, KR[3] * rx));
+    s.t2z = __builtin_fmaf(KR[8], rz, __builtin_fmaf(KR[7], ry, KR[6] * rx));
+    return s;
+}
+
+// ATen grid_sampler_unnormalize
+__device__ __forceinline__ float unnormalize(float g, float size, bool align_corners) {
+    return align_corners ? ((g + 1.f) / 2.f) * (size - 1.f) : ((g + 1.f) * size - 1.f) / 2.f;
+}
+
+// Source-image sample position (in texels) of the pixel behind `s` on the plane at depth d.
+__device__ __forceinline__ void sweep_sample_pos(const SweepTerm& s, float d, float cx, float cy,
+                                                 float wf, float hf, bool align_corners,
+                                                 float& ix, float& iy) {
+    const float px = s.t1x + s.t2x * d;
+    const float py = s.t1y + s.t2y * d;
+    const float pz = s.t1z + s.t2z * d;
+    const float den = pz + 1e-10f;
+    const float u = px / den;
+    const float v = py / den;
+    const float gx = (u - cx) / cx;
+    const float gy = (v - cy) / cy;
+    ix = unnormalize(gx, wf, align_corners);
+    iy = unnormalize(gy, hf, align_corners);
+}
+
+// Bilinear footprint with zeros padding: the four corner weights (already zeroed for corners
+// outside the image) and clamped integer corners, so loads are always in range.
+struct Bilinear {
+    int x0, x1, y0, y1;      // clamped to the image
+    float nw, ne, sw, se;    // weight * in-bounds
+};
+
+__device__ __forceinline__ Bilinear bilinear_zeros(float ix, float iy, int w, int h) {
+    Bilinear b;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float fx = ix - x0f, fy = iy - y0f;
+    const float ex = 1.f - fx, ey = 1.f - fy;
+    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+    const float wm = (float)(w - 1), hm = (float)(h - 1);
+    // float compares: NaN / out-of-range positions select nothing (ATen CPU mask semantics)
+    const bool vx0 = (x0f >= 0.f) && (x0f <= wm), vx1 = (x1f >= 0.f) && (x1f <= wm);
+    const bool vy0 = (y0f >= 0.f) && (y0f <= hm), vy1 = (y1f >= 0.f) && (y1f <= hm);
+    b.x0 = vx0 ? (int)x0f : 0; b.x1 = vx1 ? (int)x1f : 0;
+    b.y0 = vy0 ? (int)y0f : 0; b.y1 = vy1 ? (int)y1f : 0;
+    b.nw = (vx0 && vy0) ? ey * ex : 0.f;
+    b.ne = (vx1 && vy0) ? ey * fx : 0.f;
+    b.sw = (vx0 && vy1) ? fy * ex : 0.f;
+    b.se = (vx1 && vy1) ? fy * fx : 0.f;
+    return b;
+}
+
+__device__ __forceinline__ float lerp4(float a, float b, float c, float d, const Bilinear& t) {
+    float s = a * t.nw;
+    s = __builtin_fmaf(b, t.ne, s);
+    s = __builtin_fmaf(c, t.sw, s);
+    s = __builtin_fmaf(d, t.se, s);
+    return s;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace nrgbd

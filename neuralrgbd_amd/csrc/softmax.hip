@@ -1,0 +1,91 @@
+// softmax.hip — per-pixel reductions over the depth axis of a [D][n] volume (K4, K9, K13).
+// HBM-bound: lanes run along the pixel axis (coalesced), each lane walks the D candidates of its
+// pixel; for D <= 128 the column is held in registers so the volume is read once, written once.
+#include "common.hpp"
+
+namespace nrgbd {
+
+// out = log_softmax_k(scale * a + b)   (models/basic.py:299-300, models/KVNET.py:172-173)
+template <int DREG>  // DREG > 0: D <= DREG, column cached in registers; 0: three passes over memory
+__global__ __launch_bounds__(256) void logsoftmax_d_kernel(const float* __restrict__ a,
+                                                           const float* __restrict__ b, float scale,
+                                                           float* __restrict__ out, int D, size_t n) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    auto load = [&](int k) -> float {
+        float v = scale * a[(size_t)k * n + p];
+        if (b) v = v + b[(size_t)k * n + p];
+        return v;
+    };
+    if constexpr (DREG > 0) {
+        float col[DREG];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < DREG; ++k) {
+            col[k] = (k < D) ? load(k) : -INFINITY;
+            m = fmaxf(m, col[k]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < DREG; ++k)
+            if (k < D) s += expf(col[k] - m);
+        const float ls = logf(s);
+#pragma unroll
+        for (int k = 0; k < DREG; ++k)
+            if (k < D) out[(size_t)k * n + p] = (col[k] - m) - ls;
+    } else {
+        float m = -INFINITY;
+        for (int k = 0; k < D; ++k) m = fmaxf(m, load(k));
+        float s = 0.f;
+        for (int k = 0; k < D; ++k) s += expf(load(k) - m);
+        const float ls = logf(s);
+        for (int k = 0; k < D; ++k) out[(size_t)k * n + p] = (load(k) - m) - ls;
+    }
+}
+
+// depth = sum_k exp(logp_k) * d_k, conf = max_k logp_k   (mutils/misc.py:532-548)
+__global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restrict__ logp,
+                                                            const float* __restrict__ d_candi,
+                                                            float* __restrict__ depth,
+                                                            float* __restrict__ conf, int D, size_t n) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    float acc = 0.f, m = -INFINITY;
+    for (int k = 0; k < D; ++k) {
+        const float v = logp[(size_t)k * n + p];
+        acc = acc + expf(v) * d_candi[k];
+        m = fmaxf(m, v);
+    }
+    if (depth) depth[p] = acc;
+    if (conf) conf[p] = m;
+}
+
+}  // namespace nrgbd
+
+extern "C" int nrgbd_logsoftmax_d(const float* a, const float* b, float scale, float* out, int D,
+                                  long n, void* stream) {
+    using namespace nrgbd;
+    if (!a || !out) return NRGBD_E_NULL;
+    if (D <= 0 || n <= 0) return NRGBD_E_SHAPE;
+    dim3 grid(ceil_div(n, 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (D <= 64)
+        hipLaunchKernelGGL(logsoftmax_d_kernel<64>, grid, dim3(256), 0, s, a, b, scale, out, D, (size_t)n);
+    else if (D <= 128)
+        hipLaunchKernelGGL(logsoftmax_d_kernel<128>, grid, dim3(256), 0, s, a, b, scale, out, D, (size_t)n);
+    else
+        hipLaunchKernelGGL(logsoftmax_d_kernel<0>, grid, dim3(256), 0, s, a, b, scale, out, D, (size_t)n);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+extern "C" int nrgbd_depth_regress(const float* logp, const float* d_candi, float* depth,
+                                   float* conf, int D, long n, void* stream) {
+    using namespace nrgbd;
+    if (!logp || !d_candi || (!depth && !conf)) return NRGBD_E_NULL;
+    if (D <= 0 || n <= 0) return NRGBD_E_SHAPE;
+    hipLaunchKernelGGL(depth_regress_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, logp, d_candi, depth, conf, D, (size_t)n);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}

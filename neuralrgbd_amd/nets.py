@@ -1,0 +1,227 @@
+"""Convolutional sub-networks of the depth path (D-Net feature CNN, K-Net, R-Net).
+
+Parameter containers keep the attribute names of the reference so that its checkpoints
+(`kvnet_scannet.tar`, `kvnet_kitti.tar`; 459 `module.`-prefixed keys) load
+unchanged:
+  feature CNN  <- code/models/psm_submodule.py:76-167 (feature_extraction) wrapped by
+                  code/models/basic.py:13-51 (feature_extractor)
+  K-Net        <- code/models/basic.py:53-139 (KV_NET_BASIC)
+  R-Net        <- code/models/Refine.py:24-132 (RefineNet_DPV_upsample)
+The modules below only own parameters and the layer graph; tensors must live on the GPU and
+the sampling / softmax work around them goes through the HIP library (neuralrgbd_amd.ops).
+
+Behavioural notes that matter for parity: the reference never calls
+.eval(), so every BatchNorm normalises with batch statistics at inference; 58 of the 60
+BatchNorm2d are built with track_running_stats=False, the two residual-shortcut ones and the
+eleven BatchNorm3d keep (and update) running statistics.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- builders
+def _conv_bn2d(cin, cout, k, stride, pad, dilation, track=False):
+    """Conv2d(no bias) -> BatchNorm2d; children '0','1' (psm_submodule.py:10-16)."""
+    p = dilation if dilation > 1 else pad
+    return nn.Sequential(
+        nn.Conv2d(cin, cout, k, stride=stride, padding=p, dilation=dilation, bias=False),
+        nn.BatchNorm2d(cout, track_running_stats=track),
+    )
+
+
+def _conv_bn3d(cin, cout):
+    """Conv3d 3x3x3 s1 p1 (no bias) -> BatchNorm3d; children '0','1' (psm_submodule.py:19-23)."""
+    return nn.Sequential(nn.Conv3d(cin, cout, 3, stride=1, padding=1, bias=False), nn.BatchNorm3d(cout))
+
+
+def _conv_lrelu(cin, cout):
+    """Conv2d 3x3 p1 (bias) -> LeakyReLU(0.01); children '0','1' (m_submodule.py:18-27)."""
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, stride=1, padding=1, bias=True), nn.LeakyReLU())
+
+
+def _deconv_lrelu(cin, cout):
+    """ConvTranspose2d k4 s2 p1 (bias) -> LeakyReLU(0.01) (m_submodule.py:36-45)."""
+    return nn.Sequential(nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1, bias=True), nn.LeakyReLU())
+
+
+def _he_init(module):
+    """N(0, sqrt(2/(k..k*out))) for convs, gamma=1 / beta=0 for norms (basic.py:29-43,97-111)."""
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+            fan = int(np.prod(m.kernel_size)) * m.out_channels
+            m.weight.data.normal_(0, math.sqrt(2.0 / fan))
+        elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.weight.data.fill_(1)
+            m.bias.data.zero_()
+
+
+# --------------------------------------------------------------------------- 2-D feature CNN
+class ResBlock2d(nn.Module):
+    """Two conv-bn with identity / 1x1 shortcut, no activation after the add (psm_submodule.py:31-50)."""
+
+    def __init__(self, cin, cout, stride, shortcut, pad, dilation):
+        super().__init__()
+        self.conv1 = nn.Sequential(_conv_bn2d(cin, cout, 3, stride, pad, dilation), nn.ReLU(inplace=True))
+        self.conv2 = _conv_bn2d(cout, cout, 3, 1, pad, dilation)
+        self.downsample = shortcut
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + (x if self.downsample is None else self.downsample(x))
+
+
+class PSMFeatures(nn.Module):
+    """PSMNet-style pyramid feature CNN: 1/2-res stem, 1/4-res trunk, 4-scale SPP, 1x1 head.
+
+    Output: (layer1 [N,32,H/2,W/2], feat [N,feature_dim,H/4,W/4]) when multi_scale, else feat.
+    Layer graph follows psm_submodule.py:90-167 (layer3 dilation 1, layer4 dilation 2, SPP
+    windows 64/32/16/8 on the 1/4-res map, bilinear up-sampling with align_corners=True).
+    """
+
+    SPP_WINDOWS = (64, 32, 16, 8)
+
+    def __init__(self, feature_dim=32, bn_running_avg=False, multi_scale=False):
+        super().__init__()
+        self.multi_scale = multi_scale
+        t = bn_running_avg
+        self.firstconv = nn.Sequential(
+            _conv_bn2d(3, 32, 3, 2, 1, 1, t), nn.ReLU(inplace=True),
+            _conv_bn2d(32, 32, 3, 1, 1, 1, t), nn.ReLU(inplace=True),
+            _conv_bn2d(32, 32, 3, 1, 1, 1, t), nn.ReLU(inplace=True),
+        )
+        self._width = 32
+        self.layer1 = self._stage(32, 3, 1, 1, 1)
+        self.layer2 = self._stage(64, 16, 2, 1, 1)
+        self.layer3 = self._stage(128, 3, 1, 1, 1)
+        self.layer4 = self._stage(128, 3, 1, 1, 2)
+        for i, win in enumerate(self.SPP_WINDOWS, start=1):
+            setattr(self, "branch%d" % i, nn.Sequential(
+                nn.AvgPool2d((win, win), stride=(win, win)),
+                _conv_bn2d(128, 32, 1, 1, 0, 1, t), nn.ReLU(inplace=True)))
+        self.lastconv = nn.Sequential(
+            _conv_bn2d(320, 128, 3, 1, 1, 1, t), nn.ReLU(inplace=True),
+            nn.Conv2d(128, feature_dim, 1, padding=0, stride=1, bias=False))
+
+    def _stage(self, width, n_blocks, stride, pad, dilation):
+        shortcut = None
+        if stride != 1 or self._width != width:
+            # the shortcut BatchNorm is the only 2-D norm with running statistics (psm_submodule.py:131)
+            shortcut = nn.Sequential(nn.Conv2d(self._width, width, 1, stride=stride, bias=False),
+                                     nn.BatchNorm2d(width))
+        blocks = [ResBlock2d(self._width, width, stride, shortcut, pad, dilation)]
+        self._width = width
+        blocks += [ResBlock2d(width, width, 1, None, pad, dilation) for _ in range(n_blocks - 1)]
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        stem = self.firstconv(x)
+        half = self.layer1(stem)
+        quarter = self.layer2(half)
+        deep = self.layer4(self.layer3(quarter))
+        size = deep.shape[2:]
+        pyramid = [F.interpolate(getattr(self, "branch%d" % i)(deep), size=size, mode="bilinear",
+                                 align_corners=True) for i in (4, 3, 2, 1)]
+        feat = self.lastconv(torch.cat([quarter, deep] + pyramid, dim=1))
+        return (half, feat) if self.multi_scale else feat
+
+
+class FeatureExtractor(nn.Module):
+    """Wrapper holding the CNN as `.feature_extraction` (basic.py:13-51) — the object shared
+    between KVNET.feature_extractor and KVNET.d_net.feature_extraction."""
+
+    def __init__(self, feature_dim=32, bn_running_avg=False, multi_scale=False):
+        super().__init__()
+        self.feature_extraction = PSMFeatures(feature_dim, bn_running_avg, multi_scale)
+        self.multi_scale = multi_scale
+        _he_init(self)
+
+    def forward(self, img):
+        return self.feature_extraction(img)
+
+
+# --------------------------------------------------------------------------- K-Net (3-D)
+class KalmanGainNet(nn.Module):
+    """K-Net: 12 conv3d 3x3x3 (16->64, 10x 64->64, 64->1), BN3d + ReLU, 4 residual pairs.
+
+    gain = kv_net(volume[1,16,D,h,w]) -> [1,1,D,h,w]   (basic.py:53-139)
+    """
+
+    def __init__(self, input_volume_channels, feature_dim=32, if_normalize=False, up_sample_ratio=None):
+        super().__init__()
+        self.in_channels = input_volume_channels
+        self.if_normalize = if_normalize
+        self.up_sample_ratio = up_sample_ratio
+        f = feature_dim
+        self.dres0 = nn.Sequential(_conv_bn3d(input_volume_channels, f), nn.ReLU(), _conv_bn3d(f, f), nn.ReLU())
+        for i in (1, 2, 3, 4):
+            setattr(self, "dres%d" % i, nn.Sequential(_conv_bn3d(f, f), nn.ReLU(), _conv_bn3d(f, f)))
+        self.classify = nn.Sequential(_conv_bn3d(f, f), nn.ReLU(),
+                                      nn.Conv3d(f, 1, kernel_size=3, padding=1, stride=1, bias=False))
+        _he_init(self)
+
+    def forward(self, volume):
+        if volume.shape[1] != self.in_channels:
+            raise AssertionError("Input volume should have correct # of channels !")
+        x = self.dres0(volume.contiguous())
+        for i in (1, 2, 3, 4):
+            x = getattr(self, "dres%d" % i)(x) + x
+        out = self.classify(x)
+        if self.if_normalize:
+            out = F.log_softmax(out, dim=2)
+        if self.up_sample_ratio is not None:
+            d, h, w = volume.shape[2:]
+            out = F.interpolate(out, (self.up_sample_ratio * d, h, w), mode="trilinear", align_corners=True)
+        return out
+
+
+# --------------------------------------------------------------------------- R-Net (DPV up-sampler)
+class DPVUpsampleNet(nn.Module):
+    """R-Net: 2-level conv / transposed-conv decoder over the DPV (D as channels) and the
+    1/4-, 1/2- and full-resolution image features; log-softmax over D at the end.
+
+    r_net(dpv[1,D,h,w] (probabilities), [feat 1/4, feat 1/2, image]) -> [1,D,4h,4w] log-prob
+    (Refine.py:24-107; transposed convs start as bilinear kernels, :121-132).
+    """
+
+    def __init__(self, C0, C1, C2, D=64, upsample_D=False):
+        super().__init__()
+        cin = D + C0
+        D0 = 2 * D if upsample_D else D
+        D1 = 2 * D0 if upsample_D else D
+        self.conv0 = _conv_lrelu(cin, cin)
+        self.conv0_1 = _conv_lrelu(cin, cin)
+        self.trans_conv0 = _deconv_lrelu(cin, D0)
+        self.conv1 = _conv_lrelu(D0 + C1, D0 + C1)
+        self.conv1_1 = _conv_lrelu(D0 + C1, D0 + C1)
+        self.trans_conv1 = _deconv_lrelu(D0 + C1, D1)
+        self.conv2 = _conv_lrelu(D1 + C2, D1 + C2)
+        self.conv2_1 = _conv_lrelu(D1 + C2, D1)
+        self.conv2_2 = nn.Conv2d(D1, D1, kernel_size=3, stride=1, padding=1, bias=True)
+        self._init()
+
+    def _init(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / fan))
+            elif isinstance(m, nn.ConvTranspose2d):
+                n = m.kernel_size[1]
+                factor = (n + 1) // 2
+                center = factor - 1 if n % 2 == 1 else factor - 0.5
+                og = np.ogrid[:n, :n]
+                bil = (1 - abs(og[0] - center) / factor) * (1 - abs(og[1] - center) / factor)
+                m.weight.data.copy_(torch.from_numpy(bil))
+
+    def forward(self, dpv_raw, img_features):
+        quarter, half, full = img_features
+        x = self.conv0_1(self.conv0(torch.cat([dpv_raw, quarter], dim=1)))
+        x = self.trans_conv0(x)
+        x = self.conv1_1(self.conv1(torch.cat([x, half], dim=1)))
+        x = self.trans_conv1(x)
+        x = self.conv2_2(self.conv2_1(self.conv2(torch.cat([x, full], dim=1))))
+        return F.log_softmax(x, dim=1)

@@ -1,0 +1,165 @@
+"""Typed torch-tensor wrappers over the C-ABI of libnrgbd_hip.so (include/nrgbd.h).
+
+PyTorch is used here only for device memory and the current HIP stream; every function below
+launches hand-written gfx950 kernels.  Inputs must be CUDA fp32 tensors — there is no CPU
+path: a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+DIST = {"L2": 0, "L1": 1}
+
+
+def _need(t, name, shape=None, strided=False):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise _lib.NrgbdError("%s is on %s: the plane-sweep path runs on the GPU only "
+                              "(no CPU fallback)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t if (strided or t.is_contiguous()) else t.contiguous()
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def version():
+    return _lib.load().nrgbd_version().decode()
+
+
+def padded_channels(C):
+    return (C + 3) // 4 * 4
+
+
+def pack_nhwc(feat, rgb=None, Cp=None):
+    """feat [N,Cf,h,w] (+ rgb [N,3,h*pool,w*pool]) -> texels [N,h,w,Cp] (nrgbd_pack_nhwc)."""
+    feat = _need(feat, "feat")
+    N, Cf, h, w = feat.shape
+    pool = 1
+    if rgb is not None:
+        rgb = _need(rgb, "rgb")
+        if rgb.shape[0] != N or rgb.shape[1] != 3 or rgb.shape[2] % h or rgb.shape[3] % w:
+            raise ValueError("rgb %s does not pool onto feat %s" % (tuple(rgb.shape), tuple(feat.shape)))
+        pool = rgb.shape[3] // w
+        if rgb.shape[2] // h != pool:
+            raise ValueError("anisotropic pooling is not supported")
+    if Cp is None:
+        Cp = padded_channels(Cf + (3 if rgb is not None else 0))
+    out = torch.empty((N, h, w, Cp), dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        rc = _lib.load().nrgbd_pack_nhwc(_p(feat), _p(rgb), _p(out), N, Cf, h, w, pool, Cp, _stream(feat))
+    _lib.check(rc, "nrgbd_pack_nhwc")
+    return out
+
+
+def costvol(ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, cx, cy, sigma, C, dist="L2",
+            align_corners=False, want_cost=True, want_logp=False):
+    """Fused warp + cost volume (+ log-softmax).  Returns (cost [D,h,w] | None, logp [D,h,w] | None)."""
+    src_nhwc = _need(src_nhwc, "src_nhwc")
+    V, h, w, Cp = src_nhwc.shape
+    ref_nhwc = _need(ref_nhwc, "ref_nhwc", (h, w, Cp))
+    KR = _need(KR, "KR").reshape(V, 9)
+    Kt = _need(Kt, "Kt", (V, 3))
+    rays = _need(rays, "rays", (3, h * w))
+    d_candi = _need(d_candi, "d_candi")
+    D = d_candi.numel()
+    dev = src_nhwc.device
+    cost = torch.empty((D, h, w), dtype=torch.float32, device=dev) if want_cost else None
+    logp = torch.empty((D, h, w), dtype=torch.float32, device=dev) if want_logp else None
+    with torch.cuda.device(dev):
+        rc = _lib.load().nrgbd_costvol_fwd(_p(ref_nhwc), _p(src_nhwc), _p(KR), _p(Kt), _p(rays),
+                                           _p(d_candi), float(cx), float(cy), float(sigma),
+                                           DIST[dist], int(bool(align_corners)), _p(cost), _p(logp),
+                                           V, int(C), Cp, D, h, w, _stream(src_nhwc))
+    _lib.check(rc, "nrgbd_costvol_fwd")
+    return cost, logp
+
+
+def warp_volume(src, src_strides, ref, ref_strides, KR, Kt, rays, d_candi, cx, cy, V, Cs, h, w,
+                bv_cur=None, bv_pred=None, align_corners=False):
+    """Plane-sweep warp with samples kept (+ K-Net input assembly) -> [V*Cs (+Cs) (+1), D, h, w].
+
+    `src` / `ref` are any CUDA fp32 tensors; `src_strides` = (view, channel, y, x) and
+    `ref_strides` = (channel, y, x) element strides from their data pointers.
+    """
+    src = _need(src, "src", strided=True)  # addressed through src_strides
+    KR = _need(KR, "KR").reshape(V, 9)
+    Kt = _need(Kt, "Kt", (V, 3))
+    rays = _need(rays, "rays", (3, h * w))
+    d_candi = _need(d_candi, "d_candi")
+    D = d_candi.numel()
+    n_ch = V * Cs
+    if ref is not None:
+        ref = _need(ref, "ref", strided=True)
+        n_ch += Cs
+    else:
+        ref_strides = (0, 0, 0)
+    if bv_cur is not None:
+        bv_cur = _need(bv_cur, "bv_cur").reshape(D, h, w)
+        bv_pred = _need(bv_pred, "bv_pred").reshape(D, h, w)
+        n_ch += 1
+    out = torch.empty((n_ch, D, h, w), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = _lib.load().nrgbd_warp_volume(_p(src), *[int(s) for s in src_strides], _p(ref),
+                                           *[int(s) for s in ref_strides], _p(KR), _p(Kt), _p(rays),
+                                           _p(d_candi), float(cx), float(cy), int(bool(align_corners)),
+                                           _p(bv_cur), _p(bv_pred), _p(out), V, Cs, D, h, w, _stream(src))
+    _lib.check(rc, "nrgbd_warp_volume")
+    return out
+
+
+def dpv_resample(dpv, T, rays, d_candi, tan_hh, tan_hv, z_half, z_radius, pad_value, clamp=(-1000.0, 0.0)):
+    """PREDICT: dpv [D,h,w], T [4,4] (device) -> resampled [D,h,w]."""
+    dpv = _need(dpv, "dpv")
+    D, h, w = dpv.shape
+    T = _need(T, "T").reshape(16)
+    rays = _need(rays, "rays", (3, h * w))
+    d_candi = _need(d_candi, "d_candi", (D,))
+    out = torch.empty_like(dpv)
+    lo, hi = clamp if clamp is not None else (0.0, 0.0)
+    with torch.cuda.device(dpv.device):
+        rc = _lib.load().nrgbd_dpv_resample(_p(dpv), _p(T), _p(rays), _p(d_candi), float(tan_hh),
+                                            float(tan_hv), float(z_half), float(z_radius),
+                                            float(pad_value), int(clamp is not None), float(lo),
+                                            float(hi), _p(out), D, h, w, _stream(dpv))
+    _lib.check(rc, "nrgbd_dpv_resample")
+    return out
+
+
+def logsoftmax_d(a, b=None, scale=1.0):
+    """log_softmax over dim 0 of scale*a (+ b); a, b [D, ...]."""
+    a = _need(a, "a")
+    D = a.shape[0]
+    n = a.numel() // D
+    if b is not None:
+        b = _need(b, "b", a.shape)
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        rc = _lib.load().nrgbd_logsoftmax_d(_p(a), _p(b), float(scale), _p(out), D, n, _stream(a))
+    _lib.check(rc, "nrgbd_logsoftmax_d")
+    return out
+
+
+def depth_regress(logp, d_candi, want_conf=True):
+    """logp [D, ...] -> (expected depth [...], max log-prob [...])."""
+    logp = _need(logp, "logp")
+    D = logp.shape[0]
+    n = logp.numel() // D
+    d_candi = _need(d_candi, "d_candi", (D,))
+    depth = torch.empty(logp.shape[1:], dtype=torch.float32, device=logp.device)
+    conf = torch.empty_like(depth) if want_conf else None
+    with torch.cuda.device(logp.device):
+        rc = _lib.load().nrgbd_depth_regress(_p(logp), _p(d_candi), _p(depth), _p(conf), D, n, _stream(logp))
+    _lib.check(rc, "nrgbd_depth_regress")
+    return depth, conf

@@ -1,0 +1,285 @@
+/*
+ * nrgbd_oracle.c — CPU restatement of the sampling arithmetic of NVlabs/neuralrgbd's
+ * plane-sweep depth path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may call it; neuralrgbd_amd/ never imports it.
+ *
+ * Parity pin: the reference ships no golden vectors or tests for this path (SURVEY.md §4,
+ * §8c).  The pin is the reference code itself run under torch 2.10 (CPU) in the build
+ * container: oracle/gen_golden.py imports the unmodified reference and writes
+ * tests/golden/ (.npz); tests/test_oracle.py checks every function below against them.
+ *
+ * Plain scalar fp32, one rounding per written operation (build with -ffp-contract=off),
+ * every function cites the reference lines it restates (paths relative to
+ * /root/reference/code).  The bilinear / trilinear sampling follows torch's
+ * F.grid_sample(mode='bilinear') as installed (ATen GridSampler.h:
+ * grid_sampler_unnormalize / clip_coordinates; CPU kernels GridSamplerKernel.cpp and
+ * GridSampler.cpp).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* thread control for the cpu_baseline leg of bench.py */
+int oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}
+
+/* ATen GridSampler.h grid_sampler_unnormalize */
+static inline float unnormalize(float g, int size, int align_corners) {
+    if (align_corners) return ((g + 1.f) / 2.f) * (float)(size - 1);
+    return ((g + 1.f) * (float)size - 1.f) / 2.f;
+}
+
+/* warping/homography.py:315-317 (term1 = K t, term2 = (K R) ray) and :433-445
+ * (P = term1 + term2*d; P /= (P_z + 1e-10); (u - cx)/cx, (v - cy)/cy). */
+static inline void sweep_coords(const float* KR, const float* Kt, float rx, float ry,
+                                float rz, float d, float cx, float cy, int w, int h,
+                                int align_corners, float* ix, float* iy) {
+    float t2x = KR[0] * rx; t2x = fmaf(KR[1], ry, t2x); t2x = fmaf(KR[2], rz, t2x);
+    float t2y = KR[3] * rx; t2y = fmaf(KR[4], ry, t2y); t2y = fmaf(KR[5], rz, t2y);
+    float t2z = KR[6] * rx; t2z = fmaf(KR[7], ry, t2z); t2z = fmaf(KR[8], rz, t2z);
+    float px = Kt[0] + t2x * d;
+    float py = Kt[1] + t2y * d;
+    float pz = Kt[2] + t2z * d;
+    float den = pz + 1e-10f;
+    float u = px / den, v = py / den;
+    float gx = (u - cx) / cx, gy = (v - cy) / cy;
+    *ix = unnormalize(gx, w, align_corners);
+    *iy = unnormalize(gy, h, align_corners);
+}
+
+typedef struct { int x[2], y[2]; float wx[2], wy[2]; int vx[2], vy[2]; } taps2d;
+
+/* F.grid_sample bilinear, padding_mode='zeros' (homography.py:447): floor, weights
+ * (1-w, w), a tap contributes only when inside [0,W-1]x[0,H-1]. */
+static inline void bilinear_taps(float ix, float iy, int w, int h, taps2d* t) {
+    float x0 = floorf(ix), y0 = floorf(iy);
+    float fx = ix - x0, fy = iy - y0;
+    t->wx[0] = 1.f - fx; t->wx[1] = fx;
+    t->wy[0] = 1.f - fy; t->wy[1] = fy;
+    for (int i = 0; i < 2; ++i) {
+        float xf = x0 + (float)i, yf = y0 + (float)i;
+        t->vx[i] = (xf >= 0.f && xf <= (float)(w - 1));
+        t->vy[i] = (yf >= 0.f && yf <= (float)(h - 1));
+        t->x[i] = t->vx[i] ? (int)xf : 0;
+        t->y[i] = t->vy[i] ? (int)yf : 0;
+    }
+}
+
+/*
+ * Plane-sweep cost volume.  warping/homography.py:293-331 (est_swp_volume_v4),
+ * :421-448 (_back_warp_homo_parallel), :81-87 (img_dis_L2_pard / L1).
+ * feat_ref [C][h][w], feat_src [V][C][h][w]  (NCHW, as the reference holds them),
+ * KR [V][9], Kt [V][3], rays [3][hw], cost [D][h][w].
+ */
+int oracle_costvol(const float* feat_ref, const float* feat_src, const float* KR,
+                   const float* Kt, const float* rays, const float* d_candi, float cx,
+                   float cy, float sigma, int dist, int align_corners, int V, int C,
+                   int D, int h, int w, float* cost) {
+    const size_t hw = (size_t)h * w;
+    /* The reference loops views outermost (:313) and adds each view's [D,h,w] slab to costV
+     * (:325); per output element that is cost = ((0 + S_0/sigma) + S_1/sigma) + ..., which is
+     * what the v-innermost loop below computes (element-wise identical, thread-parallel). */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 0; k < D; ++k) {
+        for (size_t p = 0; p < hw; ++p) {
+            float total = 0.f;                                           /* :306 */
+            for (int v = 0; v < V; ++v) {                                /* :313 */
+                const float* src = feat_src + (size_t)v * C * hw;
+                float ix, iy; taps2d t;
+                sweep_coords(KR + 9 * v, Kt + 3 * v, rays[p], rays[hw + p],
+                             rays[2 * hw + p], d_candi[k], cx, cy, w, h, align_corners,
+                             &ix, &iy);
+                bilinear_taps(ix, iy, w, h, &t);
+                float nw = t.wy[0] * t.wx[0], ne = t.wy[0] * t.wx[1];
+                float sw = t.wy[1] * t.wx[0], se = t.wy[1] * t.wx[1];
+                int vnw = t.vy[0] && t.vx[0], vne = t.vy[0] && t.vx[1];
+                int vsw = t.vy[1] && t.vx[0], vse = t.vy[1] && t.vx[1];
+                size_t onw = (size_t)t.y[0] * w + t.x[0], one = (size_t)t.y[0] * w + t.x[1];
+                size_t osw = (size_t)t.y[1] * w + t.x[0], ose = (size_t)t.y[1] * w + t.x[1];
+                float acc = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float* pl = src + (size_t)c * hw;
+                    float s = (vnw ? pl[onw] : 0.f) * nw + (vne ? pl[one] : 0.f) * ne
+                            + (vsw ? pl[osw] : 0.f) * sw + (vse ? pl[ose] : 0.f) * se;
+                    float df = s - feat_ref[(size_t)c * hw + p];
+                    acc += (dist == 0) ? df * df : fabsf(df);            /* :81-87 */
+                }
+                total = total + acc / sigma;                             /* :325 */
+            }
+            cost[(size_t)k * hw + p] = total;
+        }
+    }
+    return 0;
+}
+
+/*
+ * K-Net input warp with the samples kept.  warping/homography.py:234-280
+ * (warp_img_feats_v3; result transposed to [C][D][h][w], :261).
+ * src [V][Cs][h][w] -> out [V][Cs][D][h][w].
+ */
+int oracle_warp_volume(const float* src, const float* KR, const float* Kt,
+                       const float* rays, const float* d_candi, float cx, float cy,
+                       int align_corners, int V, int Cs, int D, int h, int w, float* out) {
+    const size_t hw = (size_t)h * w;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int v = 0; v < V; ++v)
+        for (int k = 0; k < D; ++k)
+            for (size_t p = 0; p < hw; ++p) {
+                float ix, iy; taps2d t;
+                sweep_coords(KR + 9 * v, Kt + 3 * v, rays[p], rays[hw + p],
+                             rays[2 * hw + p], d_candi[k], cx, cy, w, h, align_corners,
+                             &ix, &iy);
+                bilinear_taps(ix, iy, w, h, &t);
+                float nw = t.wy[0] * t.wx[0], ne = t.wy[0] * t.wx[1];
+                float sw = t.wy[1] * t.wx[0], se = t.wy[1] * t.wx[1];
+                for (int c = 0; c < Cs; ++c) {
+                    const float* pl = src + ((size_t)v * Cs + c) * hw;
+                    float a = (t.vy[0] && t.vx[0]) ? pl[(size_t)t.y[0] * w + t.x[0]] : 0.f;
+                    float b = (t.vy[0] && t.vx[1]) ? pl[(size_t)t.y[0] * w + t.x[1]] : 0.f;
+                    float cc = (t.vy[1] && t.vx[0]) ? pl[(size_t)t.y[1] * w + t.x[0]] : 0.f;
+                    float dd = (t.vy[1] && t.vx[1]) ? pl[(size_t)t.y[1] * w + t.x[1]] : 0.f;
+                    out[(((size_t)v * Cs + c) * D + k) * hw + p] = a * nw + b * ne + cc * sw + dd * se;
+                }
+            }
+    return 0;
+}
+
+/* ATen GridSampler.h clip_coordinates (padding_mode='border') */
+static inline float clipf(float x, int size) {
+    float hi = (float)(size - 1);
+    x = (x < 0.f) ? 0.f : x;        /* std::max(in, 0)          */
+    return (x < hi) ? x : hi;       /* std::min(size-1, .): NaN -> size-1 */
+}
+
+/* warping/homography.py:873-887 _set_vol_border: the 6 faces read as border_val */
+static inline float vol_at(const float* vol, int D, int h, int w, int z, int y, int x,
+                           float pad) {
+    if (z == 0 || y == 0 || x == 0 || z == D - 1 || y == h - 1 || x == w - 1) return pad;
+    return vol[((size_t)z * h + y) * w + x];
+}
+
+/*
+ * PREDICT: rigid 3-D resample of the DPV.  warping/homography.py:654-723
+ * (resample_vol_cuda with d_candi_new=None), :873-887 (_set_vol_border) and the clamp of
+ * test_utils/test_KVNet.py:54-59.  T is the row-major 4x4 rel_extM.
+ */
+int oracle_dpv_resample(const float* dpv, const float* T, const float* rays,
+                        const float* d_candi, float tan_hh, float tan_hv, float z_half,
+                        float z_radius, float pad, int do_clamp, float lo, float hi,
+                        int D, int h, int w, float* out) {
+    const size_t hw = (size_t)h * w;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < D; ++k)
+        for (size_t p = 0; p < hw; ++p) {
+            /* :679-682  X = d * ray */
+            float d = d_candi[k];
+            float X = d * rays[p], Y = d * rays[hw + p], Z = d * rays[2 * hw + p];
+            /* :698-702  [4x4] matmul [X Y Z 1] */
+            float q[4];
+            for (int r = 0; r < 4; ++r) {
+                float a = T[4 * r] * X;
+                a = fmaf(T[4 * r + 1], Y, a);
+                a = fmaf(T[4 * r + 2], Z, a);
+                a = fmaf(T[4 * r + 3], 1.f, a);
+                q[r] = a;
+            }
+            /* :705-707 */
+            float gx = q[0] / (q[2] + 1e-10f) / tan_hh;
+            float gy = q[1] / (q[2] + 1e-10f) / tan_hv;
+            float gz = (q[2] - z_half) / z_radius;
+            /* :710 */
+            float wq = q[3] + 1e-10f;
+            gx = gx / wq; gy = gy / wq; gz = gz / wq;
+            /* :716 grid_sample 3-D, bilinear, border, align_corners=False */
+            float fx = clipf(unnormalize(gx, w, 0), w);
+            float fy = clipf(unnormalize(gy, h, 0), h);
+            float fz = clipf(unnormalize(gz, D, 0), D);
+            float x0f = floorf(fx), y0f = floorf(fy), z0f = floorf(fz);
+            int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+            int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+            float ex = (x0f + 1.f) - fx, ey = (y0f + 1.f) - fy, ez = (z0f + 1.f) - fz;
+            float wx_ = fx - x0f, wy_ = fy - y0f, wz_ = fz - z0f;
+            /* GridSampler.cpp grid_sampler_3d_cpu_impl: tnw tne tsw tse bnw bne bsw bse */
+            float wt[8] = { ex * ey * ez, wx_ * ey * ez, ex * wy_ * ez, wx_ * wy_ * ez,
+                            ex * ey * wz_, wx_ * ey * wz_, ex * wy_ * wz_, wx_ * wy_ * wz_ };
+            int xs[8] = { x0, x1, x0, x1, x0, x1, x0, x1 };
+            int ys[8] = { y0, y0, y1, y1, y0, y0, y1, y1 };
+            int zs[8] = { z0, z0, z0, z0, z1, z1, z1, z1 };
+            float acc = 0.f;
+            for (int i = 0; i < 8; ++i)
+                if (xs[i] >= 0 && xs[i] < w && ys[i] >= 0 && ys[i] < h && zs[i] >= 0 && zs[i] < D)
+                    acc += vol_at(dpv, D, h, w, zs[i], ys[i], xs[i], pad) * wt[i];
+            if (do_clamp) { acc = acc < lo ? lo : acc; acc = acc > hi ? hi : acc; }
+            out[(size_t)k * hw + p] = acc;
+        }
+    return 0;
+}
+
+/* models/basic.py:299-300 and models/KVNET.py:172-173: log_softmax over D of scale*a + b */
+int oracle_logsoftmax_d(const float* a, const float* b, float scale, int D, size_t n,
+                        float* out) {
+#pragma omp parallel for schedule(static)
+    for (size_t p = 0; p < n; ++p) {
+        float m = -INFINITY;
+        for (int k = 0; k < D; ++k) {
+            float v = scale * a[(size_t)k * n + p];
+            if (b) v = v + b[(size_t)k * n + p];
+            m = v > m ? v : m;
+        }
+        float s = 0.f;
+        for (int k = 0; k < D; ++k) {
+            float v = scale * a[(size_t)k * n + p];
+            if (b) v = v + b[(size_t)k * n + p];
+            s += expf(v - m);
+        }
+        float ls = logf(s);
+        for (int k = 0; k < D; ++k) {
+            float v = scale * a[(size_t)k * n + p];
+            if (b) v = v + b[(size_t)k * n + p];
+            out[(size_t)k * n + p] = (v - m) - ls;
+        }
+    }
+    return 0;
+}
+
+/* mutils/misc.py:532-548 depth_val_regression (BV_log=True); conf = max_d (export_res.py:58-59) */
+int oracle_depth_regress(const float* logp, const float* d_candi, int D, size_t n,
+                         float* depth, float* conf) {
+    for (size_t p = 0; p < n; ++p) {
+        float acc = 0.f, m = -INFINITY;
+        for (int k = 0; k < D; ++k) {
+            float v = logp[(size_t)k * n + p];
+            acc = acc + expf(v) * d_candi[k];
+            m = v > m ? v : m;
+        }
+        if (depth) depth[p] = acc;
+        if (conf) conf[p] = m;
+    }
+    return 0;
+}
+
+/* models/basic.py:254-263 / models/KVNET.py:149-151: F.avg_pool2d(img, pool) */
+int oracle_avgpool(const float* img, int N, int C, int H, int W, int pool, float* out) {
+    int h = H / pool, w = W / pool;
+    for (int nc = 0; nc < N * C; ++nc)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                float s = 0.f;
+                for (int j = 0; j < pool; ++j)
+                    for (int i = 0; i < pool; ++i)
+                        s += img[((size_t)nc * H + (y * pool + j)) * W + (x * pool + i)];
+                out[((size_t)nc * h + y) * w + x] = s / (float)(pool * pool);
+            }
+    return 0;
+}
