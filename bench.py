@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""bench.py — depth frames/s of the plane-sweep path on MI355X + roofline of the fused warp kernel.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One *step* = one depth frame of one video stream = one call of the reference's
+test_utils/test_KVNet.py::test in the update branch: KVNET.forward with a valid BV_predict (D-Net,
+K-Net, DPV update, both R-Net calls) + the PREDICT resample.  Inputs are synthetic windows that are
+resident in HBM before the timed region; weights are seeded random (no checkpoints offline).
+Each rank streams its own independent video (replicas, no data-path collective) => weak scaling,
+value = all ranks' frames / max-over-ranks time.
+
+Workload (BASELINE.json configs[1]): plane-sweep grid 256x192 (image
+1024x768), 64 depth candidates, 5-frame window (1 reference + 4 sources), fp32.
+
+The JSON line carries
+  roofline      HBM roofline of the dominant sampling kernel (fused warp + cost volume + log-softmax):
+                algorithmic bytes 4[(V+1)*67*hw + D*hw] per launch / its mean launch duration, measured
+                with HIP events on the launch stream inside the timed steps (peak 8.0 TB/s);
+  cpu_baseline  the CPU oracle (oracle/kvnet_oracle.py: the reference algorithm restated on torch-CPU
+                + the C sampling oracle) timed on this node's host cores on ONE update frame of the
+                same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    "S": dict(H=256, W=384, D=64, d_min=0.1, d_max=5.0, name="ScanNet demo 384x256 image, grid 96x64x64"),
+    "B": dict(H=768, W=1024, D=64, d_min=0.1, d_max=5.0, name="plane-sweep grid 256x192x64cand (image 1024x768)"),
+    "K": dict(H=256, W=768, D=64, d_min=1.0, d_max=60.0, name="KITTI 768x256 image, grid 192x64x64"),
+    "H": dict(H=480, W=640, D=128, d_min=0.1, d_max=5.0, name="480x640 image, grid 160x120x128"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def costvol_bytes(V, C, D, h, w):
+    """Algorithmic bytes of the fused warp + cost-volume kernel."""
+    return 4 * ((V + 1) * C * h * w + D * h * w)
+
+
+class KernelTimer:
+    """HIP-event bracket around every launch of one op on torch's current stream (= the launch stream)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.on = False
+
+    def wrap(self, fn):
+        def timed(*a, **k):
+            if not self.on:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.pairs.append((e0, e1))
+            return out
+        return timed
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else None
+
+
+def cpu_baseline(cfg, cam, d_candi, sd, window, bv_pred, sigma):
+    """One update-branch frame of the SAME workload through the CPU oracle on all host cores."""
+    from oracle import cpu_oracle, kvnet_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cpu_oracle.set_threads(cores)
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    r, s, p = (t.cpu() for t in window)
+    t0 = time.time()
+    kvnet_oracle.step(sd_cpu, r, s, p, cam, d_candi, sigma, bv_pred.cpu())
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 update-branch frame (KVNET.forward + PREDICT) of config %s through oracle/kvnet_oracle.py, "
+                      "%.1f s wall" % (cfg, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import neuralrgbd_amd
+    from neuralrgbd_amd import camera, ops, synth
+    from neuralrgbd_amd.test_step import test as step_fn
+
+    cfg = CONFIGS[args.config]
+    H, W, D, V = cfg["H"], cfg["W"], cfg["D"], 4
+    h, w = H // 4, W // 4
+    sigma = 10.0
+    cam = camera.scannet_intrinsics(w, h) if args.config != "K" else camera.kitti_intrinsics(w, h)
+    d_candi = np.linspace(cfg["d_min"], cfg["d_max"], D)
+    model = neuralrgbd_amd.KVNET(64, cam, d_candi, sigma, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    sd = synth.seeded_state_dict(model, 0)
+    model.load_state_dict(sd)
+    model = model.to(dev)  # stays in train() mode like the reference
+
+    # a short ring of synthetic windows per rank, resident in HBM (different video per rank)
+    ring = [tuple(t.to(dev) for t in synth.noise_window(1000 * rank + i, H, W, V)) for i in range(2)]
+
+    timer = KernelTimer()
+    ops.costvol = timer.wrap(ops.costvol)
+
+    def frame(i, pred):
+        r, s, p = ring[i % len(ring)]
+        Rd = [{"img": r}]
+        Sd = [[{"img": s[0, v:v + 1]} for v in range(V)]]
+        out, nxt = step_fn(model, d_candi, [cam], 2, Rd, Sd, p, pred, R_net=True,
+                           dpv_valid=None if pred is None else True)
+        return nxt
+
+    pred = frame(0, None)  # first window of the stream: D-Net only, creates the filter state
+    for i in range(args.warmup):
+        pred = frame(i + 1, pred)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    timer.on = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pred = frame(i, pred)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(pred).all()), "filter state went non-finite"
+
+    if rank == 0:
+        k_ms = timer.mean_ms()
+        algo = costvol_bytes(V, 67, D, h, w)
+        achieved = algo / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "depth frames/sec @256x192x64cand, 5-view window; warp-kernel HBM GB/s vs peak",
+            "value": args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["name"], "config_id": args.config, "grid_hw": [h, w], "depth_candidates": D,
+                       "views": V + 1, "streams_per_gpu": 1, "parallelism": "replicas x%d (independent video streams)" % world},
+            "roofline": {"bound": "hbm", "kernel": "costvol_gather (fused warp + cost volume + log-softmax)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes": algo, "kernel_ms": k_ms, "launches_timed": len(timer.pairs),
+                         "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config, cam, d_candi, sd, ring[0], pred, sigma)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

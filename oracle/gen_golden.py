@@ -1,0 +1,144 @@
+"""Generate tests/golden/ from the UNMODIFIED reference (run in the build container only).
+
+    python -m oracle.gen_golden
+
+The reference ships no golden vectors for this path, so the pin is the reference
+code itself, imported from /root/reference with the two shims of oracle/ref_shim.py and run on
+CPU under the installed torch.  Outputs (small, committed):
+
+  ops_small.npz    est_swp_volume_v4 (L2 / L1), warp_img_feats_v3, resample_vol_cuda + clamp,
+                   log_softmax, depth_val_regression on a 24x40x16 grid (inputs included)
+  net_small.npz    two frames of the streaming filter through the reference's own test():
+                   first-frame branch, update branch, both PREDICT steps, R-Net (image 256x320, D=16;
+                   inputs are regenerated from seeds by neuralrgbd_amd.synth, weights by
+                   synth.seeded_state_dict — a checksum of both is stored)
+  scene_small.npz  D-Net on a rendered textured scene (true cost minimum), BV_cur + argmax
+  state_keys.json  the 459 state-dict keys and shapes of the reference KVNET
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neuralrgbd_amd import camera, synth  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+NET = dict(H=256, W=320, D=16, seeds=(3, 4), sigma=10.0, d_min=0.1, d_max=5.0, weight_seed=0)
+OPS = dict(h=24, w=40, D=16, V=4, C=11, seed=1, sigma=10.0)
+SCENE = dict(H=256, W=320, D=32, seed=11, sigma=10.0)
+
+
+def checksum(tensors):
+    return float(sum(float(t.double().abs().sum()) for t in tensors))
+
+
+def gen_ops(ref):
+    o = OPS
+    h, w, D, V, C = o["h"], o["w"], o["D"], o["V"], o["C"]
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(o["seed"])
+    feat_ref = torch.from_numpy(rng.standard_normal((1, C, h, w)).astype(np.float32))
+    feat_src = torch.from_numpy(rng.standard_normal((1, V, C, h, w)).astype(np.float32))
+    poses = torch.from_numpy(synth.random_poses(rng, V))
+    d_candi = np.linspace(0.1, 5, D)
+    R, t = poses[:, :3, :3].contiguous(), poses[:, :3, 3].contiguous()
+    H = ref.homography
+    cost_l2 = H.est_swp_volume_v4(feat_ref, feat_src, d_candi, R, t, cam, o["sigma"])[0]
+    cost_l1 = H.est_swp_volume_v4(feat_ref, feat_src, d_candi, R, t, cam, o["sigma"], feat_dist="L1")[0]
+    bv = torch.log_softmax(-cost_l2[None], dim=1)[0]
+    rgb = torch.from_numpy(rng.standard_normal((V, 3, h, w)).astype(np.float32))
+    warped = torch.stack(H.warp_img_feats_v3([rgb[v:v + 1] for v in range(V)], d_candi,
+                                             [R[v] for v in range(V)], [t[v] for v in range(V)], cam))
+    dpv = torch.log_softmax(torch.from_numpy(rng.standard_normal((1, D, h, w)).astype(np.float32)) * 3, 1)
+    T = torch.from_numpy(synth.random_pose(rng).astype(np.float32)).inverse()
+    pad = math.log(1. / D)
+    pred = H.resample_vol_cuda(dpv, T, cam_intrinsic=cam, d_candi=d_candi, padding_value=pad).clamp(max=0, min=-1000.)
+    depth = ref.misc.depth_val_regression(bv[None], d_candi, BV_log=True)[0]
+    K = cam["intrinsic_M_cuda"]
+    KR = torch.stack([K.matmul(R[v]) for v in range(V)]).reshape(V, 9)
+    Kt = torch.stack([K.matmul(t[v]) for v in range(V)])
+    np.savez(os.path.join(OUT, "ops_small.npz"),
+             feat_ref=feat_ref[0].numpy(), feat_src=feat_src[0].numpy(), poses=poses.numpy(), d_candi=d_candi,
+             KR=KR.numpy(), Kt=Kt.numpy(), sigma=o["sigma"], cost_l2=cost_l2.numpy(), cost_l1=cost_l1.numpy(),
+             bv=bv.numpy(), rgb=rgb.numpy(), warped=warped.numpy(), dpv=dpv[0].numpy(), T=T.numpy(),
+             pad=pad, pred=pred.numpy(), depth=depth.numpy())
+    print("ops_small: cost range", float(cost_l2.min()), float(cost_l2.max()))
+
+
+def run_stream(ref, model, cam, d_candi, windows):
+    """Frames through the reference's own step function (test_utils/test_KVNet.py::test)."""
+    outs = []
+    bv_pred = None
+    for (r, s, p) in windows:
+        Rd = [{"img": r}]
+        Sd = [[{"img": s[0, v:v + 1]} for v in range(s.shape[1])]]
+        dpv, nxt = ref.test_step.test(model, d_candi, [cam], 2, Rd, Sd, p, bv_pred, R_net=False)
+        refined, _ = ref.test_step.test(model, d_candi, [cam], 2, Rd, Sd, p, bv_pred, R_net=True)
+        outs.append((dpv, nxt, refined))
+        bv_pred = nxt
+    return outs
+
+
+def gen_net(ref):
+    n = NET
+    H, W, D = n["H"], n["W"], n["D"]
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(n["d_min"], n["d_max"], D)
+    with ref_shim.quiet():
+        model = ref.KVNET.KVNET(64, cam, d_candi, n["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(OUT, "state_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    sd = synth.seeded_state_dict(model, n["weight_seed"])
+    model.load_state_dict(sd)
+    windows = [synth.noise_window(s, H, W) for s in n["seeds"]]
+    (dpv1, pred1, ref1), (dpv2, pred2, ref2) = run_stream(ref, model, cam, d_candi, windows)
+    np.savez(os.path.join(OUT, "net_small.npz"),
+             bv_cur_f1=dpv1[0].numpy(), pred_f1=pred1[0].numpy(), dpv_f2=dpv2[0].numpy(), pred_f2=pred2[0].numpy(),
+             refined_f1_argmax=ref1[0].argmax(0).numpy().astype(np.uint8),
+             refined_f2_argmax=ref2[0].argmax(0).numpy().astype(np.uint8),
+             refined_f2_sub=ref2[0, :, ::4, ::4].numpy(),
+             weights_checksum=checksum(sd.values()),
+             inputs_checksum=checksum([w[0] for w in windows] + [w[1] for w in windows] + [w[2] for w in windows]))
+    print("net_small: DPV range", float(dpv2.min()), float(dpv2.max()))
+
+
+def gen_scene(ref):
+    s = SCENE
+    H, W, D = s["H"], s["W"], s["D"]
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    cam_full = camera.scannet_intrinsics(W, H)
+    d_candi = np.linspace(0.1, 5, D)
+    with ref_shim.quiet():
+        model = ref.KVNET.KVNET(64, cam, d_candi, s["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    model.load_state_dict(synth.seeded_state_dict(model, 0))
+    r, sr, p, depth = synth.rendered_window(s["seed"], H, W, cam_full)
+    with torch.no_grad():
+        bv, _ = model.d_net(r, sr, p)
+    np.savez(os.path.join(OUT, "scene_small.npz"), bv_cur=bv[0].numpy(),
+             argmax=bv[0].argmax(0).numpy().astype(np.uint8), depth_quarter=depth[2::4, 2::4],
+             inputs_checksum=checksum([r, sr, p]))
+    est = d_candi[bv[0].argmax(0).numpy()]
+    print("scene_small: median |depth err| of the D-Net argmax", float(np.median(np.abs(est - depth[2::4, 2::4]))))
+
+
+def main():
+    if not ref_shim.available():
+        raise SystemExit("reference not present: golden vectors can only be generated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_shim.load()
+    torch.manual_seed(0)
+    gen_ops(ref)
+    gen_net(ref)
+    gen_scene(ref)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests can only run where a device exists; everything else is CPU-only by construction
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_ops():
+    return dict(np.load(os.path.join(GOLDEN, "ops_small.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_net():
+    return dict(np.load(os.path.join(GOLDEN, "net_small.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_scene():
+    return dict(np.load(os.path.join(GOLDEN, "scene_small.npz")))
+
+
+def report(name, got, want, axis=0):
+    """max-abs, mean-abs and arg-max mismatch count (the three numbers BASELINE.md §3 asks for)."""
+    got = np.asarray(got, np.float32)
+    want = np.asarray(want, np.float32)
+    d = np.abs(got - want)
+    mism = int((got.argmax(axis) != want.argmax(axis)).sum())
+    print("[parity] %-28s max|d|=%.3e mean|d|=%.3e argmax-mismatch=%d/%d" %
+          (name, d.max(), d.mean(), mism, got.argmax(axis).size))
+    return float(d.max()), float(d.mean()), mism
+
+
+def near_tie_mismatches(got, want, tol, axis=0):
+    """Arg-max mismatches that are NOT explained by a near tie in the oracle volume: at a mismatching
+    pixel the oracle's own values at the two indices must differ by more than `tol`."""
+    got = np.asarray(got)
+    want = np.asarray(want)
+    ig, iw = got.argmax(axis), want.argmax(axis)
+    bad = ig != iw
+    if not bad.any():
+        return 0
+    vg = np.take_along_axis(want, np.expand_dims(ig, axis), axis).squeeze(axis)
+    vw = np.take_along_axis(want, np.expand_dims(iw, axis), axis).squeeze(axis)
+    return int((bad & (np.abs(vw - vg) > tol)).sum())

@@ -1,0 +1,201 @@
+"""HIP kernels (through the C-ABI of libnrgbd_hip.so) vs the CPU oracle and the golden vectors.
+
+Tolerances (fp32, written here as the contract): cost / log-prob volumes within 1e-4 absolute
+(BASELINE.json: "DPV floats within 1e-4"), arg-max / arg-min indices bit-exact except at near
+ties of the oracle's own values (counted and bounded), PREDICT resample within 1e-4.
+"""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import near_tie_mismatches, report
+from neuralrgbd_amd import camera, synth
+from oracle import cpu_oracle as co
+from oracle import gen_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ops():
+    from neuralrgbd_amd import ops
+    return ops
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, sigma, dist="L2", logp=False, align=False):
+    ops = _ops()
+    V, C = feat_src.shape[:2]
+    tex = ops.pack_nhwc(_dev(np.concatenate([feat_src, feat_ref[None]], 0)))
+    cost, lp = ops.costvol(tex[V], tex[:V], _dev(KR), _dev(Kt), _dev(rays), _dev(d_candi), cx, cy, sigma, C,
+                           dist=dist, align_corners=align, want_cost=True, want_logp=logp)
+    torch.cuda.synchronize()
+    return cost.cpu().numpy(), (lp.cpu().numpy() if logp else None)
+
+
+def test_library_is_the_hip_build():
+    ops = _ops()
+    assert "gfx950" in ops.version()
+    assert torch.cuda.is_available() and "gfx95" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+def test_golden_costvol_and_logsoftmax(golden_ops):
+    g = golden_ops
+    o = gen_golden.OPS
+    cam = camera.scannet_intrinsics(o["w"], o["h"])
+    rays = cam["unit_ray_array_2D"].numpy()
+    cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
+    for dist, key in (("L2", "cost_l2"), ("L1", "cost_l1")):
+        cost, lp = _gpu_costvol(g["feat_ref"], g["feat_src"], g["KR"], g["Kt"], rays, g["d_candi"], cx, cy,
+                                float(g["sigma"]), dist=dist, logp=True)
+        mx, _, mism = report("HIP costvol %s vs reference" % dist, -cost, -g[key])
+        assert mx < 1e-4 and mism == 0
+        if dist == "L2":
+            mx, _, mism = report("HIP fused log-softmax vs reference", lp, g["bv"])
+            assert mx < 1e-4 and mism == 0
+
+
+@pytest.mark.parametrize("h,w,D,V,C,seed", [
+    (24, 40, 16, 4, 11, 1),      # appendix-C shape
+    (17, 23, 5, 1, 3, 2),        # ragged: nothing divides the tile sizes, single view, one 16-B word
+    (33, 70, 64, 5, 67, 3),      # the real channel count, 5 source views
+    (64, 96, 64, 4, 67, 4),      # reference-native ScanNet grid (config S)
+    (8, 8, 2, 2, 4, 5),          # tiny
+    (40, 56, 130, 2, 9, 6),      # D > 128
+])
+def test_costvol_vs_oracle(h, w, D, V, C, seed):
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(seed)
+    feat_ref = rng.standard_normal((C, h, w)).astype(np.float32)
+    feat_src = rng.standard_normal((V, C, h, w)).astype(np.float32)
+    poses = synth.random_poses(rng, V)
+    KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+    d_candi = np.linspace(0.1, 5, D)
+    rays = cam["unit_ray_array_2D"].numpy()
+    cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
+    want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0)
+    want_lp = co.logsoftmax_d(want, scale=-1.0)
+    cost, lp = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, logp=True)
+    mx, _, _ = report("HIP costvol %dx%dx%d V%d C%d" % (h, w, D, V, C), -cost, -want)
+    assert mx < 1e-4
+    mx, mean, _ = report("HIP BV_cur", lp, want_lp)
+    assert mx < 1e-4 and mean < 1e-5
+    assert near_tie_mismatches(lp, want_lp, tol=1e-4) == 0
+
+
+def test_costvol_out_of_view_and_align_corners():
+    """Large motions push most taps outside the source image (zeros padding); legacy align_corners path."""
+    h, w, D, V, C = 20, 28, 8, 3, 6
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(9)
+    feat_ref = rng.standard_normal((C, h, w)).astype(np.float32)
+    feat_src = rng.standard_normal((V, C, h, w)).astype(np.float32)
+    poses = synth.random_poses(rng, V, rot_sigma=0.4, trans_sigma=1.0)
+    KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+    d_candi = np.linspace(0.1, 5, D)
+    rays = cam["unit_ray_array_2D"].numpy()
+    cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
+    for align in (False, True):
+        want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 1.0, align_corners=align)
+        got, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 1.0, align=align)
+        assert np.abs(got - want).max() < 1e-4
+
+
+def test_identity_pose_reproduces_reference_features():
+    """R = I, t = 0: every candidate samples the pixel itself, so the cost is ~0 everywhere."""
+    h, w, D, C = 16, 24, 4, 8
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(10)
+    feat = rng.standard_normal((C, h, w)).astype(np.float32)
+    poses = np.eye(4, dtype=np.float32)[None]
+    KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+    got, _ = _gpu_costvol(feat, feat[None], KR, Kt, cam["unit_ray_array_2D"].numpy(), np.linspace(.1, 5, D),
+                          cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2], 1.0)
+    assert got.max() < 1e-6
+
+
+def test_pack_nhwc_with_pooled_rgb():
+    ops = _ops()
+    rng = np.random.RandomState(11)
+    N, Cf, h, w, pool = 3, 6, 10, 70, 4
+    feat = rng.standard_normal((N, Cf, h, w)).astype(np.float32)
+    rgb = rng.standard_normal((N, 3, h * pool, w * pool)).astype(np.float32)
+    tex = ops.pack_nhwc(_dev(feat), _dev(rgb)).cpu().numpy()
+    assert tex.shape == (N, h, w, 12)
+    assert np.array_equal(tex[..., :Cf], feat.transpose(0, 2, 3, 1))
+    assert np.abs(tex[..., Cf:Cf + 3] - co.avgpool(rgb, pool).transpose(0, 2, 3, 1)).max() < 1e-6
+    assert np.all(tex[..., Cf + 3:] == 0)
+
+
+def test_warp_volume_golden_and_assembly(golden_ops):
+    ops = _ops()
+    g = golden_ops
+    o = gen_golden.OPS
+    cam = camera.scannet_intrinsics(o["w"], o["h"])
+    V, D, h, w = o["V"], o["D"], o["h"], o["w"]
+    rgb = _dev(g["rgb"])
+    bv_cur, bv_pred = _dev(g["bv"]), _dev(g["pred"])
+    ref = _dev(g["rgb"][0])
+    vol = ops.warp_volume(rgb, (3 * h * w, h * w, w, 1), ref, (h * w, w, 1), _dev(g["KR"]), _dev(g["Kt"]),
+                          _dev(cam["unit_ray_array_2D"].numpy()), _dev(g["d_candi"]),
+                          cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2], V, 3, h, w,
+                          bv_cur=bv_cur, bv_pred=bv_pred).cpu().numpy()
+    assert vol.shape == (3 * V + 4, D, h, w)
+    assert np.abs(vol[:3 * V].reshape(V, 3, D, h, w) - g["warped"]).max() < 1e-5
+    assert np.array_equal(vol[3 * V:3 * V + 3], np.broadcast_to(g["rgb"][0][:, None], (3, D, h, w)))
+    assert np.array_equal(vol[-1], g["bv"] - g["pred"])
+
+
+def test_dpv_resample_golden_and_oracle(golden_ops):
+    ops = _ops()
+    g = golden_ops
+    o = gen_golden.OPS
+    cam = camera.scannet_intrinsics(o["w"], o["h"])
+    from neuralrgbd_amd import homography as H
+    z_half, z_rad = H.z_range(g["d_candi"])
+    tan_hh, tan_hv = math.tan(math.radians(cam["hfov"]) * .5), math.tan(math.radians(cam["vfov"]) * .5)
+    got = ops.dpv_resample(_dev(g["dpv"]), _dev(g["T"]), _dev(cam["unit_ray_array_2D"].numpy()), _dev(g["d_candi"]),
+                           tan_hh, tan_hv, z_half, z_rad, float(g["pad"])).cpu().numpy()
+    mx, mean, mism = report("HIP PREDICT vs reference", got, g["pred"])
+    assert mx < 1e-4 and mism == 0
+    # a larger motion: many points leave the frustum (border clamp), others hit the padded faces
+    rng = np.random.RandomState(12)
+    T = np.linalg.inv(synth.random_pose(rng, 0.2, 0.5)).astype(np.float32)
+    want = co.dpv_resample(g["dpv"], T, cam["unit_ray_array_2D"].numpy(), g["d_candi"], tan_hh, tan_hv, float(g["pad"]))
+    got = ops.dpv_resample(_dev(g["dpv"]), _dev(T), _dev(cam["unit_ray_array_2D"].numpy()), _dev(g["d_candi"]),
+                           tan_hh, tan_hv, z_half, z_rad, float(g["pad"])).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-4
+
+
+@pytest.mark.parametrize("D,n", [(64, 1000), (16, 37), (128, 513), (200, 70)])
+def test_logsoftmax_update_and_depth_regress(D, n):
+    ops = _ops()
+    rng = np.random.RandomState(D + n)
+    a = (rng.standard_normal((D, n)) * 5).astype(np.float32)
+    b = np.log(np.abs(rng.standard_normal((D, n))) + 1e-3).astype(np.float32)
+    got = ops.logsoftmax_d(_dev(a), _dev(b)).cpu().numpy()
+    want = co.logsoftmax_d(a, b)
+    assert np.abs(got - want).max() < 2e-5
+    assert np.abs(np.exp(got.astype(np.float64)).sum(0) - 1).max() < 1e-5
+    d = np.linspace(.1, 5, D)
+    depth, conf = ops.depth_regress(_dev(want), _dev(d))
+    wd, wc = co.depth_regress(want, d)
+    assert np.abs(depth.cpu().numpy() - wd).max() < 1e-5 and np.array_equal(conf.cpu().numpy(), wc)
+
+
+def test_argument_errors_and_cpu_tensors_fail_loudly():
+    from neuralrgbd_amd import _lib
+    ops = _ops()
+    with pytest.raises(_lib.NrgbdError):
+        ops.logsoftmax_d(torch.zeros(4, 4))  # CPU tensor: no fallback
+    lib = _lib.load()
+    assert lib.nrgbd_logsoftmax_d(None, None, ctypes.c_float(1), None, 4, 4, None) == -1
+    x = torch.zeros(8, 8, device=DEV)
+    assert lib.nrgbd_logsoftmax_d(ctypes.c_void_p(x.data_ptr()), None, ctypes.c_float(1),
+                                  ctypes.c_void_p(x.data_ptr()), 0, 8, None) == -2

@@ -1,0 +1,97 @@
+"""The CPU oracle against the golden vectors generated from the unmodified reference
+(oracle/gen_golden.py).  CPU only; this is what pins the oracle (prompt §3)."""
+import math
+
+import numpy as np
+import torch
+
+from conftest import report
+from neuralrgbd_amd import camera, synth
+from oracle import cpu_oracle as co
+from oracle import gen_golden, kvnet_oracle as ko
+
+
+def _cam_ops():
+    o = gen_golden.OPS
+    return camera.scannet_intrinsics(o["w"], o["h"])
+
+
+def test_costvol_l2_l1(golden_ops):
+    g, cam = golden_ops, _cam_ops()
+    rays = cam["unit_ray_array_2D"].numpy()
+    cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
+    for dist, key in (("L2", "cost_l2"), ("L1", "cost_l1")):
+        got = co.costvol(g["feat_ref"], g["feat_src"], g["KR"], g["Kt"], rays, g["d_candi"], cx, cy,
+                         float(g["sigma"]), dist=dist)
+        mx, _, _ = report("oracle costvol " + dist, -got, -g[key])
+        assert mx < 2e-5  # costs up to 16.6: a few fp32 ulps of summation-order noise
+        assert (got.argmin(0) != g[key].argmin(0)).sum() == 0
+
+
+def test_logsoftmax_and_depth(golden_ops):
+    g = golden_ops
+    bv = co.logsoftmax_d(g["cost_l2"], scale=-1.0)
+    mx, _, mism = report("oracle log_softmax", bv, g["bv"])
+    assert mx < 1e-5 and mism == 0
+    depth, conf = co.depth_regress(g["bv"], g["d_candi"])
+    assert np.abs(depth - g["depth"]).max() < 1e-5
+    assert np.array_equal(conf, g["bv"].max(0))
+
+
+def test_warp_volume(golden_ops):
+    g, cam = golden_ops, _cam_ops()
+    got = co.warp_volume(g["rgb"], g["KR"], g["Kt"], cam["unit_ray_array_2D"].numpy(), g["d_candi"],
+                         cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2])
+    assert got.shape == g["warped"].shape  # [V,3,D,h,w]
+    assert np.abs(got - g["warped"]).max() < 1e-5
+
+
+def test_dpv_resample_bit_exact(golden_ops):
+    g, cam = golden_ops, _cam_ops()
+    got = co.dpv_resample(g["dpv"], g["T"], cam["unit_ray_array_2D"].numpy(), g["d_candi"],
+                          math.tan(math.radians(cam["hfov"]) * .5), math.tan(math.radians(cam["vfov"]) * .5),
+                          float(g["pad"]))
+    assert np.array_equal(got, g["pred"])  # the 3-D sampler restatement is bit-identical to the reference
+
+
+def _net_setup(n):
+    cam = camera.scannet_intrinsics(n["W"] // 4, n["H"] // 4)
+    d_candi = np.linspace(n["d_min"], n["d_max"], n["D"])
+    import neuralrgbd_amd
+    model = neuralrgbd_amd.KVNET(64, cam, d_candi, n["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    sd = synth.seeded_state_dict(model, n["weight_seed"])
+    return cam, d_candi, sd
+
+
+def test_whole_path_two_frames(golden_net):
+    """Torch-CPU restatement of KVNET.forward + PREDICT vs the reference's own test() on two frames."""
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    n, g = gen_golden.NET, golden_net
+    cam, d_candi, sd = _net_setup(n)
+    assert abs(gen_golden.checksum(sd.values()) - float(g["weights_checksum"])) < 1e-6 * float(g["weights_checksum"])
+    w1, w2 = (synth.noise_window(s, n["H"], n["W"]) for s in n["seeds"])
+    o1 = ko.step(sd, *w1, cam, d_candi, n["sigma"], None)
+    o2 = ko.step(sd, *w2, cam, d_candi, n["sigma"], o1[3])
+    checks = [("BV_cur f1", o1[2][0], g["bv_cur_f1"], 2e-4), ("BV_predict f1", o1[3][0], g["pred_f1"], 2e-4),
+              ("DPV f2", o2[1][0], g["dpv_f2"], 5e-4), ("BV_predict f2", o2[3][0], g["pred_f2"], 5e-4)]
+    for name, got, want, tol in checks:
+        mx, mean, mism = report("oracle " + name, got.numpy(), want)
+        assert mx < tol and mean < 1e-4 and mism == 0
+    assert (o2[0][0].argmax(0).numpy() != g["refined_f2_argmax"]).sum() == 0
+    assert np.abs(o2[0][0, :, ::4, ::4].numpy() - g["refined_f2_sub"]).max() < 1e-4
+
+
+def test_rendered_scene(golden_scene):
+    s, g = gen_golden.SCENE, golden_scene
+    cam = camera.scannet_intrinsics(s["W"] // 4, s["H"] // 4)
+    cam_full = camera.scannet_intrinsics(s["W"], s["H"])
+    d_candi = np.linspace(0.1, 5, s["D"])
+    import neuralrgbd_amd
+    model = neuralrgbd_amd.KVNET(64, cam, d_candi, s["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    sd = synth.seeded_state_dict(model, 0)
+    r, sr, p, depth = synth.rendered_window(s["seed"], s["H"], s["W"], cam_full)
+    assert abs(gen_golden.checksum([r, sr, p]) - float(g["inputs_checksum"])) < 1e-6 * float(g["inputs_checksum"])
+    with torch.no_grad():
+        bv, _, _ = ko.dnet(sd, r, sr, p, cam, d_candi, s["sigma"])
+    mx, mean, mism = report("oracle scene BV_cur", bv[0].numpy(), g["bv_cur"])
+    assert mx < 5e-4 and mean < 1e-4 and mism == 0

@@ -1,0 +1,65 @@
+"""Oracle vs the LIVE reference (only where /root/reference exists, i.e. the build container):
+fresh seeds and shapes beyond the committed golden vectors."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import report
+from neuralrgbd_amd import camera, synth
+from oracle import cpu_oracle as co
+from oracle import ref_shim
+
+pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="reference not present on this machine")
+
+
+@pytest.mark.parametrize("h,w,D,V,C,seed", [(16, 24, 8, 2, 5, 21), (20, 36, 12, 5, 7, 22), (9, 13, 4, 1, 3, 23)])
+def test_ops_fresh_shapes(h, w, D, V, C, seed):
+    ref = ref_shim.load()
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(seed)
+    feat_ref = torch.from_numpy(rng.standard_normal((1, C, h, w)).astype(np.float32))
+    feat_src = torch.from_numpy(rng.standard_normal((1, V, C, h, w)).astype(np.float32))
+    poses = torch.from_numpy(synth.random_poses(rng, V, rot_sigma=0.05, trans_sigma=0.2))
+    d_candi = np.linspace(0.3, 8, D)
+    R, t = poses[:, :3, :3].contiguous(), poses[:, :3, 3].contiguous()
+    want = ref.homography.est_swp_volume_v4(feat_ref, feat_src, d_candi, R, t, cam, 3.0)[0].numpy()
+    K = cam["intrinsic_M_cuda"]
+    KR = torch.stack([K.matmul(R[v]) for v in range(V)]).reshape(V, 9).numpy()
+    Kt = torch.stack([K.matmul(t[v]) for v in range(V)]).numpy()
+    got = co.costvol(feat_ref[0].numpy(), feat_src[0].numpy(), KR, Kt, cam["unit_ray_array_2D"].numpy(), d_candi,
+                     cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2], 3.0)
+    mx, _, _ = report("oracle vs ref costvol", -got, -want)
+    assert mx < 1e-4 * max(1.0, float(np.abs(want).max()))
+
+    dpv = torch.log_softmax(torch.from_numpy(rng.standard_normal((1, D, h, w)).astype(np.float32)) * 4, 1)
+    T = torch.from_numpy(synth.random_pose(rng, 0.05, 0.2).astype(np.float32)).inverse()
+    pad = math.log(1. / D)
+    want = ref.homography.resample_vol_cuda(dpv, T, cam_intrinsic=cam, d_candi=d_candi, padding_value=pad) \
+        .clamp(max=0, min=-1000.).numpy()
+    got = co.dpv_resample(dpv[0].numpy(), T.numpy(), cam["unit_ray_array_2D"].numpy(), d_candi,
+                          math.tan(math.radians(cam["hfov"]) * .5), math.tan(math.radians(cam["vfov"]) * .5), pad)
+    assert np.array_equal(got, want)
+
+
+def test_camera_dict_matches_reference_loop():
+    ref = ref_shim.load()
+    for (w, h) in ((40, 24), (96, 64)):
+        cam = camera.scannet_intrinsics(w, h)
+        rays = ref.View.normalised_pixel_to_ray_array(width=w, height=h, hfov=cam["hfov"], vfov=cam["vfov"],
+                                                      normalize_z=True)
+        assert np.array_equal(rays, cam["unit_ray_array"])
+
+
+def test_state_dict_keys_match_live_reference():
+    import neuralrgbd_amd
+    ref = ref_shim.load()
+    cam = camera.scannet_intrinsics(96, 64)
+    d = np.linspace(.1, 5, 64)
+    with ref_shim.quiet():
+        m_ref = ref.KVNET.KVNET(64, cam, d, 10., 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    mine = neuralrgbd_amd.KVNET(64, cam, d, 10., 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    a = {k: tuple(v.shape) for k, v in m_ref.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
+    assert a == b and len(a) == 459
