@@ -11,23 +11,12 @@
 // through L1/L2.  Source texels are gathered straight from the NHWC tensor with 16-byte loads.
 // The per-candidate costs of the tile are parked in LDS so that the log-softmax over all D
 // candidates is taken in the same launch.
-#include "common.hpp"
+#include <cstdlib>
+
+#include "costvol.hpp"
 
 namespace nrgbd {
 
-struct CostvolArgs {
-    const float* ref;      // [h][w][Cp]
-    const float* src;      // [V][h][w][Cp]
-    const float* KR;       // [V][9]
-    const float* Kt;       // [V][3]
-    const float* rays;     // [3][hw]
-    const float* d_candi;  // [D]
-    float* out_cost;       // [D][hw] or null
-    float* out_logp;       // [D][hw] or null
-    float cx, cy, sigma;
-    int dist, align;
-    int V, C, Cp, D, h, w;
-};
 
 // CP4 = Cp/4 when the reference texel is cached in registers, 0 = generic (re-read per use).
 template <int TW, int TH, int KS, int CP4>
@@ -182,8 +171,20 @@ extern "C" int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc, c
     if ((reinterpret_cast<uintptr_t>(ref_nhwc) | reinterpret_cast<uintptr_t>(src_nhwc)) & 15) return NRGBD_E_ALIGN;
     if (dist != NRGBD_DIST_L2 && dist != NRGBD_DIST_L1) return NRGBD_E_ARG;
     CostvolArgs a{ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, out_cost, out_logp, cx, cy, sigma,
-                  dist, align_corners, V, C, Cp, D, h, w};
+                  dist, align_corners, V, C, Cp, D, h, w, 0};
+    if (const char* ab = getenv("NRGBD_ABLATE")) a.debug = atoi(ab);
     hipStream_t s = (hipStream_t)stream;
+    // Generation 2 (LDS-staged) whenever Cp/4 has an instantiation; NRGBD_COSTVOL=gather forces
+    // generation 1 (kept as the general fallback and as the A/B baseline).
+    const char* force = getenv("NRGBD_COSTVOL");
+    const bool want_gather = force && force[0] == 'g';
+    if (!want_gather && costvol_lds_supported(Cp >> 2)) {
+        int rc = launch_costvol_lds(a, s);
+        if (rc != NRGBD_OK) return rc;
+        if (out_logp)  // log_softmax(-cost) over D (models/basic.py:299-300); in place when only logp is wanted
+            return launch_logsoftmax_d(out_cost ? out_cost : out_logp, nullptr, -1.f, out_logp, D, (size_t)h * w, s);
+        return NRGBD_OK;
+    }
     // Enough workgroups to cover 256 CUs: small grids use 16-pixel tiles with 4 depth sub-groups
     // per wave, large grids 64-pixel tiles.
     const long tiles64 = (long)ceil_div(w, 16) * ceil_div(h, 4);

@@ -1,7 +1,7 @@
 // softmax.hip — per-pixel reductions over the depth axis of a [D][n] volume (K4, K9, K13).
 // HBM-bound: lanes run along the pixel axis (coalesced), each lane walks the D candidates of its
 // pixel; for D <= 128 the column is held in registers so the volume is read once, written once.
-#include "common.hpp"
+#include "costvol.hpp"
 
 namespace nrgbd {
 
@@ -60,23 +60,26 @@ __global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restr
     if (conf) conf[p] = m;
 }
 
+int launch_logsoftmax_d(const float* a, const float* b, float scale, float* out, int D, size_t n,
+                        hipStream_t s) {
+    dim3 grid(ceil_div((long)n, 256));
+    if (D <= 64)
+        hipLaunchKernelGGL(logsoftmax_d_kernel<64>, grid, dim3(256), 0, s, a, b, scale, out, D, n);
+    else if (D <= 128)
+        hipLaunchKernelGGL(logsoftmax_d_kernel<128>, grid, dim3(256), 0, s, a, b, scale, out, D, n);
+    else
+        hipLaunchKernelGGL(logsoftmax_d_kernel<0>, grid, dim3(256), 0, s, a, b, scale, out, D, n);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
 }  // namespace nrgbd
 
 extern "C" int nrgbd_logsoftmax_d(const float* a, const float* b, float scale, float* out, int D,
                                   long n, void* stream) {
-    using namespace nrgbd;
     if (!a || !out) return NRGBD_E_NULL;
     if (D <= 0 || n <= 0) return NRGBD_E_SHAPE;
-    dim3 grid(ceil_div(n, 256));
-    hipStream_t s = (hipStream_t)stream;
-    if (D <= 64)
-        hipLaunchKernelGGL(logsoftmax_d_kernel<64>, grid, dim3(256), 0, s, a, b, scale, out, D, (size_t)n);
-    else if (D <= 128)
-        hipLaunchKernelGGL(logsoftmax_d_kernel<128>, grid, dim3(256), 0, s, a, b, scale, out, D, (size_t)n);
-    else
-        hipLaunchKernelGGL(logsoftmax_d_kernel<0>, grid, dim3(256), 0, s, a, b, scale, out, D, (size_t)n);
-    NRGBD_CHECK_LAUNCH();
-    return NRGBD_OK;
+    return nrgbd::launch_logsoftmax_d(a, b, scale, out, D, (size_t)n, (hipStream_t)stream);
 }
 
 extern "C" int nrgbd_depth_regress(const float* logp, const float* d_candi, float* depth,

@@ -61,6 +61,14 @@ def test_golden_costvol_and_logsoftmax(golden_ops):
             assert mx < 1e-4 and mism == 0
 
 
+@pytest.fixture(params=["lds", "gather"])
+def costvol_generation(request, monkeypatch):
+    """Both generations of the fused kernel must satisfy the same parity contract (NRGBD_COSTVOL is
+    read per call by nrgbd_costvol_fwd)."""
+    monkeypatch.setenv("NRGBD_COSTVOL", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("h,w,D,V,C,seed", [
     (24, 40, 16, 4, 11, 1),      # appendix-C shape
     (17, 23, 5, 1, 3, 2),        # ragged: nothing divides the tile sizes, single view, one 16-B word
@@ -69,7 +77,7 @@ def test_golden_costvol_and_logsoftmax(golden_ops):
     (8, 8, 2, 2, 4, 5),          # tiny
     (40, 56, 130, 2, 9, 6),      # D > 128
 ])
-def test_costvol_vs_oracle(h, w, D, V, C, seed):
+def test_costvol_vs_oracle(h, w, D, V, C, seed, costvol_generation):
     cam = camera.scannet_intrinsics(w, h)
     rng = np.random.RandomState(seed)
     feat_ref = rng.standard_normal((C, h, w)).astype(np.float32)
@@ -89,7 +97,7 @@ def test_costvol_vs_oracle(h, w, D, V, C, seed):
     assert near_tie_mismatches(lp, want_lp, tol=1e-4) == 0
 
 
-def test_costvol_out_of_view_and_align_corners():
+def test_costvol_out_of_view_and_align_corners(costvol_generation):
     """Large motions push most taps outside the source image (zeros padding); legacy align_corners path."""
     h, w, D, V, C = 20, 28, 8, 3, 6
     cam = camera.scannet_intrinsics(w, h)
@@ -105,6 +113,28 @@ def test_costvol_out_of_view_and_align_corners():
         want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 1.0, align_corners=align)
         got, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 1.0, align=align)
         assert np.abs(got - want).max() < 1e-4
+
+
+def test_costvol_extreme_zoom_uses_gather_fallback():
+    """Forward motion comparable to the nearest depth: the tile footprint of the nearest candidates
+    exceeds the LDS patch (and for some tiles the plane crosses the source camera), which exercises the
+    per-candidate split and the direct-gather fallback of the LDS generation."""
+    h, w, D, V, C = 48, 64, 16, 2, 67
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(13)
+    feat_ref = rng.standard_normal((C, h, w)).astype(np.float32)
+    feat_src = rng.standard_normal((V, C, h, w)).astype(np.float32)
+    poses = synth.random_poses(rng, V)
+    poses[0, :3, 3] = (0.01, -0.02, -0.085)  # source camera 8.5 cm in front: 6.7x zoom at d = 0.1
+    poses[1, :3, 3] = (0.02, 0.01, 0.12)     # ... and 12 cm behind
+    KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+    d_candi = np.linspace(0.1, 5, D)
+    rays = cam["unit_ray_array_2D"].numpy()
+    cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
+    want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0)
+    got, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0)
+    mx, _, _ = report("HIP costvol extreme zoom", -got, -want)
+    assert mx < 1e-4
 
 
 def test_identity_pose_reproduces_reference_features():
