@@ -99,13 +99,16 @@ int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc,
  *        channel v*Cs+c   = warped source v, channel c, at depth k
  *        next Cs channels = ref[c] repeated over D
  *        last channel     = bv_cur - bv_pred
+ *   channels_last: 0 = out [Ch][D][h][w] (the torch layout of KVNET.py:166),
+ *                  1 = out [D][h][w][Ch] (the layout nrgbd_conv3d_3x3x3_f32 consumes)
  */
 int nrgbd_warp_volume(const float* src, long sv, long sc, long sy, long sx,
                       const float* ref, long rc, long ry, long rx,
                       const float* KR, const float* Kt, const float* rays,
                       const float* d_candi, float cx, float cy, int align_corners,
                       const float* bv_cur, const float* bv_pred,
-                      float* out, int V, int Cs, int D, int h, int w, void* stream);
+                      float* out, int V, int Cs, int D, int h, int w, int channels_last,
+                      void* stream);
 
 /*
  * nrgbd_dpv_resample — PREDICT step: rigid 3-D resample of the DPV into the next frame.
@@ -146,6 +149,40 @@ int nrgbd_logsoftmax_d(const float* a, const float* b, float scale, float* out,
  */
 int nrgbd_depth_regress(const float* logp, const float* d_candi,
                         float* depth, float* conf, int D, long n, void* stream);
+
+/*
+ * K-Net: 3x3x3 convolution (stride 1, padding 1, no bias) on the fp32 matrix cores, with the
+ * BatchNorm3d / ReLU / residual work of the reference fused around it.
+ * Replaces, per layer of models/basic.py:71-94,113-132 (KV_NET_BASIC): nn.Conv3d + nn.BatchNorm3d
+ * (psm_submodule.py:19-23, batch statistics) + nn.ReLU + the residual adds of :127-131.
+ *
+ * Activations are channels-last [D][H][W][C].  A layer reads its input as
+ *       in = act(x * s + t)  [+ act(res * s' + t')]           (s,t per channel; act = ReLU or identity)
+ * i.e. the normalise/affine/ReLU/add of the PREVIOUS layers is applied on the fly while the input
+ * tile is loaded; `materialized` (optional) receives `in` for use as a later residual.  The raw
+ * convolution output is written to y together with per-workgroup partial sums for the batch statistics:
+ *   stats [nrgbd_conv3d_workgroups(D,H,W)][128]   (sum of y per channel, then sum of y^2 per channel)
+ * nrgbd_bn3d_finalize reduces them (in double) to scale_shift [64][2] = (gamma*invstd, beta - mean*gamma*invstd)
+ * and applies the train-mode running-statistics update (momentum, unbiased variance).
+ *   x_ss / res_ss [Cin][2] or NULL (identity); x_relu / res_relu 0|1; res, materialized, stats may be NULL
+ *   w_packed: nrgbd_conv3d_pack_weights(w [64][Cin][3][3][3]) -> [27*Cin*64] floats
+ *   Cin in {16, 64}; Cout = 64.
+ * nrgbd_conv3d_3x3x3_cout1_f32 is the last layer (Conv3d(64,1), basic.py:92-94):
+ *   w_tap_major [27][64] = w[0][c][tap] transposed; y [D][H][W].
+ */
+int nrgbd_conv3d_workgroups(int D, int H, int W);
+int nrgbd_conv3d_pack_weights(const float* w, float* w_packed, int Cin, void* stream);
+int nrgbd_conv3d_3x3x3_f32(const float* x, const float* x_ss, int x_relu,
+                           const float* res, const float* res_ss, int res_relu,
+                           float* materialized, const float* w_packed, float* y, float* stats,
+                           int D, int H, int W, int Cin, int Cout, void* stream);
+int nrgbd_conv3d_3x3x3_cout1_f32(const float* x, const float* x_ss, int x_relu,
+                                 const float* res, const float* res_ss, int res_relu,
+                                 const float* w_tap_major, float* y,
+                                 int D, int H, int W, int Cin, void* stream);
+int nrgbd_bn3d_finalize(const float* stats, int num_workgroups, long count,
+                        const float* gamma, const float* beta, float eps, float momentum,
+                        float* running_mean, float* running_var, float* scale_shift, void* stream);
 
 #ifdef __cplusplus
 }

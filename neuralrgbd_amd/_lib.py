@@ -23,10 +23,15 @@ SIGNATURES = {
     "nrgbd_costvol_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P,
                                _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_warp_volume": (_I, [_P, _L, _L, _L, _L, _P, _L, _L, _L, _P, _P, _P, _P, _F, _F, _I,
-                               _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+                               _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_dpv_resample": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _I, _I, _P]),
     "nrgbd_logsoftmax_d": (_I, [_P, _P, _F, _P, _I, _L, _P]),
     "nrgbd_depth_regress": (_I, [_P, _P, _P, _P, _I, _L, _P]),
+    "nrgbd_conv3d_workgroups": (_I, [_I, _I, _I]),
+    "nrgbd_conv3d_pack_weights": (_I, [_P, _P, _I, _P]),
+    "nrgbd_conv3d_3x3x3_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_conv3d_3x3x3_cout1_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "nrgbd_bn3d_finalize": (_I, [_P, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,361 @@
+// conv3d.hip — K-Net 3x3x3 convolution (stride 1, pad 1, no bias) on the fp32 matrix cores of gfx950,
+// with the BatchNorm3d work of the reference fused around it.
+//
+// Replaces, per K-Net layer (models/basic.py:71-94,127-132; psm_submodule.py:19-23):
+//   nn.Conv3d(Cin, 64, 3, padding=1, bias=False)  ->  implicit GEMM on v_mfma_f32_32x32x2_f32
+//   nn.BatchNorm3d (batch statistics: the reference never leaves train() mode)
+//        statistics  -> per-workgroup (sum, sum of squares) partials written by the conv epilogue
+//        normalise + affine + ReLU + residual add -> applied by the NEXT layer while it loads its
+//        input tile (the activated tensor is only written when a later layer needs it as a residual)
+// so one layer = one pass: read Z_in (+ residual), write Z_out.  The reference runs conv, BN-stat,
+// BN-apply, ReLU and add as separate kernels over a 805 MB activation (192x256x64 grid).
+//
+// Exactness: f32 MFMA is a k-ordered fmaf chain (bit-identical to VALU fp32), so the result differs
+// from MIOpen / the CPU oracle only by summation order.
+//
+// Data layout: activations are channels-last [D][H][W][C] (a voxel's channels are contiguous), weights
+// are pre-packed per (tap, channel block, k-group, cout fragment) so that a wave's B-operand load is one
+// contiguous 1 KB line (conv3d_pack_weights below).
+//
+// Tiling: workgroup = 256 threads = 4 waves = 2 x 8 x 16 output voxels x 64 output channels; a wave
+// owns 4 rows x 16 x = 64 voxels = two 32-row MFMA tiles x two 32-column tiles (64 accumulator VGPRs).
+// The K loop runs over channel blocks of 16: the (4 x 10 x 18)-voxel halo tile of the block is staged
+// in LDS as [voxel][16 + 4 pad] (80-byte voxel stride = odd number of 16-B words, conflict-free
+// ds_read_b128), then 27 taps x 2 k-groups, each = 2 A reads (LDS, b128) + 2 B loads (L2, 16 B per
+// lane) + 16 MFMAs.  One b128 feeds FOUR k-steps: step e of a group contracts channel 4g+e (lanes
+// 0-31) and channel 8+4g+e (lanes 32-63) — the contraction order is free, A and B just agree on it.
+// MFMA row i <-> voxel: the 16 lanes of each ds_read_b128 lane group take 16 consecutive x of one row.
+#include "common.hpp"
+
+namespace nrgbd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTD = 2, kTH = 8, kTW = 16;                   // output tile (voxels)
+constexpr int kHD = kTD + 2, kHH = kTH + 2, kHW = kTW + 2;  // halo tile
+constexpr int kHaloVox = kHD * kHH * kHW;                   // 720
+constexpr int kCB = 16;                                     // channels per K block
+constexpr int kSV = kCB + 4;                                // LDS voxel stride (floats)
+constexpr int kCout = 64;
+
+struct Conv3dArgs {
+    const float* x;       // [D][H][W][Cin] raw input (pre-activation)
+    const float* x_ss;    // [Cin][2] (scale, shift) applied to x, or null = identity
+    const float* res;     // [D][H][W][Cin] second operand added after activation, or null
+    const float* res_ss;  // [Cin][2] for res, or null = identity
+    float* mat;           // [D][H][W][Cin]: materialised input act(x) + act(res), or null
+    const float* wp;      // packed weights (conv3d_pack_weights)
+    float* y;             // [D][H][W][64] raw convolution output
+    float* stats;         // [num_workgroups][128]: per-channel sum (0..63) and sum of squares (64..127), or null
+    int x_relu, res_relu;
+    int D, H, W;
+};
+
+// position of MFMA row i (0..31) inside its 2-row x 16-x patch: rows of lane group G0 = {0-3,12-15,20-27}
+// take x = 0..15 of the first row, G1 = {4-11,16-19,28-31} of the second row
+__device__ __forceinline__ void row_to_yx(int i, int& dy, int& x) {
+    dy = ((i >= 4 && i < 12) || (i >= 16 && i < 20) || (i >= 28)) ? 1 : 0;
+    x = (i < 4) ? i : (i < 12) ? i - 4 : (i < 16) ? i - 8 : (i < 20) ? i - 8 : (i < 28) ? i - 12 : i - 16;
+}
+
+// Stage the (4 x 10 x 18)-voxel halo tile of channel block `cblk` into LDS as [voxel][kSV]:
+//   in = act(x*s+t) [+ act(res*s'+t')] inside the volume, 0 outside (zero padding applies to the
+//   ACTIVATED tensor, exactly like F.conv3d(padding=1) on the materialised activation).
+template <int CIN>
+__device__ __forceinline__ void stage_halo(const Conv3dArgs& a, int cblk, float* lds, int tid, int x0, int y0, int z0) {
+    for (int idx = tid; idx < kHaloVox * (kCB / 4); idx += 256) {
+        const int hv = idx >> 2, c4 = idx & 3;
+        const int hz = hv / (kHH * kHW), rem = hv - hz * (kHH * kHW);
+        const int hy = rem / kHW, hx = rem - hy * kHW;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            const size_t vox = ((size_t)gz * a.H + gy) * a.W + gx;
+            const int c = cblk * kCB + c4 * 4;
+            v = *reinterpret_cast<const f32x4*>(a.x + vox * CIN + c);
+            if (a.x_ss) {
+                const float* ss = a.x_ss + 2 * c;
+                v.x = __builtin_fmaf(v.x, ss[0], ss[1]); v.y = __builtin_fmaf(v.y, ss[2], ss[3]);
+                v.z = __builtin_fmaf(v.z, ss[4], ss[5]); v.w = __builtin_fmaf(v.w, ss[6], ss[7]);
+            }
+            if (a.x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (a.res) {
+                f32x4 r = *reinterpret_cast<const f32x4*>(a.res + vox * CIN + c);
+                if (a.res_ss) {
+                    const float* ss = a.res_ss + 2 * c;
+                    r.x = __builtin_fmaf(r.x, ss[0], ss[1]); r.y = __builtin_fmaf(r.y, ss[2], ss[3]);
+                    r.z = __builtin_fmaf(r.z, ss[4], ss[5]); r.w = __builtin_fmaf(r.w, ss[6], ss[7]);
+                }
+                if (a.res_relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+                v = v + r;
+            }
+            // the activated input is written once, by the tile that owns the voxel
+            if (a.mat && hz >= 1 && hz <= kTD && hy >= 1 && hy <= kTH && hx >= 1 && hx <= kTW)
+                *reinterpret_cast<f32x4*>(a.mat + vox * CIN + c) = v;
+        }
+        *reinterpret_cast<f32x4*>(lds + hv * kSV + c4 * 4) = v;
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const Conv3dArgs a) {
+    constexpr int NCBLK = CIN / kCB;
+    constexpr int G4 = kCB / 8;  // k-groups per block (4 k-steps = 8 channels each)
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [kHaloVox][kSV] (+ 4*128 floats stats)
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_x = (a.W + kTW - 1) / kTW, tiles_y = (a.H + kTH - 1) / kTH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; const int tz = t / tiles_y;
+    const int x0 = tx * kTW, y0 = ty * kTH, z0 = tz * kTD;
+
+    // this lane's A rows: wave -> (dz, 4-row band); tile m -> 2 rows of the band
+    const int i = lane & 31, khalf = lane >> 5;
+    int dy, px;
+    row_to_yx(i, dy, px);
+    const int wz = wv >> 1, wy = (wv & 1) * 4;
+    // halo-relative voxel index of (wz, wy + 2m + dy, px) for tap (0,0,0); + tap offset per tap
+    const int hv0 = ((wz * kHH) + (wy + dy)) * kHW + px;
+    const float* a_base0 = lds + hv0 * kSV + khalf * (kCB / 2);
+    const float* a_base1 = a_base0 + 2 * kHW * kSV;  // m = 1: two rows further
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+    for (int cblk = 0; cblk < NCBLK; ++cblk) {
+        stage_halo<CIN>(a, cblk, lds, tid, x0, y0, z0);
+        __syncthreads();
+
+        // ---- 27 taps x G4 k-groups; B operand streamed from L2 (packed: one 1 KB line per wave load) ----
+        const f32x4* wb = reinterpret_cast<const f32x4*>(a.wp) + (size_t)cblk * (G4 * 2 * 64) + lane;
+        constexpr int WSTEP = NCBLK * G4 * 2 * 64;  // f32x4 per tap
+        f32x4 Bn[2][2], An[2][2];
+        Bn[0][0] = wb[0]; Bn[0][1] = wb[64];
+        An[0][0] = *reinterpret_cast<const f32x4*>(a_base0);
+        An[0][1] = *reinterpret_cast<const f32x4*>(a_base1);
+#pragma unroll
+        for (int s = 0; s < 27 * G4; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < 27 * G4) {  // prefetch step s+1
+                const int tap = (s + 1) / G4, g = (s + 1) % G4;
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                const int aoff = ((kd * kHH + kh) * kHW + kw) * kSV + g * 4;
+                An[nxt][0] = *reinterpret_cast<const f32x4*>(a_base0 + aoff);
+                An[nxt][1] = *reinterpret_cast<const f32x4*>(a_base1 + aoff);
+                const f32x4* wn = wb + (size_t)tap * WSTEP + g * (2 * 64);
+                Bn[nxt][0] = wn[0]; Bn[nxt][1] = wn[64];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(An[cur][m][e], Bn[cur][n][e], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: raw output (channels-last) + per-channel partial statistics ----
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const int gz = z0 + wz;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;  // MFMA C/D row held in register r
+            int ry, rx;
+            row_to_yx(row, ry, rx);
+            const int gy = y0 + wy + 2 * m + ry, gx = x0 + rx;
+            if (gz < a.D && gy < a.H && gx < a.W) {
+                const size_t vox = ((size_t)gz * a.H + gy) * a.W + gx;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const float z = acc[m][n][r];
+                    a.y[vox * kCout + n * 32 + i] = z;
+                    s1[n] += z;
+                    s2[n] = __builtin_fmaf(z, z, s2[n]);
+                }
+            }
+        }
+    }
+    if (a.stats) {
+        float* red = lds;  // reuse: [4 waves][128]
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            s1[n] += __shfl_xor(s1[n], 32, 64);
+            s2[n] += __shfl_xor(s2[n], 32, 64);
+        }
+        if (khalf == 0) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                red[wv * 128 + n * 32 + i] = s1[n];
+                red[wv * 128 + 64 + n * 32 + i] = s2[n];
+            }
+        }
+        __syncthreads();
+        if (tid < 128)
+            a.stats[(size_t)blockIdx.x * 128 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+    }
+}
+
+// Last K-Net layer (models/basic.py:92-94: Conv3d(64, 1, 3, padding=1, bias=False), no BatchNorm):
+// one output channel has nothing for the matrix cores (1 of 32 columns), so it is a VALU kernel on the
+// same staged halo tile: one thread = one output voxel, 27 taps x 64 channels of FMAs, the 1728 weights
+// are wave-uniform (scalar loads).  w1 is [27][64] (tap-major).  0.07 % of the K-Net FLOPs.
+__global__ __launch_bounds__(256, 2) void conv3d_cout1_kernel(const Conv3dArgs a, const float* __restrict__ w1) {
+    constexpr int CIN = 64, NCBLK = CIN / kCB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int tiles_x = (a.W + kTW - 1) / kTW, tiles_y = (a.H + kTH - 1) / kTH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; const int tz = t / tiles_y;
+    const int x0 = tx * kTW, y0 = ty * kTH, z0 = tz * kTD;
+    const int ox = tid & 15, oy = (tid >> 4) & 7, oz = tid >> 7;
+    const float* base = lds + ((oz * kHH + oy) * kHW + ox) * kSV;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int cblk = 0; cblk < NCBLK; ++cblk) {
+        stage_halo<CIN>(a, cblk, lds, tid, x0, y0, z0);
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const float* pv = base + ((kd * kHH + kh) * kHW + kw) * kSV;
+            const float* pw = w1 + tap * CIN + cblk * kCB;
+#pragma unroll
+            for (int c4 = 0; c4 < kCB / 4; ++c4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(pv + c4 * 4);
+                acc0 = __builtin_fmaf(v.x, pw[c4 * 4 + 0], acc0);
+                acc1 = __builtin_fmaf(v.y, pw[c4 * 4 + 1], acc1);
+                acc2 = __builtin_fmaf(v.z, pw[c4 * 4 + 2], acc2);
+                acc3 = __builtin_fmaf(v.w, pw[c4 * 4 + 3], acc3);
+            }
+        }
+        __syncthreads();
+    }
+    const int gz = z0 + oz, gy = y0 + oy, gx = x0 + ox;
+    if (gz < a.D && gy < a.H && gx < a.W) a.y[((size_t)gz * a.H + gy) * a.W + gx] = (acc0 + acc1) + (acc2 + acc3);
+}
+
+// weights [64][Cin][3][3][3] (torch layout) -> packed [tap][cblk][g][nfrag][lane = khalf*32 + j][4]
+//   value = w[cout = nfrag*32 + j][cin = cblk*16 + khalf*8 + g*4 + e][tap]
+__global__ void conv3d_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin) {
+    const int ncblk = Cin / kCB, G4 = kCB / 8;
+    const int total = 27 * ncblk * G4 * 2 * 64 * 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int t = idx;
+    const int e = t & 3; t >>= 2;
+    const int ln = t & 63; t >>= 6;
+    const int nfrag = t & 1; t >>= 1;
+    const int g = t % G4; t /= G4;
+    const int cblk = t % ncblk; const int tap = t / ncblk;
+    const int cout = nfrag * 32 + (ln & 31);
+    const int cin = cblk * kCB + (ln >> 5) * (kCB / 2) + g * 4 + e;
+    wp[idx] = w[((size_t)cout * Cin + cin) * 27 + tap];
+}
+
+// Reduce the per-workgroup partials to BatchNorm (scale, shift) and update the running statistics
+// (nn.BatchNorm3d in train mode: biased variance normalises, unbiased variance feeds running_var).
+__global__ void bn3d_finalize_kernel(const float* __restrict__ stats, int nwg, double count,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float eps, float momentum, float* __restrict__ running_mean,
+                                     float* __restrict__ running_var, float* __restrict__ ss) {
+    __shared__ double sh[2][4][64];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;  // 256 threads: 4 slices of the workgroup list
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = part; g < nwg; g += 4) {
+        s1 += (double)stats[(size_t)g * 128 + c];
+        s2 += (double)stats[(size_t)g * 128 + 64 + c];
+    }
+    sh[0][part][c] = s1; sh[1][part][c] = s2;
+    __syncthreads();
+    if (part == 0) {
+        s1 = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+        s2 = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        ss[2 * c] = sc;
+        ss[2 * c + 1] = beta[c] - (float)mean * sc;
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+}  // namespace nrgbd
+
+extern "C" int nrgbd_conv3d_workgroups(int D, int H, int W) {
+    using namespace nrgbd;
+    if (D <= 0 || H <= 0 || W <= 0) return NRGBD_E_SHAPE;
+    return ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
+}
+
+extern "C" int nrgbd_conv3d_pack_weights(const float* w, float* wp, int Cin, void* stream) {
+    using namespace nrgbd;
+    if (!w || !wp) return NRGBD_E_NULL;
+    if (Cin <= 0 || Cin % kCB) return NRGBD_E_SHAPE;
+    const int total = 27 * Cin * kCout;
+    hipLaunchKernelGGL(conv3d_pack_weights_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cin);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+extern "C" int nrgbd_conv3d_3x3x3_f32(const float* x, const float* x_ss, int x_relu, const float* res,
+                                      const float* res_ss, int res_relu, float* materialized,
+                                      const float* w_packed, float* y, float* stats, int D, int H, int W,
+                                      int Cin, int Cout, void* stream) {
+    using namespace nrgbd;
+    if (!x || !w_packed || !y) return NRGBD_E_NULL;
+    if (D <= 0 || H <= 0 || W <= 0) return NRGBD_E_SHAPE;
+    if (Cout != kCout || (Cin != 16 && Cin != 64)) return NRGBD_E_SHAPE;
+    Conv3dArgs a{x, x_ss, res, res_ss, materialized, w_packed, y, stats, x_relu, res_relu, D, H, W};
+    const int nwg = ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
+    const size_t lds = (size_t)kHaloVox * kSV * sizeof(float);  // 57,600 B (>= the 2 KB the statistics reuse)
+    if (Cin == 16)
+        hipLaunchKernelGGL(conv3d_mfma_kernel<16>, dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(conv3d_mfma_kernel<64>, dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+extern "C" int nrgbd_conv3d_3x3x3_cout1_f32(const float* x, const float* x_ss, int x_relu, const float* res,
+                                            const float* res_ss, int res_relu, const float* w_tap_major,
+                                            float* y, int D, int H, int W, int Cin, void* stream) {
+    using namespace nrgbd;
+    if (!x || !w_tap_major || !y) return NRGBD_E_NULL;
+    if (D <= 0 || H <= 0 || W <= 0 || Cin != 64) return NRGBD_E_SHAPE;
+    Conv3dArgs a{x, x_ss, res, res_ss, nullptr, nullptr, y, nullptr, x_relu, res_relu, D, H, W};
+    const int nwg = ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
+    const size_t lds = (size_t)kHaloVox * kSV * sizeof(float);
+    hipLaunchKernelGGL(conv3d_cout1_kernel, dim3(nwg), dim3(256), lds, (hipStream_t)stream, a, w_tap_major);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+extern "C" int nrgbd_bn3d_finalize(const float* stats, int num_workgroups, long count, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* scale_shift, void* stream) {
+    using namespace nrgbd;
+    if (!stats || !gamma || !beta || !scale_shift) return NRGBD_E_NULL;
+    if (num_workgroups <= 0 || count <= 0) return NRGBD_E_SHAPE;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return NRGBD_E_NULL;
+    hipLaunchKernelGGL(bn3d_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, num_workgroups,
+                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}

@@ -14,6 +14,7 @@ struct WarpVolArgs {
     float* out;
     float cx, cy;
     int align, V, Cs, D, h, w;
+    int channels_last;  // 0: out [Ch][D][h][w] (torch NCDHW), 1: out [D][h][w][Ch] (conv3d.hip input layout)
 };
 
 // grid: (ceil(hw/256), D); one lane = one (pixel, depth) pair, loops views and channels.
@@ -26,8 +27,10 @@ __global__ __launch_bounds__(256) void warp_volume_kernel(const WarpVolArgs a) {
     const float rx = a.rays[p], ry = a.rays[hw + p], rz = a.rays[2 * hw + p];
     const float d = a.d_candi[k];
     const float wf = (float)a.w, hf = (float)a.h;
-    const size_t plane = (size_t)a.D * hw;
-    float* o = a.out + (size_t)k * hw + p;
+    const int n_ch = a.V * a.Cs + (a.ref ? a.Cs : 0) + (a.bv_cur ? 1 : 0);
+    // element (channel ch, depth k, pixel p) lives at o[ch * plane]
+    const size_t plane = a.channels_last ? 1 : (size_t)a.D * hw;
+    float* o = a.channels_last ? a.out + ((size_t)k * hw + p) * n_ch : a.out + (size_t)k * hw + p;
     for (int v = 0; v < a.V; ++v) {
         const SweepTerm st = make_sweep_term(a.KR + 9 * v, a.Kt + 3 * v, rx, ry, rz);
         float ix, iy;
@@ -56,13 +59,13 @@ extern "C" int nrgbd_warp_volume(const float* src, long sv, long sc, long sy, lo
                                  const float* Kt, const float* rays, const float* d_candi,
                                  float cx, float cy, int align_corners, const float* bv_cur,
                                  const float* bv_pred, float* out, int V, int Cs, int D, int h,
-                                 int w, void* stream) {
+                                 int w, int channels_last, void* stream) {
     using namespace nrgbd;
     if (!src || !KR || !Kt || !rays || !d_candi || !out) return NRGBD_E_NULL;
     if ((bv_cur == nullptr) != (bv_pred == nullptr)) return NRGBD_E_NULL;
     if (V <= 0 || V > NRGBD_MAX_V || Cs <= 0 || D <= 0 || D > 65535 || h <= 0 || w <= 0) return NRGBD_E_SHAPE;
     WarpVolArgs a{src, sv, sc, sy, sx, ref, rc, ry, rx, KR, Kt, rays, d_candi, bv_cur, bv_pred,
-                  out, cx, cy, align_corners, V, Cs, D, h, w};
+                  out, cx, cy, align_corners, V, Cs, D, h, w, channels_last};
     dim3 grid(ceil_div((long)h * w, 256), D);
     hipLaunchKernelGGL(warp_volume_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     NRGBD_CHECK_LAUNCH();

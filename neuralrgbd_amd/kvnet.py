@@ -166,13 +166,18 @@ class KVNET(nn.Module):
         KR, Kt = warp_homo.homography_terms(K, src_cam_poses[0, :, :3, :3], src_cam_poses[0, :, :3, 3])
         rgb_src = texels[:V, :, :, F_dim:]    # strided views into the texel tensor, no copies
         rgb_ref = texels[V, :, :, F_dim:]
+        fused = (not torch.is_grad_enabled()) and self.kv_net.in_channels == 16 and self.KVNet_feature_dim == 64 \
+            and not self.kv_net.if_normalize and self.kv_net.up_sample_ratio is None
         volume = ops.warp_volume(rgb_src, (h * w * Cp, 1, w * Cp, Cp), rgb_ref, (1, w * Cp, Cp),
                                  KR, Kt, rays, warp_homo._d_candi_dev(self.d_candi, dev), cx, cy,
                                  V, 3, h, w, bv_cur=BV_cur[0], bv_pred=BV_predict[0],
-                                 align_corners=self.d_net.align_corners)
-        BV_gain = self.kv_net(volume.unsqueeze(0))                      # [1,1,D,h,w]
+                                 align_corners=self.d_net.align_corners, channels_last=fused)
+        if fused:   # inference: hand-written MFMA conv3d stack on the channels-last volume
+            gain = self.kv_net.forward_channels_last(volume)                # [D,h,w]
+        else:       # autograd path (training): torch modules on the NCDHW volume
+            gain = self.kv_net(volume.unsqueeze(0))[0, 0]
         # ---- UPDATE: DPV = log_softmax(gain + BV_predict) ----
-        DPV = ops.logsoftmax_d(BV_gain[0, 0], BV_predict[0]).unsqueeze(0)
+        DPV = ops.logsoftmax_d(gain, BV_predict[0]).unsqueeze(0)
 
         dmap_refined = self._refine(DPV, features) if self.if_refined else -1
         return dmap_cur_refined, dmap_refined, BV_cur, DPV

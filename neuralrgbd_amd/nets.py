@@ -164,6 +164,84 @@ class KalmanGainNet(nn.Module):
                                       nn.Conv3d(f, 1, kernel_size=3, padding=1, stride=1, bias=False))
         _he_init(self)
 
+    # ------------------------------------------------------------------ HIP inference path
+    def _layers(self):
+        """(conv, bn | None) in execution order: dres0 x2, dres1..4 x2 each, classify x2."""
+        seq = [self.dres0[0], self.dres0[2]]
+        for i in (1, 2, 3, 4):
+            blk = getattr(self, "dres%d" % i)
+            seq += [blk[0], blk[2]]
+        seq.append(self.classify[0])
+        return [(m[0], m[1]) for m in seq] + [(self.classify[2], None)]
+
+    def _packed(self, conv):
+        """B-operand stream of a conv, re-packed only when its weight changes."""
+        from . import ops
+        cache = self.__dict__.setdefault("_wp_cache", {})
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            if conv.out_channels == 1:
+                packed = w.detach()[0].reshape(w.shape[1], 27).t().contiguous()  # [27, Cin] tap-major
+            else:
+                packed = ops.conv3d_pack_weights(w.detach().contiguous())
+            hit = (key, packed)
+            cache[id(conv)] = hit
+        return hit[1]
+
+    def _bn_scale_shift(self, bn, stats, count):
+        """(scale, shift) of a BatchNorm3d: batch statistics in train mode (the reference never leaves it,
+        SURVEY §0.2) incl. the running-statistics side effect; running statistics in eval mode."""
+        from . import ops
+        use_batch = bn.training or not bn.track_running_stats
+        if use_batch:
+            upd = bn.training and bn.track_running_stats
+            if upd:
+                bn.num_batches_tracked += 1
+            momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            return ops.bn3d_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, momentum,
+                                     bn.running_mean if upd else None, bn.running_var if upd else None)
+        sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+        return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
+
+    def forward_channels_last(self, vol):
+        """Inference on the hand-written kernels: vol [D,H,W,Cin] (channels-last) -> gain [D,H,W].
+
+        One fused pass per layer (conv3d.hip): conv on the fp32 matrix cores, BatchNorm statistics in
+        its epilogue, normalise + affine + ReLU + residual applied by the next layer's loader.
+        Same graph as forward() (basic.py:113-132):
+            c0 = relu(bn(conv(relu(bn(conv(vol))))))
+            c_i = bn(conv(relu(bn(conv(c_{i-1}))))) + c_{i-1}     i = 1..4
+            gain = conv(relu(bn(conv(c4))))
+        """
+        from . import ops
+        if self.if_normalize or self.up_sample_ratio is not None:
+            raise NotImplementedError("if_normalize / up_sample_ratio are never enabled by the reference scripts")
+        D, H, W, C = vol.shape
+        if C != self.in_channels:
+            raise AssertionError("Input volume should have correct # of channels !")
+        L = self._layers()
+        count = D * H * W
+        need_stats = lambda bn: bn.training or not bn.track_running_stats
+
+        def run(i, x, x_ss, x_relu, res=None, materialize=False):
+            conv, bn = L[i]
+            y, st, mat = ops.conv3d(x, self._packed(conv), x_ss=x_ss, x_relu=x_relu, res=res,
+                                    materialize=materialize, want_stats=need_stats(bn))
+            return y, self._bn_scale_shift(bn, st, count), mat
+
+        z, ss, _ = run(0, vol, None, False)                       # dres0.0
+        z, ss, _ = run(1, z, ss, True)                            # dres0.2   in = relu(bn(z))
+        z, ss, skip = run(2, z, ss, True, materialize=True)       # dres1.0   in = c0 (kept as the residual)
+        z, ss, _ = run(3, z, ss, True)                            # dres1.2
+        for i in (4, 6, 8):                                       # dres2.0, dres3.0, dres4.0: in = bn(z) + c_{i-1}
+            z, ss, skip = run(i, z, ss, False, res=skip, materialize=True)
+            z, ss, _ = run(i + 1, z, ss, True)
+        z, ss, _ = run(10, z, ss, False, res=skip)                # classify.0: in = c4
+        conv, _ = L[11]
+        return ops.conv3d_cout1(z, self._packed(conv), x_ss=ss, x_relu=True)  # classify.2
+
     def forward(self, volume):
         if volume.shape[1] != self.in_channels:
             raise AssertionError("Input volume should have correct # of channels !")

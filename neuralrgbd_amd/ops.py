@@ -87,8 +87,9 @@ def costvol(ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, cx, cy, sigma, C, dist="L
 
 
 def warp_volume(src, src_strides, ref, ref_strides, KR, Kt, rays, d_candi, cx, cy, V, Cs, h, w,
-                bv_cur=None, bv_pred=None, align_corners=False):
-    """Plane-sweep warp with samples kept (+ K-Net input assembly) -> [V*Cs (+Cs) (+1), D, h, w].
+                bv_cur=None, bv_pred=None, align_corners=False, channels_last=False):
+    """Plane-sweep warp with samples kept (+ K-Net input assembly) -> [V*Cs (+Cs) (+1), D, h, w]
+    (or [D, h, w, channels] with channels_last=True, the layout conv3d consumes).
 
     `src` / `ref` are any CUDA fp32 tensors; `src_strides` = (view, channel, y, x) and
     `ref_strides` = (channel, y, x) element strides from their data pointers.
@@ -109,12 +110,14 @@ def warp_volume(src, src_strides, ref, ref_strides, KR, Kt, rays, d_candi, cx, c
         bv_cur = _need(bv_cur, "bv_cur").reshape(D, h, w)
         bv_pred = _need(bv_pred, "bv_pred").reshape(D, h, w)
         n_ch += 1
-    out = torch.empty((n_ch, D, h, w), dtype=torch.float32, device=src.device)
+    shape = (D, h, w, n_ch) if channels_last else (n_ch, D, h, w)
+    out = torch.empty(shape, dtype=torch.float32, device=src.device)
     with torch.cuda.device(src.device):
         rc = _lib.load().nrgbd_warp_volume(_p(src), *[int(s) for s in src_strides], _p(ref),
                                            *[int(s) for s in ref_strides], _p(KR), _p(Kt), _p(rays),
                                            _p(d_candi), float(cx), float(cy), int(bool(align_corners)),
-                                           _p(bv_cur), _p(bv_pred), _p(out), V, Cs, D, h, w, _stream(src))
+                                           _p(bv_cur), _p(bv_pred), _p(out), V, Cs, D, h, w,
+                                           int(bool(channels_last)), _stream(src))
     _lib.check(rc, "nrgbd_warp_volume")
     return out
 
@@ -163,3 +166,68 @@ def depth_regress(logp, d_candi, want_conf=True):
         rc = _lib.load().nrgbd_depth_regress(_p(logp), _p(d_candi), _p(depth), _p(conf), D, n, _stream(logp))
     _lib.check(rc, "nrgbd_depth_regress")
     return depth, conf
+
+
+# ----------------------------------------------------------------------------- K-Net convolutions
+def conv3d_workgroups(D, H, W):
+    return int(_lib.load().nrgbd_conv3d_workgroups(D, H, W))
+
+
+def conv3d_pack_weights(w):
+    """w [64, Cin, 3, 3, 3] -> packed B-operand stream for conv3d (one 1 KB line per wave load)."""
+    w = _need(w, "w")
+    cout, cin = w.shape[:2]
+    if cout != 64 or tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError("conv3d_pack_weights expects [64, Cin, 3, 3, 3], got %s" % (tuple(w.shape),))
+    wp = torch.empty(27 * cin * 64, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().nrgbd_conv3d_pack_weights(_p(w), _p(wp), cin, _stream(w))
+    _lib.check(rc, "nrgbd_conv3d_pack_weights")
+    return wp
+
+
+def conv3d(x, w_packed, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False,
+           materialize=False, want_stats=True, out=None, mat_out=None):
+    """Channels-last 3x3x3 convolution on the fp32 matrix cores.
+
+    x [D,H,W,Cin]; input = act(x*s+t) (+ act(res*s'+t')).  Returns (y [D,H,W,64], stats | None, materialized | None).
+    """
+    x = _need(x, "x")
+    D, H, W, Cin = x.shape
+    y = out if out is not None else torch.empty((D, H, W, 64), dtype=torch.float32, device=x.device)
+    nwg = conv3d_workgroups(D, H, W)
+    stats = torch.empty((nwg, 128), dtype=torch.float32, device=x.device) if want_stats else None
+    mat = None
+    if materialize:
+        mat = mat_out if mat_out is not None else torch.empty_like(x)
+    if res is not None:
+        res = _need(res, "res", x.shape)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv3d_3x3x3_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu),
+                                                 _p(mat), _p(w_packed), _p(y), _p(stats), D, H, W, Cin, 64, _stream(x))
+    _lib.check(rc, "nrgbd_conv3d_3x3x3_f32")
+    return y, stats, mat
+
+
+def conv3d_cout1(x, w_tap_major, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False):
+    """Last K-Net layer: x [D,H,W,64] -> y [D,H,W]; w_tap_major [27,64]."""
+    x = _need(x, "x")
+    D, H, W, Cin = x.shape
+    w_tap_major = _need(w_tap_major, "w_tap_major", (27, Cin))
+    y = torch.empty((D, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv3d_3x3x3_cout1_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu),
+                                                       _p(w_tap_major), _p(y), D, H, W, Cin, _stream(x))
+    _lib.check(rc, "nrgbd_conv3d_3x3x3_cout1_f32")
+    return y
+
+
+def bn3d_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    """Per-workgroup partials -> scale_shift [64,2]; updates the running statistics in place (train mode)."""
+    stats = _need(stats, "stats")
+    ss = torch.empty((64, 2), dtype=torch.float32, device=stats.device)
+    with torch.cuda.device(stats.device):
+        rc = _lib.load().nrgbd_bn3d_finalize(_p(stats), stats.shape[0], int(count), _p(gamma), _p(beta), float(eps),
+                                             float(momentum), _p(running_mean), _p(running_var), _p(ss), _stream(stats))
+    _lib.check(rc, "nrgbd_bn3d_finalize")
+    return ss

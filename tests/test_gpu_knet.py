@@ -1,0 +1,103 @@
+"""K-Net kernels (conv3d.hip): fp32-MFMA 3x3x3 convolution with fused BatchNorm / ReLU / residual,
+against torch's F.conv3d + F.batch_norm on the same GPU (a plain fp32 torch reference is the oracle for a
+floating-point kernel) and against the CPU oracle for the whole stack."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cl(x):   # [C,D,H,W] -> channels-last [D,H,W,C]
+    return x.permute(1, 2, 3, 0).contiguous()
+
+
+@pytest.mark.parametrize("D,H,W,Cin", [(4, 16, 32, 64), (2, 8, 16, 16), (5, 13, 21, 64), (3, 9, 40, 16), (8, 24, 48, 64)])
+def test_conv3d_plain_vs_torch(D, H, W, Cin):
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(D * 1000 + H)
+    x = torch.randn(Cin, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, Cin, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    want = F.conv3d(x[None], w, padding=1)[0]
+    y, stats, _ = ops.conv3d(_cl(x), ops.conv3d_pack_weights(w))
+    got = y.permute(3, 0, 1, 2)
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item()
+    print("[parity] conv3d %dx%dx%d Cin=%d max|d|=%.3e (|y|max %.2f)" % (D, H, W, Cin, err, scale))
+    assert err < 2e-5 * max(1.0, scale)
+    # epilogue statistics = per-channel sum and sum of squares of the output
+    s = stats.double().sum(0)
+    assert torch.allclose(s[:64], want.double().sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[64:], (want.double() ** 2).sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
+def test_conv3d_fused_prologue_and_materialize():
+    """in = relu(x*s+t) + relu(res*s'+t'); zero padding applies to the ACTIVATED tensor."""
+    from neuralrgbd_amd import ops
+    D, H, W, C = 4, 10, 20, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(C, D, H, W, generator=g).to(DEV)
+    r = torch.randn(C, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    ss = torch.randn(C, 2, generator=g).to(DEV)
+    rs = torch.randn(C, 2, generator=g).to(DEV)
+    act = torch.relu(x * ss[:, 0, None, None, None] + ss[:, 1, None, None, None]) \
+        + torch.relu(r * rs[:, 0, None, None, None] + rs[:, 1, None, None, None])
+    want = F.conv3d(act[None], w, padding=1)[0]
+    y, _, mat = ops.conv3d(_cl(x), ops.conv3d_pack_weights(w), x_ss=ss, x_relu=True, res=_cl(r), res_ss=rs,
+                           res_relu=True, materialize=True)
+    assert (y.permute(3, 0, 1, 2) - want).abs().max().item() < 2e-4
+    assert (mat.permute(3, 0, 1, 2) - act).abs().max().item() < 1e-5
+    # no-relu / identity residual form used by the residual blocks
+    act2 = (x * ss[:, 0, None, None, None] + ss[:, 1, None, None, None]) + r
+    y2, _, _ = ops.conv3d(_cl(x), ops.conv3d_pack_weights(w), x_ss=ss, res=_cl(r))
+    assert (y2.permute(3, 0, 1, 2) - F.conv3d(act2[None], w, padding=1)[0]).abs().max().item() < 2e-4
+
+
+def test_cout1_and_bn_finalize():
+    from neuralrgbd_amd import ops
+    D, H, W, C = 3, 11, 19, 64
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(C, D, H, W, generator=g).to(DEV)
+    w1 = (torch.randn(1, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    ss = torch.randn(C, 2, generator=g).to(DEV)
+    act = torch.relu(x * ss[:, 0, None, None, None] + ss[:, 1, None, None, None])
+    want = F.conv3d(act[None], w1, padding=1)[0, 0]
+    got = ops.conv3d_cout1(_cl(x), w1[0].reshape(C, 27).t().contiguous(), x_ss=ss, x_relu=True)
+    assert (got - want).abs().max().item() < 1e-4
+    # BatchNorm finalize: scale/shift reproduce F.batch_norm(training=True); running stats follow torch
+    w = (torch.randn(64, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    y, stats, _ = ops.conv3d(_cl(x), ops.conv3d_pack_weights(w))
+    gamma, beta = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV)
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    rm_t, rv_t = rm.clone(), rv.clone()
+    sc = ops.bn3d_finalize(stats, D * H * W, gamma, beta, 1e-5, 0.1, rm, rv)
+    z = y.permute(3, 0, 1, 2)[None]
+    want_bn = F.batch_norm(z, rm_t, rv_t, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    got_bn = z * sc[:, 0].view(1, 64, 1, 1, 1) + sc[:, 1].view(1, 64, 1, 1, 1)
+    assert (got_bn - want_bn).abs().max().item() < 1e-4
+    assert torch.allclose(rm, rm_t, atol=1e-6) and torch.allclose(rv, rv_t, rtol=1e-5, atol=1e-6)
+
+
+def test_knet_stack_vs_torch_modules():
+    """forward_channels_last == the nn.Module forward (same weights) incl. the BatchNorm running-stat side effect."""
+    import copy
+    from neuralrgbd_amd import nets, synth
+    torch.manual_seed(0)
+    net = nets.KalmanGainNet(16, feature_dim=64)
+    net.load_state_dict(synth.seeded_state_dict(net, 2))
+    net = net.to(DEV)
+    ref = copy.deepcopy(net)
+    D, H, W = 8, 24, 32
+    vol = torch.randn(1, 16, D, H, W, device=DEV)
+    with torch.no_grad():
+        want = ref(vol)[0, 0]
+        got = net.forward_channels_last(vol[0].permute(1, 2, 3, 0).contiguous())
+    err = (got - want).abs()
+    print("[parity] K-Net stack (12 layers) max|d|=%.3e mean|d|=%.3e (|gain|max %.2f)" %
+          (err.max().item(), err.mean().item(), want.abs().max().item()))
+    assert err.max().item() < 2e-3 and err.mean().item() < 1e-4
+    for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(b1.float(), b2.float(), rtol=1e-4, atol=1e-5), n1
