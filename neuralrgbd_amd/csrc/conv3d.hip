@@ -265,24 +265,28 @@ __global__ void conv3d_pack_weights_kernel(const float* __restrict__ w, float* _
 
 // Reduce the per-workgroup partials to BatchNorm (scale, shift) and update the running statistics
 // (nn.BatchNorm3d in train mode: biased variance normalises, unbiased variance feeds running_var).
-__global__ void bn3d_finalize_kernel(const float* __restrict__ stats, int nwg, double count,
+// grid = 64 workgroups (one per channel) x 256 threads: each thread walks a strided slice of the
+// workgroup list for its channel's (sum, sum of squares), tree-reduced in double.
+__global__ __launch_bounds__(256) void bn3d_finalize_kernel(const float* __restrict__ stats, int nwg, double count,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float eps, float momentum, float* __restrict__ running_mean,
                                      float* __restrict__ running_var, float* __restrict__ ss) {
-    __shared__ double sh[2][4][64];
-    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;  // 256 threads: 4 slices of the workgroup list
+    __shared__ double sh[2][256];
+    const int c = blockIdx.x, tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int g = part; g < nwg; g += 4) {
+    for (int g = tid; g < nwg; g += 256) {
         s1 += (double)stats[(size_t)g * 128 + c];
         s2 += (double)stats[(size_t)g * 128 + 64 + c];
     }
-    sh[0][part][c] = s1; sh[1][part][c] = s2;
+    sh[0][tid] = s1; sh[1][tid] = s2;
     __syncthreads();
-    if (part == 0) {
-        s1 = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
-        s2 = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double mean = sh[0][0] / count;
+        double var = sh[1][0] / count - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = gamma[c] * invstd;
@@ -354,7 +358,7 @@ extern "C" int nrgbd_bn3d_finalize(const float* stats, int num_workgroups, long 
     if (!stats || !gamma || !beta || !scale_shift) return NRGBD_E_NULL;
     if (num_workgroups <= 0 || count <= 0) return NRGBD_E_SHAPE;
     if ((running_mean == nullptr) != (running_var == nullptr)) return NRGBD_E_NULL;
-    hipLaunchKernelGGL(bn3d_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, num_workgroups,
+    hipLaunchKernelGGL(bn3d_finalize_kernel, dim3(kCout), dim3(256), 0, (hipStream_t)stream, stats, num_workgroups,
                        (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;

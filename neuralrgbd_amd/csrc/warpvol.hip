@@ -52,6 +52,43 @@ __global__ __launch_bounds__(256) void warp_volume_kernel(const WarpVolArgs a) {
     if (a.bv_cur) o[(size_t)ch * plane] = a.bv_cur[(size_t)k * hw + p] - a.bv_pred[(size_t)k * hw + p];
 }
 
+// K-Net input assembly specialised for the layout the model uses: sources and reference are the RGB word
+// (channels 64..67 = R,G,B,0: one aligned 16-B word) of the NHWC texel tensor, output channels-last
+// [D][h][w][16] for conv3d.hip.  One lane = one (pixel, depth): 4 views x 4 taps x one 16-B load, the
+// 16 output channels leave as four 16-B stores (64 contiguous bytes per lane).
+__global__ __launch_bounds__(256) void warp_volume_cl16_kernel(const WarpVolArgs a) {
+    const size_t hw = (size_t)a.h * a.w;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (p >= hw) return;
+    const int y = (int)(p / a.w), x = (int)(p - (size_t)y * a.w);
+    const float rx = a.rays[p], ry = a.rays[hw + p], rz = a.rays[2 * hw + p];
+    const float d = a.d_candi[k];
+    const float wf = (float)a.w, hf = (float)a.h;
+    float o[16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const SweepTerm st = make_sweep_term(a.KR + 9 * v, a.Kt + 3 * v, rx, ry, rz);
+        float ix, iy;
+        sweep_sample_pos(st, d, a.cx, a.cy, wf, hf, a.align != 0, ix, iy);
+        const Bilinear b = bilinear_zeros(ix, iy, a.w, a.h);
+        const float* s = a.src + v * a.sv;
+        const float4 A = *reinterpret_cast<const float4*>(s + b.y0 * a.sy + b.x0 * a.sx);
+        const float4 B = *reinterpret_cast<const float4*>(s + b.y0 * a.sy + b.x1 * a.sx);
+        const float4 C = *reinterpret_cast<const float4*>(s + b.y1 * a.sy + b.x0 * a.sx);
+        const float4 Dd = *reinterpret_cast<const float4*>(s + b.y1 * a.sy + b.x1 * a.sx);
+        o[3 * v + 0] = lerp4(A.x, B.x, C.x, Dd.x, b);
+        o[3 * v + 1] = lerp4(A.y, B.y, C.y, Dd.y, b);
+        o[3 * v + 2] = lerp4(A.z, B.z, C.z, Dd.z, b);
+    }
+    const float4 r = *reinterpret_cast<const float4*>(a.ref + y * a.ry + x * a.rx);
+    o[12] = r.x; o[13] = r.y; o[14] = r.z;
+    o[15] = a.bv_cur[(size_t)k * hw + p] - a.bv_pred[(size_t)k * hw + p];
+    float4* dst = reinterpret_cast<float4*>(a.out + ((size_t)k * hw + p) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+}
+
 }  // namespace nrgbd
 
 extern "C" int nrgbd_warp_volume(const float* src, long sv, long sc, long sy, long sx,
@@ -67,7 +104,13 @@ extern "C" int nrgbd_warp_volume(const float* src, long sv, long sc, long sy, lo
     WarpVolArgs a{src, sv, sc, sy, sx, ref, rc, ry, rx, KR, Kt, rays, d_candi, bv_cur, bv_pred,
                   out, cx, cy, align_corners, V, Cs, D, h, w, channels_last};
     dim3 grid(ceil_div((long)h * w, 256), D);
-    hipLaunchKernelGGL(warp_volume_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    const bool word_src = Cs == 3 && sc == 1 && rc == 1 && !((sv | sy | sx | ry | rx) & 3) &&
+                          !((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(ref) |
+                             reinterpret_cast<uintptr_t>(out)) & 15);
+    if (channels_last && V == 4 && ref && bv_cur && word_src)
+        hipLaunchKernelGGL(warp_volume_cl16_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(warp_volume_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

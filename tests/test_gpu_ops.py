@@ -182,6 +182,26 @@ def test_warp_volume_golden_and_assembly(golden_ops):
     assert np.array_equal(vol[-1], g["bv"] - g["pred"])
 
 
+def test_warp_volume_channels_last_matches_planar():
+    """The K-Net assembly in the conv3d layout ([D,h,w,16], fast path on the RGB word of the texel tensor)
+    must equal the planar torch layout."""
+    ops = _ops()
+    rng = np.random.RandomState(21)
+    V, h, w, D = 4, 20, 36, 8
+    cam = camera.scannet_intrinsics(w, h)
+    tex = _dev(rng.standard_normal((V + 1, h, w, 68)))
+    poses = synth.random_poses(rng, V)
+    KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+    bv, bp = _dev(rng.standard_normal((D, h, w))), _dev(rng.standard_normal((D, h, w)))
+    args = (tex[:V, :, :, 64:], (h * w * 68, 1, w * 68, 68), tex[V, :, :, 64:], (1, w * 68, 68), _dev(KR), _dev(Kt),
+            _dev(cam["unit_ray_array_2D"].numpy()), _dev(np.linspace(.1, 5, D)), cam["intrinsic_M"][0, 2],
+            cam["intrinsic_M"][1, 2], V, 3, h, w)
+    planar = ops.warp_volume(*args, bv_cur=bv, bv_pred=bp)
+    cl = ops.warp_volume(*args, bv_cur=bv, bv_pred=bp, channels_last=True)
+    assert cl.shape == (D, h, w, 16)
+    assert torch.equal(cl.permute(3, 0, 1, 2), planar)
+
+
 def test_dpv_resample_golden_and_oracle(golden_ops):
     ops = _ops()
     g = golden_ops
