@@ -74,7 +74,10 @@ class KernelTimer:
 def cpu_baseline(cfg, cam, d_candi, sd, window, bv_pred, sigma):
     """One update-branch frame of the SAME workload through the CPU oracle on all host cores."""
     from oracle import cpu_oracle, kvnet_oracle
-    cores = os.cpu_count() or 1
+    # torch-CPU convolutions stop scaling long before this host's 256 hardware threads: measured on the
+    # MI355X node (2 x EPYC 9575F) with tools/cpu_threads_probe.py, one config-S frame takes 1.49 / 1.47 /
+    # 2.33 / 4.6 s at 16 / 32 / 64 / 128 threads and 8x longer at 256 — so the baseline uses its best: 32.
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     cpu_oracle.set_threads(cores)
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
