@@ -171,7 +171,7 @@ extern "C" int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc, c
     if ((reinterpret_cast<uintptr_t>(ref_nhwc) | reinterpret_cast<uintptr_t>(src_nhwc)) & 15) return NRGBD_E_ALIGN;
     if (dist != NRGBD_DIST_L2 && dist != NRGBD_DIST_L1) return NRGBD_E_ARG;
     CostvolArgs a{ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, out_cost, out_logp, cx, cy, sigma,
-                  dist, align_corners, V, C, Cp, D, h, w, 0};
+                  dist, align_corners, V, C, Cp, D, h, w, 0, 0};
     if (const char* ab = getenv("NRGBD_ABLATE")) a.debug = atoi(ab);
     hipStream_t s = (hipStream_t)stream;
     // Generation 2 (LDS-staged) whenever Cp/4 has an instantiation; NRGBD_COSTVOL=gather forces

@@ -16,6 +16,7 @@ struct CostvolArgs {
     float cx, cy, sigma;
     int dist, align;
     int V, C, Cp, D, h, w;
+    int nsingle;           // LDS generation: leading candidates that get a workgroup each (set by the launcher)
     int debug;             // developer ablation bits (env NRGBD_ABLATE): 1 = no staging, 2 = no math
 };
 

@@ -25,6 +25,7 @@ namespace nrgbd {
 
 constexpr int kTile = 16;       // tile edge (pixels)
 constexpr int kKG = 8;          // depth candidates per workgroup
+constexpr int kSingles = 8;     // leading candidates that may get a workgroup each (small grids)
 constexpr int kPatchF4 = 4032;  // float4 slots of the source patch (63 KB)
 
 // Channel blocking: a texel of CP4 16-byte words is processed in NCB blocks of up to 9 words.  Every
@@ -128,8 +129,14 @@ __global__ __launch_bounds__(256, 2) void costvol_lds(const CostvolArgs a) {
     const int tid = threadIdx.x;
     const int tiles_x = (a.w + kTile - 1) / kTile;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int k0 = blockIdx.y * kKG;
-    const int nk = min(kKG, a.D - k0);
+    // blockIdx.y -> candidate range.  On grids too small to fill the chip (tiles x D/8 < 4 workgroups per CU)
+    // the first kSingles candidates — the nearest planes for an increasing d_candi: large, fast-moving
+    // footprints that are staged one by one — get a workgroup each, so that this heavy serial work spreads
+    // over idle CUs (config S: 264 -> 110 us).  On large grids the chip is throughput-bound and plain groups
+    // of kKG share more staging.  A scheduling choice only: results do not depend on it.
+    const int nsingle = a.nsingle;
+    const int k0 = ((int)blockIdx.y < nsingle) ? (int)blockIdx.y : nsingle + ((int)blockIdx.y - nsingle) * kKG;
+    const int nk = ((int)blockIdx.y < nsingle) ? 1 : min(kKG, a.D - k0);
     // Lane -> pixel map.  ds_read_b128 is serviced in four 16-lane groups {0-3,12-15,20-27},
     // {4-11,16-19,28-31}, {32-35,44-47,52-59}, {36-43,48-51,60-63} (MI355X_MICROARCH.md §LDS); each
     // group is given 16 consecutive pixels of ONE tile row, whose taps are (nearly) 16 consecutive
@@ -408,9 +415,13 @@ bool costvol_lds_supported(int cp4) {
     }
 }
 
-int launch_costvol_lds(const CostvolArgs& a, hipStream_t stream) {
+int launch_costvol_lds(const CostvolArgs& args, hipStream_t stream) {
+    CostvolArgs a = args;
     const int tiles = ceil_div(a.w, kTile) * ceil_div(a.h, kTile);
-    const dim3 grid(tiles, ceil_div(a.D, kKG));
+    const bool singles = (long)tiles * ceil_div(a.D, kKG) < 4 * 256;  // under-filled chip
+    const int nsingle = singles ? (a.D < kSingles ? a.D : kSingles) : 0;
+    a.nsingle = nsingle;
+    const dim3 grid(tiles, nsingle + ceil_div(a.D - nsingle, kKG));
     // 64,640 B: below the 64 KiB that needs no opt-in attribute, two workgroups per CU
     const size_t lds = (size_t)kPatchF4 * sizeof(float4) + kKG * 4 * sizeof(int);
 #define NRGBD_LDS_CASE(N)                                                                              \
