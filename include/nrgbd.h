@@ -184,6 +184,24 @@ int nrgbd_bn3d_finalize(const float* stats, int num_workgroups, long count,
                         const float* gamma, const float* beta, float eps, float momentum,
                         float* running_mean, float* running_var, float* scale_shift, void* stream);
 
+/*
+ * 2-D feature CNN helpers (NCHW, HW % 4 == 0, 16-B aligned planes).
+ * nrgbd_bn2d_train_act — train-mode BatchNorm2d (batch statistics over N*H*W, biased variance) fused with
+ * its activation and the residual add: y = act(gamma*(x-mean)/sqrt(var+eps) + beta) (+ residual).
+ * Replaces: psm_submodule.py:10-16 (convbn's nn.BatchNorm2d, always batch statistics: SURVEY §0.2),
+ * the nn.ReLU(inplace=True) after it (:37,:94-96) and `out += x` of BasicBlock (:47).
+ *   act: 0 none, 1 ReLU; residual NULL or [N][C][HW]; y may alias x;
+ *   partial: scratch of nrgbd_bn2d_partial_floats(C) floats; mean_var [C][2] or NULL (batch mean, biased var:
+ *   input of the running-statistics update of the shortcut norms, psm_submodule.py:131).
+ * nrgbd_avgpool8 — 8x8/stride-8 average pooling (the finest SPP window, psm_submodule.py:115; the 16/32/64
+ * windows of :103-111 are pooled from its output).  x [NC][H][W] -> y [NC][H/8][W/8].
+ */
+int nrgbd_bn2d_partial_floats(int C);
+int nrgbd_bn2d_train_act(const float* x, const float* gamma, const float* beta, float eps, int act,
+                         const float* residual, float* y, float* partial, float* mean_var,
+                         int N, int C, long HW, void* stream);
+int nrgbd_avgpool8(const float* x, float* y, int NC, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

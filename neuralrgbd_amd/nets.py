@@ -60,6 +60,37 @@ def _he_init(module):
 
 
 # --------------------------------------------------------------------------- 2-D feature CNN
+def _fused_ok(x):
+    """The hand-written BatchNorm path: inference on the GPU (autograd needs the torch modules)."""
+    return x.is_cuda and not torch.is_grad_enabled() and (x.shape[2] * x.shape[3]) % 4 == 0
+
+
+def _conv_bn_act(x, seq, relu, residual=None):
+    """conv (vendor library) -> BatchNorm2d(batch stats) -> [ReLU] -> [+ residual]; `seq` = Sequential(conv, bn).
+
+    On the fused path the normalise / activation / add are one hand-written two-pass kernel pair
+    (csrc/bn2d.hip) instead of MIOpen BN + separate ReLU + separate add.
+    """
+    conv, bn = seq[0], seq[1]
+    y = conv(x)
+    use_batch = bn.training or not bn.track_running_stats
+    if _fused_ok(y) and use_batch:
+        from . import ops
+        upd = bn.training and bn.track_running_stats
+        y, mv = ops.bn2d_train_act(y, bn.weight, bn.bias, bn.eps, relu=relu, residual=residual, want_mean_var=upd)
+        if upd:  # the shortcut norms keep running statistics (psm_submodule.py:131): same update as nn.BatchNorm2d
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            n = y.shape[0] * y.shape[2] * y.shape[3]
+            bn.running_mean.mul_(1 - m).add_(mv[:, 0], alpha=m)
+            bn.running_var.mul_(1 - m).add_(mv[:, 1] * (n / max(n - 1, 1)), alpha=m)
+        return y
+    y = bn(y)
+    if relu:
+        y = F.relu(y, inplace=True)
+    return y if residual is None else y + residual
+
+
 class ResBlock2d(nn.Module):
     """Two conv-bn with identity / 1x1 shortcut, no activation after the add (psm_submodule.py:31-50)."""
 
@@ -71,8 +102,9 @@ class ResBlock2d(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = self.conv2(self.conv1(x))
-        return y + (x if self.downsample is None else self.downsample(x))
+        skip = x if self.downsample is None else _conv_bn_act(x, self.downsample, relu=False)
+        y = _conv_bn_act(x, self.conv1[0], relu=True)
+        return _conv_bn_act(y, self.conv2, relu=False, residual=skip)
 
 
 class PSMFeatures(nn.Module):
@@ -118,15 +150,32 @@ class PSMFeatures(nn.Module):
         blocks += [ResBlock2d(width, width, 1, None, pad, dilation) for _ in range(n_blocks - 1)]
         return nn.Sequential(*blocks)
 
+    def _spp_pools(self, deep):
+        """Average pools of the SPP windows (64, 32, 16, 8).  On the fused path the map is read once by the
+        hand-written 8x8 kernel and the coarser windows are pooled from that result (equal-size windows: the
+        mean of means is the mean)."""
+        if _fused_ok(deep) and deep.shape[2] % 64 == 0 and deep.shape[3] % 64 == 0:
+            from . import ops
+            p8 = ops.avgpool8(deep)
+            return {8: p8, 16: F.avg_pool2d(p8, 2), 32: F.avg_pool2d(p8, 4), 64: F.avg_pool2d(p8, 8)}
+        return {w: F.avg_pool2d(deep, (w, w), stride=(w, w)) for w in self.SPP_WINDOWS}
+
     def forward(self, x):
-        stem = self.firstconv(x)
+        stem = x
+        for i in (0, 2, 4):
+            stem = _conv_bn_act(stem, self.firstconv[i], relu=True)
         half = self.layer1(stem)
         quarter = self.layer2(half)
         deep = self.layer4(self.layer3(quarter))
         size = deep.shape[2:]
-        pyramid = [F.interpolate(getattr(self, "branch%d" % i)(deep), size=size, mode="bilinear",
-                                 align_corners=True) for i in (4, 3, 2, 1)]
-        feat = self.lastconv(torch.cat([quarter, deep] + pyramid, dim=1))
+        pools = self._spp_pools(deep)
+        pyramid = []
+        for i in (4, 3, 2, 1):
+            branch = getattr(self, "branch%d" % i)          # Sequential(AvgPool2d, conv-bn, ReLU)
+            y = _conv_bn_act(pools[self.SPP_WINDOWS[i - 1]], branch[1], relu=True)
+            pyramid.append(F.interpolate(y, size=size, mode="bilinear", align_corners=True))
+        y = _conv_bn_act(torch.cat([quarter, deep] + pyramid, dim=1), self.lastconv[0], relu=True)
+        feat = self.lastconv[2](y)
         return (half, feat) if self.multi_scale else feat
 
 

@@ -231,3 +231,31 @@ def bn3d_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, r
                                              float(momentum), _p(running_mean), _p(running_var), _p(ss), _stream(stats))
     _lib.check(rc, "nrgbd_bn3d_finalize")
     return ss
+
+
+# ----------------------------------------------------------------------------- 2-D feature CNN helpers
+def bn2d_train_act(x, gamma, beta, eps, relu=False, residual=None, inplace=True, want_mean_var=False):
+    """Train-mode BatchNorm2d + activation (+ residual) in two HBM passes.  x [N,C,H,W] -> (y, mean_var | None)."""
+    x = _need(x, "x")
+    N, C, H, W = x.shape
+    if residual is not None:
+        residual = _need(residual, "residual", x.shape)
+    y = x if inplace else torch.empty_like(x)
+    partial = torch.empty(int(_lib.load().nrgbd_bn2d_partial_floats(C)), dtype=torch.float32, device=x.device)
+    mv = torch.empty((C, 2), dtype=torch.float32, device=x.device) if want_mean_var else None
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_bn2d_train_act(_p(x), _p(gamma), _p(beta), float(eps), int(bool(relu)), _p(residual),
+                                               _p(y), _p(partial), _p(mv), N, C, H * W, _stream(x))
+    _lib.check(rc, "nrgbd_bn2d_train_act")
+    return y, mv
+
+
+def avgpool8(x):
+    """8x8 / stride-8 average pooling of [N,C,H,W]."""
+    x = _need(x, "x")
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H // 8, W // 8), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_avgpool8(_p(x), _p(y), N * C, H, W, _stream(x))
+    _lib.check(rc, "nrgbd_avgpool8")
+    return y

@@ -101,3 +101,44 @@ def test_knet_stack_vs_torch_modules():
     assert err.max().item() < 2e-3 and err.mean().item() < 1e-4
     for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
         assert torch.allclose(b1.float(), b2.float(), rtol=1e-4, atol=1e-5), n1
+
+
+@pytest.mark.parametrize("N,C,H,W,relu,res", [(5, 32, 24, 40, True, False), (5, 64, 16, 20, False, True), (1, 3, 8, 12, True, True)])
+def test_bn2d_train_act_vs_torch(N, C, H, W, relu, res):
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 3 + 1).to(DEV)
+    r = torch.randn(N, C, H, W, generator=g).to(DEV) if res else None
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    want = F.batch_norm(x, None, None, gamma, beta, training=True, eps=1e-5)
+    if relu:
+        want = torch.relu(want)
+    if res:
+        want = want + r
+    got, mv = ops.bn2d_train_act(x.clone(), gamma, beta, 1e-5, relu=relu, residual=r, want_mean_var=True)
+    assert (got - want).abs().max().item() < 2e-5
+    assert torch.allclose(mv[:, 0], x.mean((0, 2, 3)), atol=1e-5)
+    assert torch.allclose(mv[:, 1], x.var((0, 2, 3), unbiased=False), rtol=1e-4, atol=1e-5)
+
+
+def test_avgpool8_and_feature_cnn_fused_vs_modules():
+    """The fused inference path of the feature CNN equals running the same modules the plain torch way."""
+    import copy
+    from neuralrgbd_amd import nets, ops, synth
+    x = torch.randn(2, 7, 64, 128, device=DEV)
+    assert (ops.avgpool8(x) - F.avg_pool2d(x, 8)).abs().max().item() < 1e-6
+    net = nets.FeatureExtractor(feature_dim=64, multi_scale=True)
+    net.load_state_dict(synth.seeded_state_dict(net, 4))
+    net = net.to(DEV)
+    ref = copy.deepcopy(net)
+    img = torch.randn(5, 3, 256, 320, device=DEV)
+    with torch.no_grad():
+        half, feat = net(img)
+    with torch.enable_grad():               # autograd on -> the plain module path
+        half_r, feat_r = ref(img)
+    e1, e2 = (half - half_r).abs().max().item(), (feat - feat_r).abs().max().item()
+    print("[parity] feature CNN fused vs modules: layer1 max|d|=%.2e feat max|d|=%.2e (|feat|max %.1f)" %
+          (e1, e2, feat_r.abs().max().item()))
+    assert e1 < 1e-3 and e2 < 2e-3
+    for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(b1.float(), b2.float(), rtol=1e-3, atol=1e-4), n1
