@@ -20,11 +20,13 @@
 // Tiling: workgroup = 256 threads = 4 waves = 2 x 8 x 16 output voxels x 64 output channels; a wave
 // owns 4 rows x 16 x = 64 voxels = two 32-row MFMA tiles x two 32-column tiles (64 accumulator VGPRs).
 // The K loop runs over channel blocks of 16: the (4 x 10 x 18)-voxel halo tile of the block is staged
-// in LDS as [voxel][16 + 4 pad] (80-byte voxel stride = odd number of 16-B words, conflict-free
-// ds_read_b128), then 27 taps x 2 k-groups, each = 2 A reads (LDS, b128) + 2 B loads (L2, 16 B per
+// in LDS as [voxel][16] with the 16-B slots XOR-swizzled by the voxel index (conflict-free
+// ds_read_b128 at a 64-B stride, no padding), then 27 taps x 2 k-groups, each = 2 A reads (LDS, b128) + 2 B loads (L2, 16 B per
 // lane) + 16 MFMAs.  One b128 feeds FOUR k-steps: step e of a group contracts channel 4g+e (lanes
 // 0-31) and channel 8+4g+e (lanes 32-63) — the contraction order is free, A and B just agree on it.
 // MFMA row i <-> voxel: the 16 lanes of each ds_read_b128 lane group take 16 consecutive x of one row.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace nrgbd {
@@ -36,7 +38,13 @@ constexpr int kTD = 2, kTH = 8, kTW = 16;                   // output tile (voxe
 constexpr int kHD = kTD + 2, kHH = kTH + 2, kHW = kTW + 2;  // halo tile
 constexpr int kHaloVox = kHD * kHH * kHW;                   // 720
 constexpr int kCB = 16;                                     // channels per K block
-constexpr int kSV = kCB + 4;                                // LDS voxel stride (floats)
+constexpr int kSV = kCB;                                    // LDS voxel stride (floats): 64 B, XOR-swizzled
+
+// LDS image of the halo tile: [voxel][4 x 16 B], the 16-B slot s of voxel v stored at slot s ^ ((v >> 2) & 3).
+// A ds_read_b128 lane group reads one logical slot of 16 consecutive voxels: voxels v, v+4, v+8, v+12 share a
+// bank quad at a 64-B stride, the swizzle sends them to 4 different slots -> conflict-free without padding
+// (46 KB per workgroup instead of 57.6 KB: three workgroups per CU).
+__device__ __forceinline__ int lds_slot(int voxel, int slot) { return voxel * kSV + ((slot ^ ((voxel >> 2) & 3)) << 2); }
 constexpr int kCout = 64;
 
 struct Conv3dArgs {
@@ -94,13 +102,18 @@ __device__ __forceinline__ void stage_halo(const Conv3dArgs& a, int cblk, float*
             if (a.mat && hz >= 1 && hz <= kTD && hy >= 1 && hy <= kTH && hx >= 1 && hx <= kTW)
                 *reinterpret_cast<f32x4*>(a.mat + vox * CIN + c) = v;
         }
-        *reinterpret_cast<f32x4*>(lds + hv * kSV + c4 * 4) = v;
+        *reinterpret_cast<f32x4*>(lds + lds_slot(hv, c4)) = v;
     }
 }
 
-template <int CIN>
-__global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const Conv3dArgs a) {
+// PF = true (layers without a residual operand, Cin = 64): the raw input words of channel block c+1 are
+// fetched into registers WHILE the 864 MFMAs of block c run (one 16-B load per step, so each load's latency
+// hides inside the one-step-ahead operand pipeline), and are normalised / activated / written to LDS after
+// the loop — the matrix pipe no longer idles during staging (78.9 % busy without it, rocprofv3 PMC).
+template <int CIN, bool PF>
+__global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv3dArgs a) {
     constexpr int NCBLK = CIN / kCB;
+    constexpr int NPF = (kHaloVox * (kCB / 4) + 255) / 256;  // 16-B words per thread per block (12)
     constexpr int G4 = kCB / 8;  // k-groups per block (4 k-steps = 8 channels each)
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [kHaloVox][kSV] (+ 4*128 floats stats)
 
@@ -117,9 +130,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const Conv3dArgs a)
     row_to_yx(i, dy, px);
     const int wz = wv >> 1, wy = (wv & 1) * 4;
     // halo-relative voxel index of (wz, wy + 2m + dy, px) for tap (0,0,0); + tap offset per tap
-    const int hv0 = ((wz * kHH) + (wy + dy)) * kHW + px;
-    const float* a_base0 = lds + hv0 * kSV + khalf * (kCB / 2);
-    const float* a_base1 = a_base0 + 2 * kHW * kSV;  // m = 1: two rows further
+    const int hv0 = ((wz * kHH) + (wy + dy)) * kHW + px;   // m = 0
+    const int hv1 = hv0 + 2 * kHW;                         // m = 1: two rows further
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -129,8 +141,53 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const Conv3dArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
+    // prefetch bookkeeping: word u of this thread = halo voxel (tid>>2) + 64u, 16-B word tid&3 of the block
+    const int c4 = tid & 3;
+    unsigned pf_off[PF ? NPF : 1];   // element offset of the voxel's channel 0 (+ c4*4), ~0u outside the volume
+    unsigned pf_own = 0;             // bit u: the voxel belongs to this tile's interior (materialise target)
+    f32x4 pre[PF ? NPF : 1];
+    if constexpr (PF) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u) {
+            const int hv = (tid >> 2) + 64 * u;
+            const int hz = hv / (kHH * kHW), rem = hv - hz * (kHH * kHW);
+            const int hy = rem / kHW, hx = rem - hy * kHW;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = hv < kHaloVox && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            pf_off[u] = ok ? (unsigned)((((size_t)gz * a.H + gy) * a.W + gx) * CIN + c4 * 4) : ~0u;
+            if (ok && hz >= 1 && hz <= kTD && hy >= 1 && hy <= kTH && hx >= 1 && hx <= kTW) pf_own |= 1u << u;
+        }
+#pragma unroll
+        for (int u = 0; u < NPF; ++u)
+            pre[u] = (pf_off[u] != ~0u) ? *reinterpret_cast<const f32x4*>(a.x + pf_off[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
     for (int cblk = 0; cblk < NCBLK; ++cblk) {
-        stage_halo<CIN>(a, cblk, lds, tid, x0, y0, z0);
+        if constexpr (PF) {
+            // normalise / activate the prefetched words of this block and publish them to LDS
+            const int c = cblk * kCB + c4 * 4;
+            float ss[8] = {1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f};
+            if (a.x_ss) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss[e] = a.x_ss[2 * c + e];
+            }
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int hv = (tid >> 2) + 64 * u;
+                if (hv >= kHaloVox) continue;
+                f32x4 v = pre[u];
+                if (pf_off[u] != ~0u) {
+                    v.x = __builtin_fmaf(v.x, ss[0], ss[1]); v.y = __builtin_fmaf(v.y, ss[2], ss[3]);
+                    v.z = __builtin_fmaf(v.z, ss[4], ss[5]); v.w = __builtin_fmaf(v.w, ss[6], ss[7]);
+                    if (a.x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (a.mat && ((pf_own >> u) & 1u))
+                        *reinterpret_cast<f32x4*>(a.mat + pf_off[u] + cblk * kCB) = v;
+                }
+                *reinterpret_cast<f32x4*>(lds + lds_slot(hv, c4)) = v;
+            }
+        } else {
+            stage_halo<CIN>(a, cblk, lds, tid, x0, y0, z0);
+        }
         __syncthreads();
 
         // ---- 27 taps x G4 k-groups; B operand streamed from L2 (packed: one 1 KB line per wave load) ----
@@ -138,19 +195,31 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const Conv3dArgs a)
         constexpr int WSTEP = NCBLK * G4 * 2 * 64;  // f32x4 per tap
         f32x4 Bn[2][2], An[2][2];
         Bn[0][0] = wb[0]; Bn[0][1] = wb[64];
-        An[0][0] = *reinterpret_cast<const f32x4*>(a_base0);
-        An[0][1] = *reinterpret_cast<const f32x4*>(a_base1);
+        An[0][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv0, khalf * 2));
+        An[0][1] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv1, khalf * 2));
 #pragma unroll
         for (int s = 0; s < 27 * G4; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
             if (s + 1 < 27 * G4) {  // prefetch step s+1
                 const int tap = (s + 1) / G4, g = (s + 1) % G4;
                 const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                const int aoff = ((kd * kHH + kh) * kHW + kw) * kSV + g * 4;
-                An[nxt][0] = *reinterpret_cast<const f32x4*>(a_base0 + aoff);
-                An[nxt][1] = *reinterpret_cast<const f32x4*>(a_base1 + aoff);
+                const int voff = (kd * kHH + kh) * kHW + kw;  // tap offset in halo voxels
+                // opaque copy: the swizzled address is recomputed here (6 VALU beside 16 MFMAs) instead of all
+                // 54 x 2 addresses being hoisted out of the unrolled loop into registers (that spills)
+                int h0 = hv0;
+                asm volatile("" : "+v"(h0));
+                An[nxt][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(h0 + voff, khalf * 2 + g));
+                An[nxt][1] = *reinterpret_cast<const f32x4*>(lds + lds_slot(h0 + 2 * kHW + voff, khalf * 2 + g));
                 const f32x4* wn = wb + (size_t)tap * WSTEP + g * (2 * 64);
                 Bn[nxt][0] = wn[0]; Bn[nxt][1] = wn[64];
+            }
+            if constexpr (PF) {  // one word of the NEXT channel block per step, steps 2 .. 2+NPF-1
+                constexpr int PF0 = 2;
+                if (s >= PF0 && s < PF0 + NPF && cblk + 1 < NCBLK) {
+                    const int u = s - PF0;
+                    pre[u] = (pf_off[u] != ~0u) ? *reinterpret_cast<const f32x4*>(a.x + pf_off[u] + (cblk + 1) * kCB)
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -220,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_cout1_kernel(const Conv3dArgs a
     const int ty = t % tiles_y; const int tz = t / tiles_y;
     const int x0 = tx * kTW, y0 = ty * kTH, z0 = tz * kTD;
     const int ox = tid & 15, oy = (tid >> 4) & 7, oz = tid >> 7;
-    const float* base = lds + ((oz * kHH + oy) * kHW + ox) * kSV;
+    const int hv_base = (oz * kHH + oy) * kHW + ox;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (int cblk = 0; cblk < NCBLK; ++cblk) {
         stage_halo<CIN>(a, cblk, lds, tid, x0, y0, z0);
@@ -228,11 +297,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_cout1_kernel(const Conv3dArgs a
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const float* pv = base + ((kd * kHH + kh) * kHW + kw) * kSV;
+            const int hv = hv_base + (kd * kHH + kh) * kHW + kw;
             const float* pw = w1 + tap * CIN + cblk * kCB;
 #pragma unroll
             for (int c4 = 0; c4 < kCB / 4; ++c4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(pv + c4 * 4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv, c4));
                 acc0 = __builtin_fmaf(v.x, pw[c4 * 4 + 0], acc0);
                 acc1 = __builtin_fmaf(v.y, pw[c4 * 4 + 1], acc1);
                 acc2 = __builtin_fmaf(v.z, pw[c4 * 4 + 2], acc2);
@@ -328,11 +397,14 @@ extern "C" int nrgbd_conv3d_3x3x3_f32(const float* x, const float* x_ss, int x_r
     if (Cout != kCout || (Cin != 16 && Cin != 64)) return NRGBD_E_SHAPE;
     Conv3dArgs a{x, x_ss, res, res_ss, materialized, w_packed, y, stats, x_relu, res_relu, D, H, W};
     const int nwg = ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
-    const size_t lds = (size_t)kHaloVox * kSV * sizeof(float);  // 57,600 B (>= the 2 KB the statistics reuse)
+    const size_t lds = (size_t)kHaloVox * kSV * sizeof(float);  // 46,080 B (>= the 2 KB the statistics reuse)
+    const bool prefetch = (Cin == 64) && !res && ((long)D * H * W * Cin < (1L << 32)) && !getenv("NRGBD_CONV3D_NOPF");
     if (Cin == 16)
-        hipLaunchKernelGGL(conv3d_mfma_kernel<16>, dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv3d_mfma_kernel<16, false>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    else if (prefetch)
+        hipLaunchKernelGGL((conv3d_mfma_kernel<64, true>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(conv3d_mfma_kernel<64>, dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv3d_mfma_kernel<64, false>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }
