@@ -86,6 +86,20 @@ int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc,
                       int V, int C, int Cp, int D, int h, int w, void* stream);
 
 /*
+ * nrgbd_costvol_bwd — backward of nrgbd_costvol_fwd with respect to the packed features (training).
+ * Replaces: what autograd records for warping/homography.py:293-331 (grid_sample backward scatter-add,
+ * broadcast subtract, channel sum).  Same geometry arguments as the forward.
+ *   g_cost [D][h][w]  gradient of the loss w.r.t. out_cost
+ *   g_ref  [h][w][Cp], g_src [V][h][w][Cp]   overwritten (zeroed by the call, then accumulated)
+ */
+int nrgbd_costvol_bwd(const float* ref_nhwc, const float* src_nhwc,
+                      const float* KR, const float* Kt, const float* rays,
+                      const float* d_candi, float cx, float cy, float sigma,
+                      int dist, int align_corners, const float* g_cost,
+                      float* g_ref, float* g_src,
+                      int V, int C, int Cp, int D, int h, int w, void* stream);
+
+/*
  * nrgbd_warp_volume — plane-sweep warp of low-channel maps with the samples kept, plus
  * the K-Net input-volume assembly.
  * Replaces: warping/homography.py:234-280 warp_img_feats_v3 / :183-232 warp_img_feats_mgpu

@@ -59,22 +59,28 @@ class DNet(nn.Module):
         F_dim, h, w = feats.shape[1:]
         C = F_dim + (3 if self.use_img_intensity else 0)
         # avg-pooled RGB appended as channels F..F+2 and the whole window transposed to 16-B texels
-        texels = ops.pack_nhwc(feats, frames if self.use_img_intensity else None)
-        self.texels = texels
-
         cam = self.cam_intrinsics if cam_intrinsics is None else cam_intrinsics
         dev = feats.device
         K, rays = warp_homo._cam_dev(cam, dev)
         KR, Kt = warp_homo.homography_terms(K, src_cam_poses[0, :, :3, :3], src_cam_poses[0, :, :3, 3])
         cx, cy = cam['intrinsic_M'][0, 2], cam['intrinsic_M'][1, 2]
-        cost, logp = ops.costvol(texels[V], texels[:V], KR, Kt, rays, warp_homo._d_candi_dev(self.d_candi, dev),
-                                 cx, cy, self.sigma_soft_max, C, dist=self.feat_dist,
-                                 align_corners=self.align_corners, want_cost=not self.BV_log,
-                                 want_logp=self.BV_log)
-        if self.BV_log:
-            BV = logp.unsqueeze(0)
+        d_dev = warp_homo._d_candi_dev(self.d_candi, dev)
+        rgb = frames if self.use_img_intensity else None
+        if torch.is_grad_enabled() and feats.requires_grad:
+            # training: same kernels behind autograd.Function (backward = csrc/costvol_bwd.hip)
+            from .autograd import PackNHWC, PlaneSweepCost
+            texels = PackNHWC.apply(feats, rgb)
+            cost = PlaneSweepCost.apply(texels, KR, Kt, rays, d_dev, cx, cy, self.sigma_soft_max, C,
+                                        self.feat_dist, self.align_corners)
+            self.texels = texels.detach()
+            BV = (torch.log_softmax(-cost, dim=0) if self.BV_log else torch.softmax(-cost, dim=0)).unsqueeze(0)
         else:
-            BV = torch.softmax(-cost.unsqueeze(0), dim=1)
+            texels = ops.pack_nhwc(feats, rgb)
+            self.texels = texels
+            cost, logp = ops.costvol(texels[V], texels[:V], KR, Kt, rays, d_dev, cx, cy, self.sigma_soft_max, C,
+                                     dist=self.feat_dist, align_corners=self.align_corners,
+                                     want_cost=not self.BV_log, want_logp=self.BV_log)
+            BV = logp.unsqueeze(0) if self.BV_log else torch.softmax(-cost.unsqueeze(0), dim=1)
 
         if BV_predict is not None:  # filtering inside the D-Net (unused by KVNET, basic.py:304-314)
             if not self.BV_log:
@@ -168,16 +174,18 @@ class KVNET(nn.Module):
         rgb_ref = texels[V, :, :, F_dim:]
         fused = (not torch.is_grad_enabled()) and self.kv_net.in_channels == 16 and self.KVNet_feature_dim == 64 \
             and not self.kv_net.if_normalize and self.kv_net.up_sample_ratio is None
-        volume = ops.warp_volume(rgb_src, (h * w * Cp, 1, w * Cp, Cp), rgb_ref, (1, w * Cp, Cp),
-                                 KR, Kt, rays, warp_homo._d_candi_dev(self.d_candi, dev), cx, cy,
-                                 V, 3, h, w, bv_cur=BV_cur[0], bv_pred=BV_predict[0],
-                                 align_corners=self.d_net.align_corners, channels_last=fused)
+        warp_args = (rgb_src, (h * w * Cp, 1, w * Cp, Cp), rgb_ref, (1, w * Cp, Cp), KR, Kt, rays,
+                     warp_homo._d_candi_dev(self.d_candi, dev), cx, cy, V, 3, h, w)
         if fused:   # inference: hand-written MFMA conv3d stack on the channels-last volume
+            volume = ops.warp_volume(*warp_args, bv_cur=BV_cur[0], bv_pred=BV_predict[0],
+                                     align_corners=self.d_net.align_corners, channels_last=True)
             gain = self.kv_net.forward_channels_last(volume)                # [D,h,w]
-        else:       # autograd path (training): torch modules on the NCDHW volume
-            gain = self.kv_net(volume.unsqueeze(0))[0, 0]
-        # ---- UPDATE: DPV = log_softmax(gain + BV_predict) ----
-        DPV = ops.logsoftmax_d(gain, BV_predict[0]).unsqueeze(0)
+            DPV = ops.logsoftmax_d(gain, BV_predict[0]).unsqueeze(0)        # UPDATE
+        else:       # autograd path (training): the warped RGB is constant, BV_cur - BV_predict carries the gradient
+            warped = ops.warp_volume(*warp_args, align_corners=self.d_net.align_corners)   # [15,D,h,w]
+            volume = torch.cat((warped, BV_cur - BV_predict), dim=0).unsqueeze(0)
+            gain = self.kv_net(volume)                                      # torch modules, [1,1,D,h,w]
+            DPV = torch.log_softmax(torch.squeeze(gain, dim=1) + BV_predict, dim=1)
 
         dmap_refined = self._refine(DPV, features) if self.if_refined else -1
         return dmap_cur_refined, dmap_refined, BV_cur, DPV

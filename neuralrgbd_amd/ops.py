@@ -86,6 +86,24 @@ def costvol(ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, cx, cy, sigma, C, dist="L
     return cost, logp
 
 
+def costvol_bwd(ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, cx, cy, sigma, C, g_cost, dist="L2", align_corners=False):
+    """Gradient of the cost volume w.r.t. the packed features: (g_ref [h,w,Cp], g_src [V,h,w,Cp])."""
+    src_nhwc = _need(src_nhwc, "src_nhwc")
+    V, h, w, Cp = src_nhwc.shape
+    ref_nhwc = _need(ref_nhwc, "ref_nhwc", (h, w, Cp))
+    d_candi = _need(d_candi, "d_candi")
+    D = d_candi.numel()
+    g_cost = _need(g_cost, "g_cost", (D, h, w))
+    g_ref, g_src = torch.empty_like(ref_nhwc), torch.empty_like(src_nhwc)
+    with torch.cuda.device(src_nhwc.device):
+        rc = _lib.load().nrgbd_costvol_bwd(_p(ref_nhwc), _p(src_nhwc), _p(_need(KR, "KR").reshape(V, 9)), _p(_need(Kt, "Kt", (V, 3))),
+                                           _p(_need(rays, "rays", (3, h * w))), _p(d_candi), float(cx), float(cy), float(sigma),
+                                           DIST[dist], int(bool(align_corners)), _p(g_cost), _p(g_ref), _p(g_src),
+                                           V, int(C), Cp, D, h, w, _stream(src_nhwc))
+    _lib.check(rc, "nrgbd_costvol_bwd")
+    return g_ref, g_src
+
+
 def warp_volume(src, src_strides, ref, ref_strides, KR, Kt, rays, d_candi, cx, cy, V, Cs, h, w,
                 bv_cur=None, bv_pred=None, align_corners=False, channels_last=False):
     """Plane-sweep warp with samples kept (+ K-Net input assembly) -> [V*Cs (+Cs) (+1), D, h, w]
