@@ -275,10 +275,9 @@ __global__ __launch_bounds__(256, 2) void costvol_lds(const CostvolArgs a) {
                             const int i = min(tid + 256 * (it0 + u), total - 1);
                             const int q = i / NS, jw = i - q * NS;
                             const int qy = (cols > 1) ? (int)__umulhi((unsigned)q, magic) : q;
-                            const int qx = q - qy * cols;
+                            const int qx = q - __mul24(qy, cols);
                             // 32-bit element offset from the (uniform) view base: SGPR base + VGPR offset loads
-                            const unsigned off = ((unsigned)(ylo + qy) * (unsigned)a.w + (unsigned)(xlo + qx)) * (unsigned)a.Cp
-                                                 + 4u * (unsigned)(W0 + jw);
+                            const unsigned off = (unsigned)__mul24(__mul24(ylo + qy, a.w) + (xlo + qx), a.Cp) + 4u * (unsigned)(W0 + jw);
                             tmp[u] = *reinterpret_cast<const float4*>(sv + off);
                         }
 #pragma unroll
@@ -312,13 +311,13 @@ __global__ __launch_bounds__(256, 2) void costvol_lds(const CostvolArgs a) {
                         b.sw = (vx0 && vy1) ? fy * ex : 0.f; b.se = (vx1 && vy1) ? fy * fx : 0.f;
                         // patch-relative texel indices; a tap that is out of view reads texel 0 with weight 0
                         const int xo0 = vx0 ? (int)x0f - xlo : 0, xo1 = vx1 ? (int)x1f - xlo : 0;
-                        const int yo0 = vy0 ? ((int)y0f - ylo) * cols : 0, yo1 = vy1 ? ((int)y1f - ylo) * cols : 0;
+                        const int yo0 = vy0 ? __mul24((int)y0f - ylo, cols) : 0, yo1 = vy1 ? __mul24((int)y1f - ylo, cols) : 0;
                         const int last = area - 1;  // belt and braces: never address outside the patch
                         const f32x4* sm = reinterpret_cast<const f32x4*>(smem4);
-                        const f32x4* tnw = sm + min(max(yo0 + xo0, 0), last) * S4;
-                        const f32x4* tne = sm + min(max(yo0 + xo1, 0), last) * S4;
-                        const f32x4* tsw = sm + min(max(yo1 + xo0, 0), last) * S4;
-                        const f32x4* tse = sm + min(max(yo1 + xo1, 0), last) * S4;
+                        const f32x4* tnw = sm + __mul24(min(max(yo0 + xo0, 0), last), S4);
+                        const f32x4* tne = sm + __mul24(min(max(yo0 + xo1, 0), last), S4);
+                        const f32x4* tsw = sm + __mul24(min(max(yo1 + xo0, 0), last), S4);
+                        const f32x4* tse = sm + __mul24(min(max(yo1 + xo1, 0), last), S4);
                         // Packed fp32 math on the (x,y) and (z,w) halves of each 16-B word (v_pk_fma_f32: two
                         // channels per instruction, adjacent registers, no shuffles); two independent
                         // 2-wide partial sums keep the FMA chains short.
