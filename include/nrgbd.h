@@ -194,6 +194,18 @@ int nrgbd_conv3d_3x3x3_cout1_f32(const float* x, const float* x_ss, int x_relu,
                                  const float* res, const float* res_ss, int res_relu,
                                  const float* w_tap_major, float* y,
                                  int D, int H, int W, int Cin, void* stream);
+/*
+ * nrgbd_conv3d_wgrad_f32 — weight gradient of the 3x3x3 convolution (training):
+ *   dW[co][ci][kd][kh][kw] = sum_voxels gy[v][co] * x[v + tap][ci]      (x zero outside the volume)
+ * Replaces what autograd/MIOpen compute for nn.Conv3d.weight.grad in models/basic.py:71-94.
+ *   x [D][H][W][Cin], gy [D][H][W][64] channels-last; dw [64][Cin][3][3][3] (torch layout, overwritten);
+ *   partial: scratch of nrgbd_conv3d_wgrad_workgroups() * 27 * 64 * Cin floats.
+ * The data gradient needs no new kernel: it is nrgbd_conv3d_3x3x3_f32 applied to gy with the weights
+ * transposed (cin <-> cout) and flipped in all three tap axes.
+ */
+int nrgbd_conv3d_wgrad_workgroups(void);
+int nrgbd_conv3d_wgrad_f32(const float* x, const float* gy, float* partial, float* dw,
+                           int D, int H, int W, int Cin, void* stream);
 int nrgbd_bn3d_finalize(const float* stats, int num_workgroups, long count,
                         const float* gamma, const float* beta, float eps, float momentum,
                         float* running_mean, float* running_var, float* scale_shift, void* stream);

@@ -41,3 +41,35 @@ class PlaneSweepCost(torch.autograd.Function):
         g_ref, g_src = ops.costvol_bwd(texels[V], texels[:V], KR, Kt, rays, d_candi, cx, cy, sigma, C,
                                        g_cost.contiguous(), dist=dist, align_corners=align)
         return (torch.cat((g_src, g_ref.unsqueeze(0)), dim=0),) + (None,) * 10
+
+
+class Conv3dCL(torch.autograd.Function):
+    """3x3x3 convolution (stride 1, padding 1, no bias, 64 outputs) on channels-last activations, both directions on
+    the fp32 matrix cores: forward = csrc/conv3d.hip; data gradient = the same kernel on the output gradient with
+    transposed + flipped weights; weight gradient = csrc/conv3d_wgrad.hip.
+
+    x [D,H,W,Cin] (Cin in {16, 64}), w [64,Cin,3,3,3] -> y [D,H,W,64].
+    """
+
+    @staticmethod
+    def forward(ctx, x, w):
+        y, _, _ = ops.conv3d(x.contiguous(), ops.conv3d_pack_weights(w.contiguous()), want_stats=False)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv3d_wgrad(x.contiguous(), gy)
+        if ctx.needs_input_grad[0]:
+            cin = w.shape[1]
+            wt = w.transpose(0, 1).flip(2, 3, 4)                      # [Cin, 64, 3,3,3]: correlation with the flipped kernel
+            if cin < 64:                                              # the kernel produces 64 outputs: pad, then slice
+                wt = torch.cat((wt, wt.new_zeros(64 - cin, 64, 3, 3, 3)), dim=0)
+            gx, _, _ = ops.conv3d(gy, ops.conv3d_pack_weights(wt.contiguous()), want_stats=False)
+            if cin < 64:
+                gx = gx[..., :cin].contiguous()
+        return gx, gw

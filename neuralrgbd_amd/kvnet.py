@@ -183,9 +183,12 @@ class KVNET(nn.Module):
             DPV = ops.logsoftmax_d(gain, BV_predict[0]).unsqueeze(0)        # UPDATE
         else:       # autograd path (training): the warped RGB is constant, BV_cur - BV_predict carries the gradient
             warped = ops.warp_volume(*warp_args, align_corners=self.d_net.align_corners)   # [15,D,h,w]
-            volume = torch.cat((warped, BV_cur - BV_predict), dim=0).unsqueeze(0)
-            gain = self.kv_net(volume)                                      # torch modules, [1,1,D,h,w]
-            DPV = torch.log_softmax(torch.squeeze(gain, dim=1) + BV_predict, dim=1)
+            volume = torch.cat((warped, BV_cur - BV_predict), dim=0)                       # [16,D,h,w]
+            if self.kv_net.in_channels == 16 and self.KVNet_feature_dim == 64 and torch.is_grad_enabled():
+                gain = self.kv_net.forward_channels_last_autograd(volume.permute(1, 2, 3, 0).contiguous()).unsqueeze(0)
+            else:
+                gain = torch.squeeze(self.kv_net(volume.unsqueeze(0)), dim=1)   # torch modules
+            DPV = torch.log_softmax(gain + BV_predict, dim=1)
 
         dmap_refined = self._refine(DPV, features) if self.if_refined else -1
         return dmap_cur_refined, dmap_refined, BV_cur, DPV

@@ -291,6 +291,38 @@ class KalmanGainNet(nn.Module):
         conv, _ = L[11]
         return ops.conv3d_cout1(z, self._packed(conv), x_ss=ss, x_relu=True)  # classify.2
 
+    def forward_channels_last_autograd(self, vol):
+        """Training path: same graph on channels-last activations with the convolutions (forward, data gradient and
+        weight gradient) on the hand-written matrix-core kernels (autograd.Conv3dCL); BatchNorm3d / ReLU / adds are
+        ordinary torch autograd ops on the [1,C,D,H,W] view of the channels-last tensor.  vol [D,H,W,Cin] -> [D,H,W]."""
+        from .autograd import Conv3dCL
+
+        def as_ncdhw(t):           # [D,H,W,C] -> [1,C,D,H,W] view (channels_last_3d strides)
+            return t.permute(3, 0, 1, 2).unsqueeze(0)
+
+        def as_cl(t):              # back to a contiguous [D,H,W,C]
+            return t[0].permute(1, 2, 3, 0).contiguous()
+
+        L = self._layers()
+
+        def cbr(x_cl, i, relu):
+            conv, bn = L[i]
+            y = bn(as_ncdhw(Conv3dCL.apply(x_cl, conv.weight)))
+            return torch.relu(y) if relu else y
+
+        x = cbr(vol, 0, True)
+        x = cbr(as_cl(x), 1, True)
+        for i in (2, 4, 6, 8):
+            y = cbr(as_cl(x), i, True)
+            x = cbr(as_cl(y), i + 1, False) + x
+        y = cbr(as_cl(x), 10, True)
+        # classify.2 = Conv3d(64, 1): zero-padded to 64 outputs so that forward, data gradient and weight gradient
+        # all run on the matrix-core kernels (the vendor weight-gradient of this layer alone costs 58 ms at the
+        # ScanNet grid); autograd's slice / cat backward route the gradients of the single real output channel
+        w1 = L[11][0].weight
+        w_pad = torch.cat((w1, w1.new_zeros(63, *w1.shape[1:])), dim=0)
+        return Conv3dCL.apply(as_cl(y), w_pad)[..., 0]
+
     def forward(self, volume):
         if volume.shape[1] != self.in_channels:
             raise AssertionError("Input volume should have correct # of channels !")

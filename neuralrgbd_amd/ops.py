@@ -227,6 +227,20 @@ def conv3d(x, w_packed, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu
     return y, stats, mat
 
 
+def conv3d_wgrad(x, gy):
+    """Weight gradient of the channels-last 3x3x3 convolution: x [D,H,W,Cin], gy [D,H,W,64] -> dW [64,Cin,3,3,3]."""
+    x = _need(x, "x")
+    D, H, W, Cin = x.shape
+    gy = _need(gy, "gy", (D, H, W, 64))
+    nwg = int(_lib.load().nrgbd_conv3d_wgrad_workgroups())
+    partial = torch.empty(nwg * 27 * 64 * Cin, dtype=torch.float32, device=x.device)
+    dw = torch.empty((64, Cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv3d_wgrad_f32(_p(x), _p(gy), _p(partial), _p(dw), D, H, W, Cin, _stream(x))
+    _lib.check(rc, "nrgbd_conv3d_wgrad_f32")
+    return dw
+
+
 def conv3d_cout1(x, w_tap_major, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False):
     """Last K-Net layer: x [D,H,W,64] -> y [D,H,W]; w_tap_major [27,64]."""
     x = _need(x, "x")

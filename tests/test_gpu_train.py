@@ -91,3 +91,47 @@ def test_one_training_iteration_updates_weights_and_predicts():
     assert not torch.equal(before, model.kv_net.dres1[0][0].weight)
     assert not torch.equal(before_f, model.feature_extractor.feature_extraction.firstconv[0][0].weight)
     assert lo.shape == (1, H // 4, W // 4) and hi.shape == (1, H, W)
+
+
+@pytest.mark.parametrize("D,H,W,Cin", [(4, 8, 16, 64), (3, 9, 21, 16), (6, 12, 40, 64)])
+def test_conv3d_backward_kernels_vs_torch_autograd(D, H, W, Cin):
+    """Data gradient (forward kernel on flipped/transposed weights) and weight gradient (conv3d_wgrad.hip)."""
+    from neuralrgbd_amd.autograd import Conv3dCL
+    g = torch.Generator().manual_seed(D + W)
+    x = torch.randn(Cin, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, Cin, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    gy = torch.randn(64, D, H, W, generator=g).to(DEV)
+    x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    (F.conv3d(x1[None], w1, padding=1)[0] * gy).sum().backward()
+    x2, w2 = x.permute(1, 2, 3, 0).contiguous().requires_grad_(True), w.clone().requires_grad_(True)
+    (Conv3dCL.apply(x2, w2) * gy.permute(1, 2, 3, 0)).sum().backward()
+    ex = (x2.grad.permute(3, 0, 1, 2) - x1.grad).abs().max().item()
+    ew = (w2.grad - w1.grad).abs().max().item()
+    print("[parity] conv3d backward %dx%dx%d Cin=%d: max|d gx|=%.2e (|gx|max %.1f)  max|d gw|=%.2e (|gw|max %.1f)" %
+          (D, H, W, Cin, ex, x1.grad.abs().max().item(), ew, w1.grad.abs().max().item()))
+    assert ex < 5e-5 * max(1.0, x1.grad.abs().max().item())
+    assert ew < 1e-4 * max(1.0, w1.grad.abs().max().item())
+
+
+def test_knet_training_path_matches_module_path():
+    """forward_channels_last_autograd (hand-written conv kernels under autograd) == the nn.Module graph: outputs and
+    parameter gradients."""
+    import copy
+    from neuralrgbd_amd import nets
+    net = nets.KalmanGainNet(16, feature_dim=64)
+    net.load_state_dict(synth.seeded_state_dict(net, 5))
+    net = net.to(DEV)
+    ref = copy.deepcopy(net)
+    D, H, W = 4, 12, 24
+    vol = torch.randn(1, 16, D, H, W, device=DEV)
+    want = ref(vol)[0, 0]
+    want.square().sum().backward()
+    got = net.forward_channels_last_autograd(vol[0].permute(1, 2, 3, 0).contiguous())
+    got.square().sum().backward()
+    assert (got - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
+    worst = 0.0
+    for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref.named_parameters()):
+        rel = (p1.grad - p2.grad).abs().max().item() / max(1e-6, p2.grad.abs().max().item())
+        worst = max(worst, rel)
+    print("[parity] K-Net training path: worst relative parameter-gradient difference %.2e" % worst)
+    assert worst < 5e-3
