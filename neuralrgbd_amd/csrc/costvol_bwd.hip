@@ -21,54 +21,79 @@ struct CostvolBwdArgs {
     int dist, align, V, C, Cp, D, h, w, kchunks;
 };
 
-// grid (ceil(hw/64), kchunks), block 64: one lane = one pixel x one slice of the depth candidates
+// grid (ceil(hw/64), kchunks, Cp/4), block 64: one lane = one pixel x one slice of consecutive depth candidates x
+// one 16-byte channel word.  Consecutive candidates of a pixel sample neighbouring positions along its epipolar
+// line — for the far planes the SAME 2x2 source cell for several candidates in a row — so the four tap gradients
+// are accumulated in registers while the cell stays the same and flushed with atomics only when it changes
+// (4-8x fewer atomics than one per (pixel, candidate, view, channel); the kernel is atomic-bound).
 __global__ __launch_bounds__(64) void costvol_bwd_kernel(const CostvolBwdArgs a) {
     const size_t hw = (size_t)a.h * a.w;
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (p >= hw) return;
     const int per = (a.D + a.kchunks - 1) / a.kchunks;
     const int k_begin = blockIdx.y * per, k_end = min(a.D, k_begin + per);
-    const int cp4 = a.Cp >> 2;
+    const int i = blockIdx.z;                      // channel word
     const float rx = a.rays[p], ry = a.rays[hw + p], rz = a.rays[2 * hw + p];
     const float wf = (float)a.w, hf = (float)a.h;
-    const float4* refp = reinterpret_cast<const float4*>(a.ref + p * a.Cp);
-    for (int i = 0; i < cp4; ++i) {
-        const float4 r = refp[i];
-        float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 r = *reinterpret_cast<const float4*>(a.ref + p * a.Cp + 4 * i);
+    const int ncomp = min(4, a.C - 4 * i);         // valid components of this word
+    float gr[4] = {0.f, 0.f, 0.f, 0.f};
+
+    for (int v = 0; v < a.V; ++v) {
+        const SweepTerm st = make_sweep_term(a.KR + 9 * v, a.Kt + 3 * v, rx, ry, rz);
+        const float* sv = a.src + (size_t)v * hw * a.Cp + 4 * i;
+        float* gs = a.g_src + (size_t)v * hw * a.Cp + 4 * i;
+        // register accumulator of the current cell: 4 taps x 4 components
+        float acc[4][4];
+        float cx0 = -1e30f, cy0 = -1e30f;          // floor of the current cell (never matches initially)
+        size_t o[4] = {0, 0, 0, 0};
+        bool have = false;
+        auto flush = [&]() {
+            if (!have) return;
+#pragma unroll
+            for (int tpi = 0; tpi < 4; ++tpi)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (acc[tpi][e] != 0.f) atomicAdd(gs + o[tpi] + e, acc[tpi][e]);
+        };
         for (int k = k_begin; k < k_end; ++k) {
             const float gk = a.g_cost[(size_t)k * hw + p] / a.sigma;
-            if (gk == 0.f) continue;
-            const float d = a.d_candi[k];
-            for (int v = 0; v < a.V; ++v) {
-                const SweepTerm st = make_sweep_term(a.KR + 9 * v, a.Kt + 3 * v, rx, ry, rz);
-                float ix, iy;
-                sweep_sample_pos(st, d, a.cx, a.cy, wf, hf, a.align != 0, ix, iy);
-                const Bilinear b = bilinear_zeros(ix, iy, a.w, a.h);
-                const size_t onw = ((size_t)b.y0 * a.w + b.x0) * a.Cp + 4 * i, one = ((size_t)b.y0 * a.w + b.x1) * a.Cp + 4 * i;
-                const size_t osw = ((size_t)b.y1 * a.w + b.x0) * a.Cp + 4 * i, ose = ((size_t)b.y1 * a.w + b.x1) * a.Cp + 4 * i;
-                const float* sv = a.src + (size_t)v * hw * a.Cp;
-                float* gs = a.g_src + (size_t)v * hw * a.Cp;
-                const float4 A = *reinterpret_cast<const float4*>(sv + onw), B = *reinterpret_cast<const float4*>(sv + one);
-                const float4 Cc = *reinterpret_cast<const float4*>(sv + osw), Dd = *reinterpret_cast<const float4*>(sv + ose);
-                const float df[4] = {lerp4(A.x, B.x, Cc.x, Dd.x, b) - r.x, lerp4(A.y, B.y, Cc.y, Dd.y, b) - r.y,
-                                     lerp4(A.z, B.z, Cc.z, Dd.z, b) - r.z, lerp4(A.w, B.w, Cc.w, Dd.w, b) - r.w};
-                float* grp = &gr.x;
+            float ix, iy;
+            sweep_sample_pos(st, a.d_candi[k], a.cx, a.cy, wf, hf, a.align != 0, ix, iy);
+            const Bilinear b = bilinear_zeros(ix, iy, a.w, a.h);
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            if (!(x0f == cx0 && y0f == cy0)) {      // new cell (also taken for NaN positions)
+                flush();
+                cx0 = x0f; cy0 = y0f; have = true;
+                o[0] = ((size_t)b.y0 * a.w + b.x0) * a.Cp; o[1] = ((size_t)b.y0 * a.w + b.x1) * a.Cp;
+                o[2] = ((size_t)b.y1 * a.w + b.x0) * a.Cp; o[3] = ((size_t)b.y1 * a.w + b.x1) * a.Cp;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (4 * i + e >= a.C) continue;
-                    const float ds = (a.dist == NRGBD_DIST_L2) ? 2.f * df[e] : (df[e] > 0.f ? 1.f : (df[e] < 0.f ? -1.f : 0.f));
-                    const float c = ds * gk;
-                    grp[e] -= c;
-                    if (b.nw != 0.f) atomicAdd(gs + onw + e, b.nw * c);
-                    if (b.ne != 0.f) atomicAdd(gs + one + e, b.ne * c);
-                    if (b.sw != 0.f) atomicAdd(gs + osw + e, b.sw * c);
-                    if (b.se != 0.f) atomicAdd(gs + ose + e, b.se * c);
-                }
+                for (int tpi = 0; tpi < 4; ++tpi)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[tpi][e] = 0.f;
+            }
+            if (gk == 0.f) continue;
+            const float4 A = *reinterpret_cast<const float4*>(sv + o[0]), B = *reinterpret_cast<const float4*>(sv + o[1]);
+            const float4 Cc = *reinterpret_cast<const float4*>(sv + o[2]), Dd = *reinterpret_cast<const float4*>(sv + o[3]);
+            const float df[4] = {lerp4(A.x, B.x, Cc.x, Dd.x, b) - r.x, lerp4(A.y, B.y, Cc.y, Dd.y, b) - r.y,
+                                 lerp4(A.z, B.z, Cc.z, Dd.z, b) - r.z, lerp4(A.w, B.w, Cc.w, Dd.w, b) - r.w};
+            const float wt[4] = {b.nw, b.ne, b.sw, b.se};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e >= ncomp) continue;
+                const float ds = (a.dist == NRGBD_DIST_L2) ? 2.f * df[e] : (df[e] > 0.f ? 1.f : (df[e] < 0.f ? -1.f : 0.f));
+                const float c = ds * gk;
+                gr[e] -= c;
+#pragma unroll
+                for (int tpi = 0; tpi < 4; ++tpi) acc[tpi][e] = __builtin_fmaf(wt[tpi], c, acc[tpi][e]);
             }
         }
-        float* go = a.g_ref + p * a.Cp + 4 * i;
-        atomicAdd(go + 0, gr.x); atomicAdd(go + 1, gr.y); atomicAdd(go + 2, gr.z); atomicAdd(go + 3, gr.w);
+        flush();
     }
+    float* go = a.g_ref + p * a.Cp + 4 * i;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (gr[e] != 0.f) atomicAdd(go + e, gr[e]);
 }
 
 }  // namespace nrgbd
@@ -88,10 +113,12 @@ extern "C" int nrgbd_costvol_bwd(const float* ref_nhwc, const float* src_nhwc, c
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(g_src, 0, (size_t)V * hw * Cp * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    const int kchunks = D < 16 ? D : 16;
+    // slices of consecutive candidates: long enough for the register run-accumulation, parallelism comes from
+    // the channel-word axis of the grid
+    const int kchunks = D >= 32 ? 4 : (D >= 8 ? 2 : 1);
     CostvolBwdArgs a{ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, g_cost, g_ref, g_src, cx, cy, sigma,
                      dist, align_corners, V, C, Cp, D, h, w, kchunks};
-    hipLaunchKernelGGL(costvol_bwd_kernel, dim3(ceil_div((long)hw, 64), kchunks), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(costvol_bwd_kernel, dim3(ceil_div((long)hw, 64), kchunks, Cp >> 2), dim3(64), 0, s, a);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }
