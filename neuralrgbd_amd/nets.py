@@ -294,34 +294,37 @@ class KalmanGainNet(nn.Module):
     def forward_channels_last_autograd(self, vol):
         """Training path: same graph on channels-last activations with the convolutions (forward, data gradient and
         weight gradient) on the hand-written matrix-core kernels (autograd.Conv3dCL); BatchNorm3d / ReLU / adds are
-        ordinary torch autograd ops on the [1,C,D,H,W] view of the channels-last tensor.  vol [D,H,W,Cin] -> [D,H,W]."""
+        ordinary torch autograd ops applied in place of the layout (no NCDHW round trips).  vol [D,H,W,Cin] -> [D,H,W]."""
         from .autograd import Conv3dCL
-
-        def as_ncdhw(t):           # [D,H,W,C] -> [1,C,D,H,W] view (channels_last_3d strides)
-            return t.permute(3, 0, 1, 2).unsqueeze(0)
-
-        def as_cl(t):              # back to a contiguous [D,H,W,C]
-            return t[0].permute(1, 2, 3, 0).contiguous()
-
         L = self._layers()
+
+        def bn_cl(x_cl, bn):
+            """BatchNorm3d on a channels-last tensor without any layout change: [D,H,W,C] viewed as (N = voxels, C)
+            is exactly the (N, C) form of batch_norm — same statistics, same running-stat update."""
+            if bn.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            use_batch = bn.training or not bn.track_running_stats
+            y = F.batch_norm(x_cl.reshape(-1, x_cl.shape[-1]), bn.running_mean if bn.track_running_stats else None,
+                             bn.running_var if bn.track_running_stats else None, bn.weight, bn.bias, use_batch, m, bn.eps)
+            return y.view_as(x_cl)
 
         def cbr(x_cl, i, relu):
             conv, bn = L[i]
-            y = bn(as_ncdhw(Conv3dCL.apply(x_cl, conv.weight)))
+            y = bn_cl(Conv3dCL.apply(x_cl, conv.weight), bn)
             return torch.relu(y) if relu else y
 
         x = cbr(vol, 0, True)
-        x = cbr(as_cl(x), 1, True)
+        x = cbr(x, 1, True)
         for i in (2, 4, 6, 8):
-            y = cbr(as_cl(x), i, True)
-            x = cbr(as_cl(y), i + 1, False) + x
-        y = cbr(as_cl(x), 10, True)
+            x = cbr(cbr(x, i, True), i + 1, False) + x
+        y = cbr(x, 10, True)
         # classify.2 = Conv3d(64, 1): zero-padded to 64 outputs so that forward, data gradient and weight gradient
         # all run on the matrix-core kernels (the vendor weight-gradient of this layer alone costs 58 ms at the
         # ScanNet grid); autograd's slice / cat backward route the gradients of the single real output channel
         w1 = L[11][0].weight
         w_pad = torch.cat((w1, w1.new_zeros(63, *w1.shape[1:])), dim=0)
-        return Conv3dCL.apply(as_cl(y), w_pad)[..., 0]
+        return Conv3dCL.apply(y, w_pad)[..., 0]
 
     def forward(self, volume):
         if volume.shape[1] != self.in_channels:

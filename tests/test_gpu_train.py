@@ -113,25 +113,34 @@ def test_conv3d_backward_kernels_vs_torch_autograd(D, H, W, Cin):
     assert ew < 1e-4 * max(1.0, w1.grad.abs().max().item())
 
 
-def test_knet_training_path_matches_module_path():
-    """forward_channels_last_autograd (hand-written conv kernels under autograd) == the nn.Module graph: outputs and
-    parameter gradients."""
+def test_knet_training_path_vs_fp64_autograd():
+    """forward_channels_last_autograd (hand-written conv kernels under autograd): output and every parameter gradient
+    against float64 CPU autograd of the same nn.Module graph.  (The fp32 vendor-module path on the GPU is reported
+    too; it is NOT the oracle.)  The input is seeded on purpose: with other random inputs ANY two fp32 implementations
+    (including the vendor path vs fp64) occasionally differ by ~1e-2 in one layer's weight gradient, because a
+    pre-activation within rounding of the ReLU kink flips side (tools/knet_grad_probe.py, seeds 14-17); the kernels
+    themselves are run-to-run deterministic (tools/determinism_probe.py)."""
     import copy
     from neuralrgbd_amd import nets
     net = nets.KalmanGainNet(16, feature_dim=64)
     net.load_state_dict(synth.seeded_state_dict(net, 5))
-    net = net.to(DEV)
-    ref = copy.deepcopy(net)
+    gold_net = copy.deepcopy(net).double()
     D, H, W = 4, 12, 24
-    vol = torch.randn(1, 16, D, H, W, device=DEV)
-    want = ref(vol)[0, 0]
+    vol = torch.randn(1, 16, D, H, W, generator=torch.Generator().manual_seed(3))
+    want = gold_net(vol.double())[0, 0]
     want.square().sum().backward()
-    got = net.forward_channels_last_autograd(vol[0].permute(1, 2, 3, 0).contiguous())
+    gold = {n: p.grad.float() for n, p in gold_net.named_parameters()}
+
+    mine, vendor = copy.deepcopy(net).to(DEV), copy.deepcopy(net).to(DEV)
+    got = mine.forward_channels_last_autograd(vol[0].permute(1, 2, 3, 0).contiguous().to(DEV))
     got.square().sum().backward()
-    assert (got - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())
-    worst = 0.0
-    for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref.named_parameters()):
-        rel = (p1.grad - p2.grad).abs().max().item() / max(1e-6, p2.grad.abs().max().item())
-        worst = max(worst, rel)
-    print("[parity] K-Net training path: worst relative parameter-gradient difference %.2e" % worst)
-    assert worst < 5e-3
+    vendor(vol.to(DEV))[0, 0].square().sum().backward()
+    assert (got.cpu() - want.float()).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+    def worst(model):
+        return max(((p.grad.cpu() - gold[n]).abs().max() / gold[n].abs().max()).item() for n, p in model.named_parameters())
+    w_mine, w_vendor = worst(mine), worst(vendor)
+    print("[parity] K-Net parameter gradients vs fp64 CPU autograd: hand-written kernels %.2e, vendor modules %.2e" % (w_mine, w_vendor))
+    assert w_mine < 1e-4
+    for (n1, b1), (n2, b2) in zip(mine.named_buffers(), gold_net.named_buffers()):
+        assert torch.allclose(b1.float().cpu(), b2.float(), rtol=1e-4, atol=1e-5), n1   # running statistics
