@@ -41,6 +41,12 @@ CONFIGS = {
     "H": dict(H=480, W=640, D=128, d_min=0.1, d_max=5.0, name="480x640 image, grid 160x120x128"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM bytes per launch of the fused warp + cost-volume kernel at config B from the L2's fabric-side counters
+# (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes: tools/pmc_costvol.sh, summary in
+# profiles/r1_pmc_summary.txt): FETCH_SIZE 561,502 KB, doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950
+# (calibrated in this access pattern on logsoftmax_d: 6,283 KB reported for the 12,583 KB it reads), WRITE_SIZE
+# 12,288 KB (= the cost volume exactly).  Counters cannot be read from inside this process, hence a constant.
+PMC_TRAFFIC_BYTES = {"B": 2 * 561502 * 1024 + 12288 * 1024}
 
 
 def costvol_bytes(V, C, D, h, w):
@@ -187,7 +193,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes": algo, "kernel_ms": k_ms, "launches_timed": n_k,
                          "timing": "HIP events around back-to-back launches of the frame's own costvol call (log-softmax launch included), right after the timed region",
-                         "traffic": None},
+                         "traffic": PMC_TRAFFIC_BYTES.get(args.config),
+                         "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r1_pmc_summary.txt"
+                         if args.config in PMC_TRAFFIC_BYTES else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, cam, d_candi, sd, ring[0], pred, sigma)
