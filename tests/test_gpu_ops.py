@@ -249,3 +249,62 @@ def test_argument_errors_and_cpu_tensors_fail_loudly():
     x = torch.zeros(8, 8, device=DEV)
     assert lib.nrgbd_logsoftmax_d(ctypes.c_void_p(x.data_ptr()), None, ctypes.c_float(1),
                                   ctypes.c_void_p(x.data_ptr()), 0, 8, None) == -2
+
+
+def test_limits_and_degenerate_sizes():
+    """Maximum candidate / view counts of the C-ABI (NRGBD_MAX_D = 256, NRGBD_MAX_V = 16), D = 1, a 1-pixel-wide grid,
+    and the error codes just beyond the limits."""
+    from neuralrgbd_amd import _lib
+    ops = _ops()
+    rng = np.random.RandomState(31)
+    for (h, w, D, V, C) in ((6, 10, 256, 2, 5), (5, 7, 3, 16, 4), (9, 1, 1, 1, 3), (1, 9, 2, 1, 67)):
+        cam = camera.scannet_intrinsics(max(w, 2), max(h, 2)) if min(h, w) < 2 else camera.scannet_intrinsics(w, h)
+        cam = camera.make_cam_intrinsics(cam["hfov"], cam["vfov"], w, h)
+        feat_ref = rng.standard_normal((C, h, w)).astype(np.float32)
+        feat_src = rng.standard_normal((V, C, h, w)).astype(np.float32)
+        poses = synth.random_poses(rng, V)
+        KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+        d = np.linspace(0.2, 6, D) if D > 1 else np.array([1.5])
+        rays = cam["unit_ray_array_2D"].numpy()
+        cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
+        want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d, cx, cy, 2.0)
+        got, lp = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d, cx, cy, 2.0, logp=True)
+        assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max()), (h, w, D, V, C)
+        assert np.abs(lp - co.logsoftmax_d(want, scale=-1.0)).max() < 2e-4
+    lib = _lib.load()
+    x = torch.zeros(64, device=DEV)
+    p = ctypes.c_void_p(x.data_ptr())
+    f = ctypes.c_float
+    assert lib.nrgbd_costvol_fwd(p, p, p, p, p, p, f(1), f(1), f(1), 0, 0, p, None, 1, 4, 4, 257, 2, 2, None) == -2   # D > MAX_D
+    assert lib.nrgbd_costvol_fwd(p, p, p, p, p, p, f(1), f(1), f(1), 0, 0, p, None, 17, 4, 4, 2, 2, 2, None) == -2   # V > MAX_V
+    assert lib.nrgbd_costvol_fwd(p, p, p, p, p, p, f(1), f(1), f(1), 0, 0, p, None, 1, 4, 6, 2, 2, 2, None) == -3    # Cp % 4
+    assert lib.nrgbd_costvol_fwd(p, p, p, p, p, p, f(1), f(1), f(1), 7, 0, p, None, 1, 4, 4, 2, 2, 2, None) == -4    # metric
+    assert lib.nrgbd_costvol_fwd(p, p, p, p, p, p, f(1), f(1), f(1), 0, 0, None, None, 1, 4, 4, 2, 2, 2, None) == -1  # no output
+
+
+def test_operator_surface_matches_reference_signatures(golden_ops):
+    """neuralrgbd_amd.homography called exactly like warping.homography (tensors on the GPU) reproduces the golden
+    outputs of est_swp_volume_v4 / warp_img_feats_v3 / resample_vol_cuda — the Level-2 integration of INTEGRATION.md."""
+    from neuralrgbd_amd import homography as Hm
+    g = golden_ops
+    o = gen_golden.OPS
+    cam = camera.scannet_intrinsics(o["w"], o["h"])
+    poses = torch.from_numpy(g["poses"]).to(DEV)
+    R, t = poses[:, :3, :3].contiguous(), poses[:, :3, 3].contiguous()
+    cost = Hm.est_swp_volume_v4(_dev(g["feat_ref"])[None], _dev(g["feat_src"])[None], g["d_candi"], R, t, cam, float(g["sigma"]))
+    assert cost.shape == (1, o["D"], o["h"], o["w"]) and np.abs(cost[0].cpu().numpy() - g["cost_l2"]).max() < 1e-4
+    V = o["V"]
+    warped = Hm.warp_img_feats_v3([_dev(g["rgb"][v:v + 1]) for v in range(V)], g["d_candi"], [R[v] for v in range(V)],
+                                  [t[v] for v in range(V)], cam)
+    assert len(warped) == V and tuple(warped[0].shape) == (3, o["D"], o["h"], o["w"])
+    assert np.abs(torch.stack(warped).cpu().numpy() - g["warped"]).max() < 1e-4
+    K = cam["intrinsic_M_cuda"].to(DEV)[None]
+    rays = cam["unit_ray_array_2D"].to(DEV)[None]
+    warped2 = Hm.warp_img_feats_mgpu([_dev(g["rgb"][v:v + 1]) for v in range(V)], g["d_candi"], [R[v] for v in range(V)],
+                                     [t[v] for v in range(V)], K, rays)
+    assert np.abs(torch.stack(warped2).cpu().numpy() - g["warped"]).max() < 1e-4
+    pred = Hm.resample_vol_cuda(_dev(g["dpv"])[None], _dev(g["T"]), cam_intrinsic=cam, d_candi=g["d_candi"],
+                                padding_value=float(g["pad"])).clamp(max=0, min=-1000.)
+    assert np.array_equal(pred.cpu().numpy(), g["pred"])
+    with pytest.raises(Exception):
+        Hm.est_swp_volume_v4(_dev(g["feat_ref"])[None], _dev(g["feat_src"])[None], g["d_candi"], R, t, cam, 1.0, feat_dist="cosine")
