@@ -50,14 +50,14 @@ const char* nrgbd_strerror(int code);
  * nrgbd_pack_nhwc — feature packing for the sampling kernels.
  * Replaces: models/basic.py:254-263 (F.avg_pool2d of the RGB frames + torch.cat onto the
  * CNN features) and the implicit NCHW layout handed to homography.py:293.
- *   feat [N][Cf][h][w]            CNN features (NCHW)
+ *   feat [N][Cf][h][w]            CNN features (NCHW), or [N][h][w][Cf] when feat_channels_last != 0
  *   rgb  [N][3][h*pool][w*pool]   full-resolution frames, or NULL (then only a transpose)
  *   out  [N][h][w][Cp]            out[..,c] = feat[c] (c<Cf); mean of the pool x pool RGB
  *                                 window (c = Cf..Cf+2, rgb != NULL); 0 for padding
  * Requires Cp % 4 == 0 and Cp >= Cf (+3 if rgb).
  */
 int nrgbd_pack_nhwc(const float* feat, const float* rgb, float* out,
-                    int N, int Cf, int h, int w, int pool, int Cp, void* stream);
+                    int N, int Cf, int h, int w, int pool, int Cp, int feat_channels_last, void* stream);
 
 /*
  * nrgbd_costvol_fwd — fused homography warp + bilinear sample + cost accumulate
@@ -227,6 +227,41 @@ int nrgbd_bn2d_train_act(const float* x, const float* gamma, const float* beta, 
                          const float* residual, float* y, float* partial, float* mean_var,
                          int N, int C, long HW, void* stream);
 int nrgbd_avgpool8(const float* x, float* y, int NC, int H, int W, void* stream);
+
+/*
+ * Feature CNN (and R-Net form): 3x3 convolution, stride 1, padding = dilation, on the fp32 matrix cores with the
+ * BatchNorm2d / ReLU / residual work fused around it — the 2-D sibling of nrgbd_conv3d_3x3x3_f32.
+ * Replaces, per trunk layer of models/psm_submodule.py:90-167 (feature_extraction; convbn :10-16, BasicBlock :31-50):
+ * nn.Conv2d(bias=False) + nn.BatchNorm2d (batch statistics) + nn.ReLU + `out += x`; with (bias, out_lrelu) it is the
+ * conv2d_leakyRelu of models/m_submodule.py:18-27 used by the R-Net (Refine.py:36-71).
+ *
+ * Activations are channels-last [N][H][W][C].  A layer reads its input as
+ *       in = act(x * s + t)  [+ act(res * s' + t')]          (s,t per channel; act = ReLU or identity)
+ * `materialized` (optional) receives `in`.  y = conv(in) (+ bias, LeakyReLU 0.01 if out_lrelu) and
+ *   stats [nrgbd_conv2d_workgroups(N,H,W)][2*Cout] = per-workgroup sum of y, then sum of y^2, per channel.
+ *   w_packed: nrgbd_conv_pack_weights(w [Cout][Cin][3][3], taps = 9) -> [9*Cin*Cout] floats
+ *   Cin % 16 == 0; (Cout, dilation) in {(32,1), (64,1), (128,1), (128,2)}; N*H*W*Cin < 2^32.
+ * nrgbd_bn_finalize: partials [num_workgroups][2*C] -> scale_shift [C][2] = (gamma*invstd, beta - mean*gamma*invstd),
+ *   reduced in double; running_mean / running_var (both or neither) get the train-mode update.
+ * nrgbd_nhwc_stats: the same partials for a channels-last tensor produced elsewhere (the stride-2 / 1x1 layers that
+ *   stay on the vendor library): x [P][C], stats [nrgbd_nhwc_stats_workgroups(P)][2*C]; C in {32, 64, 128}.
+ * nrgbd_nhwc_act: y[p*ldy + c] = act(x*s+t) [+ act(res*s'+t')] — the loader's prologue as a stand-alone pass, for
+ *   consumers that are not the conv kernel (pooling, the SPP concat of psm_submodule.py:160-163, the 1x1 head).
+ */
+int nrgbd_conv2d_workgroups(int N, int H, int W);
+int nrgbd_conv_pack_weights(const float* w, float* w_packed, int Cin, int Cout, int taps, void* stream);
+int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_relu,
+                         const float* res, const float* res_ss, int res_relu,
+                         float* materialized, const float* w_packed, const float* bias, int out_lrelu,
+                         float* y, float* stats, int N, int H, int W, int Cin, int Cout, int dilation,
+                         void* stream);
+int nrgbd_bn_finalize(const float* stats, int num_workgroups, int C, long count,
+                      const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, float* scale_shift, void* stream);
+int nrgbd_nhwc_stats_workgroups(long P);
+int nrgbd_nhwc_stats(const float* x, long P, int C, float* stats, void* stream);
+int nrgbd_nhwc_act(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
+                   int res_relu, float* y, long P, int C, int ldy, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ _L = _c.c_long
 SIGNATURES = {
     "nrgbd_version": (_c.c_char_p, []),
     "nrgbd_strerror": (_c.c_char_p, [_I]),
-    "nrgbd_pack_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_pack_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_costvol_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P,
                                _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_costvol_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P, _P,
@@ -39,6 +39,13 @@ SIGNATURES = {
     "nrgbd_bn2d_partial_floats": (_I, [_I]),
     "nrgbd_bn2d_train_act": (_I, [_P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _L, _P]),
     "nrgbd_avgpool8": (_I, [_P, _P, _I, _I, _I, _P]),
+    "nrgbd_conv2d_workgroups": (_I, [_I, _I, _I]),
+    "nrgbd_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _P]),
+    "nrgbd_conv2d_3x3_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P]),
+    "nrgbd_nhwc_stats_workgroups": (_I, [_L]),
+    "nrgbd_nhwc_stats": (_I, [_P, _L, _I, _P, _P]),
+    "nrgbd_nhwc_act": (_I, [_P, _P, _I, _P, _P, _I, _P, _L, _I, _I, _P]),
 }
 
 _lib = None

@@ -1,4 +1,4 @@
-// pack.hip — NCHW features (+ pooled RGB) -> NHWC texels.  HBM-bound: every input element is
+// pack.hip — NCHW (or channels-last) features (+ pooled RGB) -> NHWC texels.  HBM-bound: every input element is
 // read once (coalesced along x) and every output texel written once as whole 16-B words.
 //
 // Replaces models/basic.py:254-263 (F.avg_pool2d + torch.cat) and produces the channel-last
@@ -14,7 +14,7 @@ constexpr int kPackTX = 64;  // pixels of one image row per workgroup
 __global__ __launch_bounds__(256) void pack_nhwc_kernel(const float* __restrict__ feat,
                                                         const float* __restrict__ rgb,
                                                         float* __restrict__ out, int Cf, int h,
-                                                        int w, int pool, int Cp) {
+                                                        int w, int pool, int Cp, int feat_nhwc) {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [Cp][kPackTX + 1]
     constexpr int LD = kPackTX + 1;
     const int x0 = blockIdx.x * kPackTX, y = blockIdx.y, n = blockIdx.z;
@@ -23,8 +23,16 @@ __global__ __launch_bounds__(256) void pack_nhwc_kernel(const float* __restrict_
     const size_t hw = (size_t)h * w;
 
     // 1. CNN channels: one wave per channel row, lanes along x (256-B coalesced reads)
-    const float* f = feat + ((size_t)n * Cf) * hw + (size_t)y * w + x0;
-    for (int c = wv; c < Cf; c += 4) tile[c * LD + lane] = (lane < npx) ? f[(size_t)c * hw + lane] : 0.f;
+    if (!feat_nhwc) {
+        const float* f = feat + ((size_t)n * Cf) * hw + (size_t)y * w + x0;
+        for (int c = wv; c < Cf; c += 4) tile[c * LD + lane] = (lane < npx) ? f[(size_t)c * hw + lane] : 0.f;
+    } else {  // features already channels-last (the matrix-core trunk): the row segment is one contiguous run
+        const float* f = feat + (((size_t)n * h + y) * w + x0) * Cf;
+        for (int t = tid; t < kPackTX * Cf; t += 256) {
+            const int px = t / Cf, c = t - px * Cf;
+            tile[c * LD + px] = (px < npx) ? f[t] : 0.f;
+        }
+    }
 
     // 2. pooled RGB channels Cf..Cf+2 (row-major window sum, then one division: avg_pool2d)
     const int n_rgb = rgb ? 3 : 0;
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(256) void pack_nhwc_kernel(const float* __restrict_
 }  // namespace nrgbd
 
 extern "C" int nrgbd_pack_nhwc(const float* feat, const float* rgb, float* out, int N, int Cf,
-                               int h, int w, int pool, int Cp, void* stream) {
+                               int h, int w, int pool, int Cp, int feat_channels_last, void* stream) {
     if (!feat || !out) return NRGBD_E_NULL;
     if (N <= 0 || Cf <= 0 || h <= 0 || w <= 0 || pool <= 0 || h > 65535 || N > 65535) return NRGBD_E_SHAPE;
     if ((Cp & 3) || Cp < Cf + (rgb ? 3 : 0)) return NRGBD_E_ALIGN;
@@ -69,7 +77,7 @@ extern "C" int nrgbd_pack_nhwc(const float* feat, const float* rgb, float* out, 
     if (lds > 160 * 1024) return NRGBD_E_SHAPE;
     dim3 grid(nrgbd::ceil_div(w, nrgbd::kPackTX), h, N);
     hipLaunchKernelGGL(nrgbd::pack_nhwc_kernel, grid, dim3(256), lds, (hipStream_t)stream, feat,
-                       rgb, out, Cf, h, w, pool, Cp);
+                       rgb, out, Cf, h, w, pool, Cp, feat_channels_last);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

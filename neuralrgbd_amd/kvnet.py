@@ -51,12 +51,21 @@ class DNet(nn.Module):
     def forward(self, ref_frame, src_frames, src_cam_poses, cam_intrinsics=None, BV_predict=None, debug_ipdb=False):
         assert src_frames.shape[0] == 1, 'dim0 of src_frames should be 0'
         frames = torch.cat((src_frames[0], ref_frame), dim=0)  # batch of V+1: BN statistics span the window
-        if self.output_features:
-            layer1, feats = self.feature_extraction(frames)
+        fe = self.feature_extraction
+        # inference: the CNN trunk on the matrix-core kernels, activations channels-last end to end
+        feats_cl = hasattr(fe, "forward_channels_last") and fe.fused_ok(frames)
+        if feats_cl:
+            out = fe.forward_channels_last(frames)
+            layer1, feats = out if self.output_features else (None, out)
+            V = src_frames.shape[1]
+            h, w, F_dim = feats.shape[1:]
         else:
-            layer1, feats = None, self.feature_extraction(frames)
-        V = src_frames.shape[1]
-        F_dim, h, w = feats.shape[1:]
+            if self.output_features:
+                layer1, feats = fe(frames)
+            else:
+                layer1, feats = None, fe(frames)
+            V = src_frames.shape[1]
+            F_dim, h, w = feats.shape[1:]
         C = F_dim + (3 if self.use_img_intensity else 0)
         # avg-pooled RGB appended as channels F..F+2 and the whole window transposed to 16-B texels
         cam = self.cam_intrinsics if cam_intrinsics is None else cam_intrinsics
@@ -75,7 +84,7 @@ class DNet(nn.Module):
             self.texels = texels.detach()
             BV = (torch.log_softmax(-cost, dim=0) if self.BV_log else torch.softmax(-cost, dim=0)).unsqueeze(0)
         else:
-            texels = ops.pack_nhwc(feats, rgb)
+            texels = ops.pack_nhwc(feats, rgb, channels_last=feats_cl)
             self.texels = texels
             cost, logp = ops.costvol(texels[V], texels[:V], KR, Kt, rays, d_dev, cx, cy, self.sigma_soft_max, C,
                                      dist=self.feat_dist, align_corners=self.align_corners,
@@ -92,6 +101,8 @@ class DNet(nn.Module):
                     BV = ops.logsoftmax_d(BV[0]).unsqueeze(0)
 
         if self.output_features:
+            if feats_cl:   # NCHW-shaped views of the channels-last tensors (the R-Net's convs take either layout)
+                return BV, [feats[V:V + 1].permute(0, 3, 1, 2), layer1[V:V + 1].permute(0, 3, 1, 2)]
             return BV, [feats[V:V + 1], layer1[V:V + 1]]
         return BV
 

@@ -59,6 +59,48 @@ def _he_init(module):
             m.bias.data.zero_()
 
 
+
+# --------------------------------------------------------------------------- channels-last matrix-core path (shared)
+class _Act(object):
+    """A channels-last activation that is still owed its normalisation: value = act(z*s+t) (+ act(r*s'+t')).
+    The next matrix-core conv applies it while loading its input tile (csrc/conv2d.hip, conv3d.hip)."""
+    __slots__ = ("z", "ss", "relu", "r", "r_ss", "r_relu")
+
+    def __init__(self, z, ss=None, relu=False, r=None, r_ss=None, r_relu=False):
+        self.z, self.ss, self.relu, self.r, self.r_ss, self.r_relu = z, ss, relu, r, r_ss, r_relu
+
+
+def _packed_weights(owner, conv):
+    """B-operand stream of a conv for the matrix-core kernels, re-packed only when its weight changes."""
+    from . import ops
+    cache = owner.__dict__.setdefault("_wp_cache", {})
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        hit = (key, ops.conv_pack_weights(w.detach().contiguous()))
+        cache[id(conv)] = hit
+    return hit[1]
+
+
+def _bn_scale_shift(bn, stats, count):
+    """(scale, shift) [C,2] of a BatchNorm: batch statistics from the conv epilogue's partials in train mode (the
+    reference never leaves it) incl. the running-statistics side effect; running statistics in eval mode."""
+    from . import ops
+    if bn.training or not bn.track_running_stats:
+        upd = bn.training and bn.track_running_stats
+        if upd:
+            bn.num_batches_tracked += 1
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        return ops.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, momentum,
+                               bn.running_mean if upd else None, bn.running_var if upd else None)
+    sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+    return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
+
+
+def _needs_stats(bn):
+    return bn.training or not bn.track_running_stats
+
 # --------------------------------------------------------------------------- 2-D feature CNN
 def _fused_ok(x):
     """The hand-written BatchNorm path: inference on the GPU (autograd needs the torch modules)."""
@@ -160,6 +202,108 @@ class PSMFeatures(nn.Module):
             return {8: p8, 16: F.avg_pool2d(p8, 2), 32: F.avg_pool2d(p8, 4), 64: F.avg_pool2d(p8, 8)}
         return {w: F.avg_pool2d(deep, (w, w), stride=(w, w)) for w in self.SPP_WINDOWS}
 
+    # ------------------------------------------------------------------ matrix-core inference path
+    _MFMA_SHAPES = {(32, 1), (64, 1), (128, 1), (128, 2)}   # (Cout, dilation) instantiated in csrc/conv2d.hip
+
+    def _conv_bn_cl(self, seq, a, relu, materialize=False):
+        """Sequential(conv, bn) on a pending channels-last activation -> (pending output, materialised input | None).
+        3x3 / stride-1 layers run on csrc/conv2d.hip; the stride-2 3x3 layers stay on the vendor library."""
+        from . import ops
+        conv, bn = seq[0], seq[1]
+        d = conv.dilation[0]
+        mfma = (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (d, d)
+                and conv.in_channels % 16 == 0 and (conv.out_channels, d) in self._MFMA_SHAPES)
+        if mfma:
+            z, st, mat = ops.conv2d(a.z, _packed_weights(self, conv), conv.out_channels, d, x_ss=a.ss, x_relu=a.relu,
+                                    res=a.r, res_ss=a.r_ss, res_relu=a.r_relu, materialize=materialize,
+                                    want_stats=_needs_stats(bn))
+        else:
+            mat = a.z if (a.ss is None and a.r is None and not a.relu) else \
+                ops.nhwc_act(a.z, a.ss, a.relu, a.r, a.r_ss, a.r_relu)
+            z = F.conv2d(mat.permute(0, 3, 1, 2), conv.weight, None, conv.stride, conv.padding, conv.dilation)
+            z = z.permute(0, 2, 3, 1).contiguous()
+            st = ops.nhwc_stats(z) if _needs_stats(bn) else None
+        count = z.shape[0] * z.shape[1] * z.shape[2]
+        return _Act(z, _bn_scale_shift(bn, st, count), relu), mat
+
+    def _pointwise_bn_cl(self, seq, m, stride=1):
+        """1x1 Sequential(conv, bn) on a materialised channels-last tensor: a plain GEMM (vendor BLAS) + statistics."""
+        from . import ops
+        conv, bn = seq[0], seq[1]
+        if stride != 1:
+            m = m[:, ::stride, ::stride, :]
+        N, H, W, C = m.shape
+        z = torch.mm(m.reshape(-1, C), conv.weight.view(conv.out_channels, C).t()).view(N, H, W, conv.out_channels)
+        st = ops.nhwc_stats(z) if _needs_stats(bn) else None
+        return _Act(z, _bn_scale_shift(bn, st, N * H * W), False)
+
+    def _block_cl(self, blk, a):
+        """BasicBlock (psm_submodule.py:31-50): out = bn(conv2(relu(bn(conv1(x))))) + shortcut(x), no ReLU after the add."""
+        y1, m = self._conv_bn_cl(blk.conv1[0], a, relu=True, materialize=True)   # m = the block's input, materialised
+        y2, _ = self._conv_bn_cl(blk.conv2, y1, relu=False)
+        if blk.downsample is None:
+            return _Act(y2.z, y2.ss, False, r=m)
+        sk = self._pointwise_bn_cl(blk.downsample, m, blk.downsample[0].stride[0])
+        return _Act(y2.z, y2.ss, False, r=sk.z, r_ss=sk.ss)
+
+    def fused_ok(self, x):
+        """Inference on the GPU; NRGBD_CNN=vendor keeps the 3x3 convolutions on the vendor library (A/B switch)."""
+        import os
+        return x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32 \
+            and os.environ.get("NRGBD_CNN", "mfma") != "vendor"
+
+    def forward_channels_last(self, x):
+        """Inference on the hand-written kernels: x [N,3,H,W] -> (layer1 [N,H/2,W/2,32], feat [N,H/4,W/4,F]), both
+        channels-last.  Same graph as forward() (psm_submodule.py:136-167); every 3x3 stride-1 conv is one fused pass
+        (conv on the fp32 matrix cores, BatchNorm statistics in its epilogue, normalise + ReLU + residual in the next
+        layer's loader).  The three stride-2 / 3-channel convs and the 1x1 convs (GEMMs) use the vendor libraries."""
+        from . import ops
+        conv, bn = self.firstconv[0]
+        z = F.conv2d(x, conv.weight, None, conv.stride, conv.padding).permute(0, 2, 3, 1).contiguous()
+        a = _Act(z, _bn_scale_shift(bn, ops.nhwc_stats(z) if _needs_stats(bn) else None, z.numel() // z.shape[-1]), True)
+        for i in (2, 4):
+            a, _ = self._conv_bn_cl(self.firstconv[i], a, relu=True)
+        for blk in self.layer1:
+            a = self._block_cl(blk, a)
+        half = ops.nhwc_act(a.z, a.ss, a.relu, a.r, a.r_ss, a.r_relu)      # returned to the R-Net and read by layer2
+        a = _Act(half)
+        for blk in self.layer2:
+            a = self._block_cl(blk, a)
+        quarter = None
+        for k, blk in enumerate(self.layer3):
+            y1, m = self._conv_bn_cl(blk.conv1[0], a, relu=True, materialize=True)
+            if k == 0:
+                quarter = m                                                # layer2's output, needed by the SPP concat
+            y2, _ = self._conv_bn_cl(blk.conv2, y1, relu=False)
+            if blk.downsample is None:
+                a = _Act(y2.z, y2.ss, False, r=m)
+            else:
+                sk = self._pointwise_bn_cl(blk.downsample, m, blk.downsample[0].stride[0])
+                a = _Act(y2.z, y2.ss, False, r=sk.z, r_ss=sk.ss)
+        for blk in self.layer4:
+            a = self._block_cl(blk, a)
+        deep = ops.nhwc_act(a.z, a.ss, a.relu, a.r, a.r_ss, a.r_relu)
+        N, h, w, _ = deep.shape
+        deep_nchw = deep.permute(0, 3, 1, 2)                               # channels-last view for the torch pooling ops
+        if h % 64 == 0 and w % 64 == 0:
+            p8 = F.avg_pool2d(deep_nchw, 8)
+            pools = {8: p8, 16: F.avg_pool2d(p8, 2), 32: F.avg_pool2d(p8, 4), 64: F.avg_pool2d(p8, 8)}
+        else:
+            pools = {k: F.avg_pool2d(deep_nchw, (k, k), stride=(k, k)) for k in self.SPP_WINDOWS}
+        pyramid = []
+        for i in (4, 3, 2, 1):
+            branch = getattr(self, "branch%d" % i)
+            y = _conv_bn_act(pools[self.SPP_WINDOWS[i - 1]].contiguous(), branch[1], relu=True)   # tiny maps
+            y = F.interpolate(y.contiguous(memory_format=torch.channels_last), size=(h, w), mode="bilinear",
+                              align_corners=True)
+            pyramid.append(y.permute(0, 2, 3, 1))                          # channels-last in memory already
+        cat = torch.cat([quarter, deep] + pyramid, dim=3)                  # [N,h,w,320]
+        y, _ = self._conv_bn_cl(self.lastconv[0], _Act(cat), relu=True)
+        y = ops.nhwc_act(y.z, y.ss, True)
+        head = self.lastconv[2]
+        feat = torch.mm(y.view(-1, y.shape[-1]), head.weight.view(head.out_channels, -1).t()).view(N, h, w, head.out_channels)
+        return half, feat
+
     def forward(self, x):
         stem = x
         for i in (0, 2, 4):
@@ -191,6 +335,13 @@ class FeatureExtractor(nn.Module):
 
     def forward(self, img):
         return self.feature_extraction(img)
+
+    def fused_ok(self, img):
+        return self.feature_extraction.fused_ok(img)
+
+    def forward_channels_last(self, img):
+        half, feat = self.feature_extraction.forward_channels_last(img)
+        return (half, feat) if self.multi_scale else feat
 
 
 # --------------------------------------------------------------------------- K-Net (3-D)

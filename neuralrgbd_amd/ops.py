@@ -42,10 +42,13 @@ def padded_channels(C):
     return (C + 3) // 4 * 4
 
 
-def pack_nhwc(feat, rgb=None, Cp=None):
-    """feat [N,Cf,h,w] (+ rgb [N,3,h*pool,w*pool]) -> texels [N,h,w,Cp] (nrgbd_pack_nhwc)."""
+def pack_nhwc(feat, rgb=None, Cp=None, channels_last=False):
+    """feat [N,Cf,h,w] (or [N,h,w,Cf] if channels_last) (+ rgb [N,3,h*pool,w*pool]) -> texels [N,h,w,Cp] (nrgbd_pack_nhwc)."""
     feat = _need(feat, "feat")
-    N, Cf, h, w = feat.shape
+    if channels_last:
+        N, h, w, Cf = feat.shape
+    else:
+        N, Cf, h, w = feat.shape
     pool = 1
     if rgb is not None:
         rgb = _need(rgb, "rgb")
@@ -58,7 +61,8 @@ def pack_nhwc(feat, rgb=None, Cp=None):
         Cp = padded_channels(Cf + (3 if rgb is not None else 0))
     out = torch.empty((N, h, w, Cp), dtype=torch.float32, device=feat.device)
     with torch.cuda.device(feat.device):
-        rc = _lib.load().nrgbd_pack_nhwc(_p(feat), _p(rgb), _p(out), N, Cf, h, w, pool, Cp, _stream(feat))
+        rc = _lib.load().nrgbd_pack_nhwc(_p(feat), _p(rgb), _p(out), N, Cf, h, w, pool, Cp, int(bool(channels_last)),
+                                          _stream(feat))
     _lib.check(rc, "nrgbd_pack_nhwc")
     return out
 
@@ -266,6 +270,88 @@ def bn3d_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, r
 
 
 # ----------------------------------------------------------------------------- 2-D feature CNN helpers
+def conv2d_workgroups(N, H, W):
+    return int(_lib.load().nrgbd_conv2d_workgroups(N, H, W))
+
+
+def conv_pack_weights(w):
+    """w [Cout, Cin, 3, 3] (or [Cout, Cin, 3, 3, 3]) -> packed B-operand stream of the matrix-core conv kernels."""
+    w = _need(w, "w")
+    cout, cin = w.shape[:2]
+    taps = 1
+    for k in w.shape[2:]:
+        taps *= int(k)
+    wp = torch.empty(taps * cin * cout, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().nrgbd_conv_pack_weights(_p(w), _p(wp), cin, cout, taps, _stream(w))
+    _lib.check(rc, "nrgbd_conv_pack_weights")
+    return wp
+
+
+def conv2d(x, w_packed, cout, dilation=1, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False,
+           materialize=False, bias=None, out_lrelu=False, want_stats=True):
+    """Channels-last 3x3 convolution (stride 1, pad = dilation) on the fp32 matrix cores.
+
+    x [N,H,W,Cin]; input = act(x*s+t) (+ act(res*s'+t')).  Returns (y [N,H,W,cout], stats | None, materialized | None).
+    """
+    x = _need(x, "x")
+    N, H, W, Cin = x.shape
+    y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
+    stats = torch.empty((conv2d_workgroups(N, H, W), 2 * cout), dtype=torch.float32, device=x.device) if want_stats else None
+    mat = torch.empty_like(x) if materialize else None
+    if res is not None:
+        res = _need(res, "res", x.shape)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv2d_3x3_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(mat),
+                                               _p(w_packed), _p(bias), int(out_lrelu), _p(y), _p(stats), N, H, W, Cin,
+                                               int(cout), int(dilation), _stream(x))
+    _lib.check(rc, "nrgbd_conv2d_3x3_f32")
+    return y, stats, mat
+
+
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    """Per-workgroup partials [nwg, 2C] -> scale_shift [C,2]; updates the running statistics in place (train mode)."""
+    stats = _need(stats, "stats")
+    C = stats.shape[1] // 2
+    ss = torch.empty((C, 2), dtype=torch.float32, device=stats.device)
+    with torch.cuda.device(stats.device):
+        rc = _lib.load().nrgbd_bn_finalize(_p(stats), stats.shape[0], C, int(count), _p(gamma), _p(beta), float(eps),
+                                           float(momentum), _p(running_mean), _p(running_var), _p(ss), _stream(stats))
+    _lib.check(rc, "nrgbd_bn_finalize")
+    return ss
+
+
+def nhwc_stats(x):
+    """Per-workgroup (sum, sum of squares) partials of a channels-last tensor [..., C] -> [nwg, 2C]."""
+    x = _need(x, "x")
+    C = x.shape[-1]
+    P = x.numel() // C
+    nwg = int(_lib.load().nrgbd_nhwc_stats_workgroups(P))
+    stats = torch.empty((nwg, 2 * C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_nhwc_stats(_p(x), P, C, _p(stats), _stream(x))
+    _lib.check(rc, "nrgbd_nhwc_stats")
+    return stats
+
+
+def nhwc_act(x, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False, out=None, ldy=None):
+    """y = act(x*s+t) (+ act(res*s'+t')) on channels-last [..., C]; `out` may be a wider buffer (pixel stride ldy)."""
+    x = _need(x, "x")
+    C = x.shape[-1]
+    P = x.numel() // C
+    if res is not None:
+        res = _need(res, "res", x.shape)
+    if out is None:
+        out, ldy = torch.empty_like(x), C
+    elif ldy is None:
+        raise ValueError("nhwc_act: out needs its pixel stride ldy")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_nhwc_act(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(out), P, C,
+                                         int(ldy), _stream(x))
+    _lib.check(rc, "nrgbd_nhwc_act")
+    return out
+
+
 def bn2d_train_act(x, gamma, beta, eps, relu=False, residual=None, inplace=True, want_mean_var=False):
     """Train-mode BatchNorm2d + activation (+ residual) in two HBM passes.  x [N,C,H,W] -> (y, mean_var | None)."""
     x = _need(x, "x")

