@@ -17,6 +17,8 @@
 // then 9 taps x 2 k-groups, each = 2 A reads (LDS, b128) + COUT/32 B loads (L2, one 1 KB line per wave) +
 // 8 * COUT/32 MFMAs.  The raw words of block c+1 (input and residual operand) are fetched into registers
 // while the MFMAs of block c run, one 16-B load per step, and normalised / published to LDS after the loop.
+#include <cstdlib>
+
 #include "conv_tile.hpp"
 
 namespace nrgbd {
@@ -35,6 +37,7 @@ struct Conv2dArgs {
     float* stats;         // [num_workgroups][2*Cout]: per-channel sum and sum of squares of y, or null
     int x_relu, res_relu, out_lrelu;
     int N, H, W, Cin;
+    int xcd;              // re-map workgroups so each XCD owns a contiguous run of tiles (conv_tile.hpp)
 };
 
 template <int COUT, int DIL, bool RES>
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tiles_x = (a.W + kT2 - 1) / kT2, tiles_y = (a.H + kT2 - 1) / kT2;
-    int t = blockIdx.x;
+    int t = xcd_tile(blockIdx.x, gridDim.x, a.xcd);
+    const int tile_id = t;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y; const int n = t / tiles_y;
     const int x0 = tx * kT2, y0 = ty * kT2;
@@ -143,7 +147,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
         for (int f = 0; f < NF; ++f) Bn[0][f] = wb[f * 64];
         An[0][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv0, khalf * 2));
         An[0][1] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv0 + 2 * HS, khalf * 2));
-        const int nb = (cblk + 1 < ncblk ? cblk + 1 : cblk) * kCB;  // last block: a redundant re-read instead of a branch
+        // next block's words; in the last block every lane re-reads element 0 instead (one cached line, no branch)
+        const unsigned nb = (cblk + 1) * kCB, live = cblk + 1 < ncblk ? ~0u : 0u;
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
@@ -159,10 +164,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
                 for (int f = 0; f < NF; ++f) Bn[nxt][f] = wn[f * 64];
             }
             // one word of the NEXT channel block per step: x in steps 2 .. 2+NPF-1, the residual operand after it
-            if (s >= 2 && s < 2 + NPF) pre[s - 2] = *reinterpret_cast<const f32x4*>(a.x + pf_off[s - 2] + nb);
+            if (s >= 2 && s < 2 + NPF) pre[s - 2] = *reinterpret_cast<const f32x4*>(a.x + ((pf_off[s - 2] + nb) & live));
             if constexpr (RES) {
                 if (s >= 2 + NPF && s < 2 + 2 * NPF)
-                    prer[s - 2 - NPF] = *reinterpret_cast<const f32x4*>(a.res + pf_off[s - 2 - NPF] + nb);
+                    prer[s - 2 - NPF] = *reinterpret_cast<const f32x4*>(a.res + ((pf_off[s - 2 - NPF] + nb) & live));
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a)
         }
         __syncthreads();
         if (tid < 2 * COUT)
-            a.stats[(size_t)blockIdx.x * (2 * COUT) + tid] =
+            a.stats[(size_t)tile_id * (2 * COUT) + tid] =
                 (red[tid] + red[2 * COUT + tid]) + (red[4 * COUT + tid] + red[6 * COUT + tid]);
     }
 }
@@ -368,7 +373,8 @@ extern "C" int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_rel
     if (!x || !w_packed || !y) return NRGBD_E_NULL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB) return NRGBD_E_SHAPE;
     if ((long)N * H * W * Cin >= (1L << 32)) return NRGBD_E_SHAPE;  // 32-bit element offsets in the loader
-    Conv2dArgs a{x, x_ss, res, res_ss, materialized, w_packed, bias, y, stats, x_relu, res_relu, out_lrelu, N, H, W, Cin};
+    Conv2dArgs a{x, x_ss, res, res_ss, materialized, w_packed, bias, y, stats, x_relu, res_relu, out_lrelu, N, H, W, Cin,
+                 getenv("NRGBD_XCD") ? atoi(getenv("NRGBD_XCD")) : 0};
     const int nwg = ceil_div(W, kT2) * ceil_div(H, kT2) * N;
     hipStream_t st = (hipStream_t)stream;
     if (dilation == 1 && Cout == 32) launch_conv2d<32, 1>(a, nwg, st);

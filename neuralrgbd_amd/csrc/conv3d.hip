@@ -47,6 +47,7 @@ struct Conv3dArgs {
     float* stats;         // [num_workgroups][128]: per-channel sum (0..63) and sum of squares (64..127), or null
     int x_relu, res_relu;
     int D, H, W;
+    int xcd;              // re-map workgroups so each XCD owns a contiguous run of tiles (conv_tile.hpp)
 };
 
 // Stage the (4 x 10 x 18)-voxel halo tile of channel block `cblk` into LDS as [voxel][kSV]:
@@ -92,7 +93,7 @@ __device__ __forceinline__ void stage_halo(const Conv3dArgs& a, int cblk, float*
 // fetched into registers WHILE the 864 MFMAs of block c run (one 16-B load per step, so each load's latency
 // hides inside the one-step-ahead operand pipeline), and are normalised / activated / written to LDS after
 // the loop — the matrix pipe no longer idles during staging (78.9 % busy without it, rocprofv3 PMC).
-template <int CIN, bool PF>
+template <int CIN, bool PF, bool RES = false>
 __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv3dArgs a) {
     constexpr int NCBLK = CIN / kCB;
     constexpr int NPF = (kHaloVox * (kCB / 4) + 255) / 256;  // 16-B words per thread per block (12)
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tiles_x = (a.W + kTW - 1) / kTW, tiles_y = (a.H + kTH - 1) / kTH;
-    int t = blockIdx.x;
+    int t = xcd_tile(blockIdx.x, gridDim.x, a.xcd);
+    const int tile_id = t;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y; const int tz = t / tiles_y;
     const int x0 = tx * kTW, y0 = ty * kTH, z0 = tz * kTD;
@@ -125,9 +127,10 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
 
     // prefetch bookkeeping: word u of this thread = halo voxel (tid>>2) + 64u, 16-B word tid&3 of the block
     const int c4 = tid & 3;
-    unsigned pf_off[PF ? NPF : 1];   // element offset of the voxel's channel 0 (+ c4*4), ~0u outside the volume
+    unsigned pf_off[PF ? NPF : 1];   // element offset of the voxel's channel c4*4 (a harmless in-tensor offset when outside)
+    unsigned pf_ok = 0;              // bit u: the voxel is inside the volume (outside = zero padding)
     unsigned pf_own = 0;             // bit u: the voxel belongs to this tile's interior (materialise target)
-    f32x4 pre[PF ? NPF : 1];
+    f32x4 pre[PF ? NPF : 1], prer[(PF && RES) ? NPF : 1];
     if constexpr (PF) {
 #pragma unroll
         for (int u = 0; u < NPF; ++u) {
@@ -136,32 +139,50 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
             const int hy = rem / kHW, hx = rem - hy * kHW;
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
             const bool ok = hv < kHaloVox && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            pf_off[u] = ok ? (unsigned)((((size_t)gz * a.H + gy) * a.W + gx) * CIN + c4 * 4) : ~0u;
+            pf_off[u] = ok ? (unsigned)((((size_t)gz * a.H + gy) * a.W + gx) * CIN + c4 * 4) : (unsigned)(c4 * 4);
+            if (ok) pf_ok |= 1u << u;
             if (ok && hz >= 1 && hz <= kTD && hy >= 1 && hy <= kTH && hx >= 1 && hx <= kTW) pf_own |= 1u << u;
         }
+        // unconditional loads: lanes outside the volume read a valid dummy word that is zeroed when published
 #pragma unroll
-        for (int u = 0; u < NPF; ++u)
-            pre[u] = (pf_off[u] != ~0u) ? *reinterpret_cast<const f32x4*>(a.x + pf_off[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NPF; ++u) {
+            pre[u] = *reinterpret_cast<const f32x4*>(a.x + pf_off[u]);
+            if constexpr (RES) prer[u] = *reinterpret_cast<const f32x4*>(a.res + pf_off[u]);
+        }
     }
 
     for (int cblk = 0; cblk < NCBLK; ++cblk) {
         if constexpr (PF) {
             // normalise / activate the prefetched words of this block and publish them to LDS
             const int c = cblk * kCB + c4 * 4;
-            float ss[8] = {1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f};
+            float ss[8] = {1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f}, rs[8] = {1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f};
             if (a.x_ss) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ss[e] = a.x_ss[2 * c + e];
+            }
+            if (RES && a.res_ss) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rs[e] = a.res_ss[2 * c + e];
             }
 #pragma unroll
             for (int u = 0; u < NPF; ++u) {
                 const int hv = (tid >> 2) + 64 * u;
                 if (hv >= kHaloVox) continue;
-                f32x4 v = pre[u];
-                if (pf_off[u] != ~0u) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((pf_ok >> u) & 1u) {
+                    v = pre[u];
                     v.x = __builtin_fmaf(v.x, ss[0], ss[1]); v.y = __builtin_fmaf(v.y, ss[2], ss[3]);
                     v.z = __builtin_fmaf(v.z, ss[4], ss[5]); v.w = __builtin_fmaf(v.w, ss[6], ss[7]);
                     if (a.x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if constexpr (RES) {
+                        f32x4 r = prer[u];
+                        if (a.res_ss) {
+                            r.x = __builtin_fmaf(r.x, rs[0], rs[1]); r.y = __builtin_fmaf(r.y, rs[2], rs[3]);
+                            r.z = __builtin_fmaf(r.z, rs[4], rs[5]); r.w = __builtin_fmaf(r.w, rs[6], rs[7]);
+                        }
+                        if (a.res_relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+                        v = v + r;
+                    }
                     if (a.mat && ((pf_own >> u) & 1u))
                         *reinterpret_cast<f32x4*>(a.mat + pf_off[u] + cblk * kCB) = v;
                 }
@@ -176,6 +197,8 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
         const f32x4* wb = reinterpret_cast<const f32x4*>(a.wp) + (size_t)cblk * (G4 * 2 * 64) + lane;
         constexpr int WSTEP = NCBLK * G4 * 2 * 64;  // f32x4 per tap
         f32x4 Bn[2][2], An[2][2];
+        // next block's words; in the last block every lane re-reads element 0 instead (one cached line, no branch)
+        const unsigned nb = (cblk + 1) * kCB, live = cblk + 1 < NCBLK ? ~0u : 0u;
         Bn[0][0] = wb[0]; Bn[0][1] = wb[64];
         An[0][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv0, khalf * 2));
         An[0][1] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv1, khalf * 2));
@@ -195,12 +218,12 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
                 const f32x4* wn = wb + (size_t)tap * WSTEP + g * (2 * 64);
                 Bn[nxt][0] = wn[0]; Bn[nxt][1] = wn[64];
             }
-            if constexpr (PF) {  // one word of the NEXT channel block per step, steps 2 .. 2+NPF-1
+            if constexpr (PF) {  // one word of the NEXT channel block per step: x in steps 2 .. 2+NPF-1, then the residual
                 constexpr int PF0 = 2;
-                if (s >= PF0 && s < PF0 + NPF && cblk + 1 < NCBLK) {
-                    const int u = s - PF0;
-                    pre[u] = (pf_off[u] != ~0u) ? *reinterpret_cast<const f32x4*>(a.x + pf_off[u] + (cblk + 1) * kCB)
-                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (s >= PF0 && s < PF0 + NPF) pre[s - PF0] = *reinterpret_cast<const f32x4*>(a.x + ((pf_off[s - PF0] + nb) & live));
+                if constexpr (RES) {
+                    if (s >= PF0 + NPF && s < PF0 + 2 * NPF)
+                        prer[s - PF0 - NPF] = *reinterpret_cast<const f32x4*>(a.res + ((pf_off[s - PF0 - NPF] + nb) & live));
                 }
             }
 #pragma unroll
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
         }
         __syncthreads();
         if (tid < 128)
-            a.stats[(size_t)blockIdx.x * 128 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            a.stats[(size_t)tile_id * 128 + tid] = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
     }
 }
 
@@ -377,13 +400,15 @@ extern "C" int nrgbd_conv3d_3x3x3_f32(const float* x, const float* x_ss, int x_r
     if (!x || !w_packed || !y) return NRGBD_E_NULL;
     if (D <= 0 || H <= 0 || W <= 0) return NRGBD_E_SHAPE;
     if (Cout != kCout || (Cin != 16 && Cin != 64)) return NRGBD_E_SHAPE;
-    Conv3dArgs a{x, x_ss, res, res_ss, materialized, w_packed, y, stats, x_relu, res_relu, D, H, W};
+    Conv3dArgs a{x, x_ss, res, res_ss, materialized, w_packed, y, stats, x_relu, res_relu, D, H, W, getenv("NRGBD_XCD") ? atoi(getenv("NRGBD_XCD")) : 0};
     const int nwg = ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
     const size_t lds = (size_t)kHaloVox * kSV * sizeof(float);  // 46,080 B (>= the 2 KB the statistics reuse)
-    const bool prefetch = (Cin == 64) && !res && ((long)D * H * W * Cin < (1L << 32)) && !getenv("NRGBD_CONV3D_NOPF");
+    const bool prefetch = (Cin == 64) && ((long)D * H * W * Cin < (1L << 32)) && !getenv("NRGBD_CONV3D_NOPF");
     if (Cin == 16)
         hipLaunchKernelGGL((conv3d_mfma_kernel<16, false>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
-    else if (prefetch)
+    else if (prefetch && res && !getenv("NRGBD_CONV3D_NOPFRES"))
+        hipLaunchKernelGGL((conv3d_mfma_kernel<64, true, true>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    else if (prefetch && !res)
         hipLaunchKernelGGL((conv3d_mfma_kernel<64, true>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((conv3d_mfma_kernel<64, false>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
@@ -397,7 +422,7 @@ extern "C" int nrgbd_conv3d_3x3x3_cout1_f32(const float* x, const float* x_ss, i
     using namespace nrgbd;
     if (!x || !w_tap_major || !y) return NRGBD_E_NULL;
     if (D <= 0 || H <= 0 || W <= 0 || Cin != 64) return NRGBD_E_SHAPE;
-    Conv3dArgs a{x, x_ss, res, res_ss, nullptr, nullptr, y, nullptr, x_relu, res_relu, D, H, W};
+    Conv3dArgs a{x, x_ss, res, res_ss, nullptr, nullptr, y, nullptr, x_relu, res_relu, D, H, W, 0};
     const int nwg = ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
     const size_t lds = (size_t)kHaloVox * kSV * sizeof(float);
     hipLaunchKernelGGL(conv3d_cout1_kernel, dim3(nwg), dim3(256), lds, (hipStream_t)stream, a, w_tap_major);

@@ -23,4 +23,13 @@ __device__ __forceinline__ void row_to_yx(int i, int& dy, int& x) {
     x = (i < 4) ? i : (i < 12) ? i - 4 : (i < 16) ? i - 8 : (i < 20) ? i - 8 : (i < 28) ? i - 12 : i - 16;
 }
 
+// Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  With xcd != 0 the launch order is
+// re-mapped so that XCD k works on the k-th contiguous eighth of the tile list: neighbouring tiles (which share
+// their halo voxels) then hit the same L2 instead of each XCD fetching the halo from HBM again.
+__device__ __forceinline__ int xcd_tile(int bid, int nwg, int xcd) {
+    if (!xcd) return bid;
+    const int x = bid & 7, chunk = nwg >> 3, rem = nwg & 7;
+    return x * chunk + (x < rem ? x : rem) + (bid >> 3);
+}
+
 }  // namespace nrgbd
