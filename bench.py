@@ -41,6 +41,7 @@ CONFIGS = {
     "H": dict(H=480, W=640, D=128, d_min=0.1, d_max=5.0, name="480x640 image, grid 160x120x128"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (256 CUs x 256 FLOP/clk x 2.4 GHz)
 # HBM bytes per launch of the fused warp + cost-volume kernel at config B from the L2's fabric-side counters
 # (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes: tools/pmc_costvol.sh, summary in
 # profiles/r1_pmc_summary.txt): FETCH_SIZE 561,502 KB, doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950
@@ -55,20 +56,23 @@ def costvol_bytes(V, C, D, h, w):
 
 
 class KernelTimer:
-    """Duration of the dominant sampling kernel (ops.costvol) from HIP events on torch's current stream (= the
+    """Duration of one kernel of the frame (ops.costvol: the sampling kernel the metric names; ops.conv3d: the K-Net
+    layer that dominates the frame time) from HIP events on torch's current stream (= the
     stream the kernel is launched on).  Frames are replayed as one hipGraph, inside which single kernels cannot be
     bracketed, so the wrapper remembers the arguments of the last in-model launch (same tensors, same shapes) and
     `measure()` re-launches exactly that K times back to back between two events right after the timed region."""
 
-    def __init__(self):
+    def __init__(self, keep=lambda a, k: True):
         self.last = None
         self.fn = None
+        self.keep = keep
 
     def wrap(self, fn):
         self.fn = fn
 
         def remembering(*a, **k):
-            self.last = (a, k)
+            if self.keep(a, k):
+                self.last = (a, k)
             return fn(*a, **k)
         return remembering
 
@@ -145,6 +149,9 @@ def main():
 
     timer = KernelTimer()
     ops.costvol = timer.wrap(ops.costvol)
+    # the K-Net's plain 64->64 layer (BatchNorm+ReLU prologue, no residual operand): 6 of its 12 layers
+    knet_timer = KernelTimer(keep=lambda a, k: a[0].shape[-1] == 64 and k.get("res") is None and k.get("x_ss") is not None)
+    ops.conv3d = knet_timer.wrap(ops.conv3d)
 
     # the streaming driver: same per-frame work as test_utils/test_KVNet.py::test (R_net=True), state resident,
     # the update-branch frame captured into one hipGraph after an eager warm-up frame
@@ -197,6 +204,14 @@ def main():
                          "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r1_pmc_summary.txt"
                          if args.config in PMC_TRAFFIC_BYTES else None},
         }
+        if knet_timer.last is not None:   # secondary roofline: the matrix-core kernel that takes most of the frame
+            c_ms = knet_timer.measure(5)
+            flops = 2.0 * D * h * w * 64 * 64 * 27
+            tf = flops / (c_ms * 1e-3) / 1e12
+            line["roofline_mfma"] = {"bound": "mfma", "kernel": "conv3d_mfma_kernel<64> (one K-Net 3x3x3 64->64 layer; the 10 such "
+                                     "layers are ~2/3 of the frame)", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "flops": flops, "kernel_ms": c_ms,
+                                     "launches_timed": 5, "timing": "HIP events around back-to-back re-launches of the frame's own layer call"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, cam, d_candi, sd, ring[0], pred, sigma)
         print(json.dumps(line))

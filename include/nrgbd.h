@@ -240,7 +240,7 @@ int nrgbd_avgpool8(const float* x, float* y, int NC, int H, int W, void* stream)
  * `materialized` (optional) receives `in`.  y = conv(in) (+ bias, LeakyReLU 0.01 if out_lrelu) and
  *   stats [nrgbd_conv2d_workgroups(N,H,W)][2*Cout] = per-workgroup sum of y, then sum of y^2, per channel.
  *   w_packed: nrgbd_conv_pack_weights(w [Cout][Cin][3][3], taps = 9) -> [9*Cin*Cout] floats
- *   Cin % 16 == 0; (Cout, dilation) in {(32,1), (64,1), (128,1), (128,2)}; N*H*W*Cin < 2^32.
+ *   Cin % 16 == 0; (Cout, dilation) in {(32,1), (64,1), (96,1), (128,1), (128,2)}; N*H*W*Cin < 2^32.
  * nrgbd_bn_finalize: partials [num_workgroups][2*C] -> scale_shift [C][2] = (gamma*invstd, beta - mean*gamma*invstd),
  *   reduced in double; running_mean / running_var (both or neither) get the train-mode update.
  * nrgbd_nhwc_stats: the same partials for a channels-last tensor produced elsewhere (the stride-2 / 1x1 layers that

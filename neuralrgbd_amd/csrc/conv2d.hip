@@ -379,6 +379,7 @@ extern "C" int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_rel
     hipStream_t st = (hipStream_t)stream;
     if (dilation == 1 && Cout == 32) launch_conv2d<32, 1>(a, nwg, st);
     else if (dilation == 1 && Cout == 64) launch_conv2d<64, 1>(a, nwg, st);
+    else if (dilation == 1 && Cout == 96) launch_conv2d<96, 1>(a, nwg, st);
     else if (dilation == 1 && Cout == 128) launch_conv2d<128, 1>(a, nwg, st);
     else if (dilation == 2 && Cout == 128) launch_conv2d<128, 2>(a, nwg, st);
     else return NRGBD_E_SHAPE;

@@ -18,7 +18,7 @@ def _cl(x):   # [N,C,H,W] -> channels-last [N,H,W,C]
 @pytest.mark.parametrize("N,H,W,Cin,Cout,dil", [
     (2, 32, 48, 32, 32, 1), (1, 16, 16, 64, 64, 1), (3, 21, 37, 64, 64, 1), (2, 24, 40, 64, 128, 1),
     (2, 30, 34, 128, 128, 1), (2, 30, 34, 128, 128, 2), (1, 5, 7, 128, 128, 2), (1, 16, 32, 320, 128, 1),
-    (5, 48, 64, 16, 32, 1)])
+    (5, 48, 64, 16, 32, 1), (1, 40, 56, 96, 96, 1), (1, 33, 47, 80, 64, 1)])
 def test_conv2d_plain_vs_torch(N, H, W, Cin, Cout, dil):
     from neuralrgbd_amd import ops
     g = torch.Generator().manual_seed(N * 1000 + H + Cin)
@@ -113,3 +113,4 @@ def test_pack_nhwc_channels_last_input():
     a = ops.pack_nhwc(feat, rgb)
     b = ops.pack_nhwc(feat.permute(0, 2, 3, 1).contiguous(), rgb, channels_last=True)
     assert torch.equal(a, b)
+
