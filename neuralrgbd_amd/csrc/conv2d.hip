@@ -41,7 +41,7 @@ struct Conv2dArgs {
 };
 
 template <int COUT, int DIL, bool RES>
-__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(const Conv2dArgs a) {
+__global__ __launch_bounds__(256, COUT <= 64 ? 3 : 2) void conv2d_mfma_kernel(const Conv2dArgs a) {
     constexpr int HS = kT2 + 2 * DIL, HALO = HS * HS;   // halo tile edge / pixels (324 | 400)
     constexpr int NPF = (HALO * (kCB / 4) + 255) / 256;  // 16-B words per thread per channel block (6 | 7)
     constexpr int NF = COUT / 32;                        // 32-column output fragments
