@@ -164,7 +164,11 @@ __global__ __launch_bounds__(256, COUT <= 64 ? 3 : 2) void conv2d_mfma_kernel(co
                 for (int f = 0; f < NF; ++f) Bn[nxt][f] = wn[f * 64];
             }
             // one word of the NEXT channel block per step: x in steps 2 .. 2+NPF-1, the residual operand after it
-            if (s >= 2 && s < 2 + NPF) pre[s - 2] = *reinterpret_cast<const f32x4*>(a.x + ((pf_off[s - 2] + nb) & live));
+            if constexpr (!RES) {   // registers to spare: a scalar branch skips the loads in the last block
+                if (s >= 2 && s < 2 + NPF && live) pre[s - 2] = *reinterpret_cast<const f32x4*>(a.x + pf_off[s - 2] + nb);
+            } else {
+                if (s >= 2 && s < 2 + NPF) pre[s - 2] = *reinterpret_cast<const f32x4*>(a.x + ((pf_off[s - 2] + nb) & live));
+            }
             if constexpr (RES) {
                 if (s >= 2 + NPF && s < 2 + 2 * NPF)
                     prer[s - 2 - NPF] = *reinterpret_cast<const f32x4*>(a.res + ((pf_off[s - 2 - NPF] + nb) & live));

@@ -220,7 +220,11 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
             }
             if constexpr (PF) {  // one word of the NEXT channel block per step: x in steps 2 .. 2+NPF-1, then the residual
                 constexpr int PF0 = 2;
-                if (s >= PF0 && s < PF0 + NPF) pre[s - PF0] = *reinterpret_cast<const f32x4*>(a.x + ((pf_off[s - PF0] + nb) & live));
+                if constexpr (!RES) {   // registers to spare: a scalar branch skips the loads in the last block
+                    if (s >= PF0 && s < PF0 + NPF && live) pre[s - PF0] = *reinterpret_cast<const f32x4*>(a.x + pf_off[s - PF0] + nb);
+                } else {
+                    if (s >= PF0 && s < PF0 + NPF) pre[s - PF0] = *reinterpret_cast<const f32x4*>(a.x + ((pf_off[s - PF0] + nb) & live));
+                }
                 if constexpr (RES) {
                     if (s >= PF0 + NPF && s < PF0 + 2 * NPF)
                         prer[s - PF0 - NPF] = *reinterpret_cast<const f32x4*>(a.res + ((pf_off[s - PF0 - NPF] + nb) & live));

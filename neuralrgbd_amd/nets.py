@@ -288,10 +288,17 @@ class PSMFeatures(nn.Module):
         return _Act(y2.z, y2.ss, False, r=sk.z, r_ss=sk.ss)
 
     def fused_ok(self, x):
-        """Inference on the GPU; NRGBD_CNN=vendor keeps the 3x3 convolutions on the vendor library (A/B switch)."""
+        """Inference on the GPU, and a 1/4-resolution grid large enough to fill the chip with the conv kernel's
+        16 x 16-pixel workgroup tiles (>= 1.5 per CU; measured: 1024x768 and 640x480 images gain, 384x256 and
+        768x256 lose against the vendor convolutions + csrc/bn2d.hip).  NRGBD_CNN=vendor|mfma overrides."""
         import os
-        return x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32 \
-            and os.environ.get("NRGBD_CNN", "mfma") != "vendor"
+        if not (x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32):
+            return False
+        mode = os.environ.get("NRGBD_CNN", "auto")
+        if mode != "auto":
+            return mode == "mfma"
+        tiles = x.shape[0] * (-(-x.shape[2] // 64)) * (-(-x.shape[3] // 64))
+        return tiles >= 384
 
     def forward_channels_last(self, x):
         """Inference on the hand-written kernels: x [N,3,H,W] -> (layer1 [N,H/2,W/2,32], feat [N,H/4,W/4,F]), both

@@ -32,7 +32,11 @@ def _stream(model, cam, d_candi, windows, R_net=False):
     return outs
 
 
-def test_two_frame_stream_vs_golden(golden_net):
+@pytest.mark.parametrize("cnn", ["mfma", "vendor"])
+def test_two_frame_stream_vs_golden(golden_net, monkeypatch, cnn):
+    """Both executions of the feature CNN (hand-written matrix-core trunk / vendor convolutions + fused BatchNorm;
+    the default picks by grid size) against the reference's outputs."""
+    monkeypatch.setenv("NRGBD_CNN", cnn)
     n, g = gen_golden.NET, golden_net
     cam = camera.scannet_intrinsics(n["W"] // 4, n["H"] // 4)
     d_candi = np.linspace(n["d_min"], n["d_max"], n["D"])
@@ -56,9 +60,10 @@ def test_two_frame_stream_vs_golden(golden_net):
     assert np.abs(sub - g["refined_f2_sub"]).mean() < 1e-3
 
 
-def test_update_frame_vs_cpu_oracle_config_S_small():
+def test_update_frame_vs_cpu_oracle_config_S_small(monkeypatch):
     """One update-branch frame at a second shape/seed against the oracle run on this machine's CPU."""
     H, W, D = 256, 256, 24
+    monkeypatch.setenv("NRGBD_CNN", "mfma")
     cam = camera.scannet_intrinsics(W // 4, H // 4)
     d_candi = np.linspace(0.1, 5, D)
     model, sd = _model(cam, d_candi, 10.0, seed=1)
@@ -73,7 +78,9 @@ def test_update_frame_vs_cpu_oracle_config_S_small():
     assert near_tie_mismatches(dpv2[0].cpu().numpy(), o2[1][0].numpy(), 1e-3) == 0
 
 
-def test_rendered_scene_vs_golden(golden_scene):
+@pytest.mark.parametrize("cnn", ["mfma", "vendor"])
+def test_rendered_scene_vs_golden(golden_scene, monkeypatch, cnn):
+    monkeypatch.setenv("NRGBD_CNN", cnn)
     s, g = gen_golden.SCENE, golden_scene
     cam = camera.scannet_intrinsics(s["W"] // 4, s["H"] // 4)
     cam_full = camera.scannet_intrinsics(s["W"], s["H"])
