@@ -41,7 +41,7 @@ struct Conv2dArgs {
 };
 
 template <int COUT, int DIL, bool RES>
-__global__ __launch_bounds__(256, COUT <= 64 ? 3 : 2) void conv2d_mfma_kernel(const Conv2dArgs a) {
+__global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(const Conv2dArgs a) {
     constexpr int HS = kT2 + 2 * DIL, HALO = HS * HS;   // halo tile edge / pixels (324 | 400)
     constexpr int NPF = (HALO * (kCB / 4) + 255) / 256;  // 16-B words per thread per channel block (6 | 7)
     constexpr int NF = COUT / 32;                        // 32-column output fragments
@@ -142,9 +142,16 @@ __global__ __launch_bounds__(256, COUT <= 64 ? 3 : 2) void conv2d_mfma_kernel(co
 
         // ---- 9 taps x G4 k-groups; B operand streamed from L2 (packed: one 1 KB line per wave load) ----
         const f32x4* wb = reinterpret_cast<const f32x4*>(a.wp) + (size_t)cblk * (G4 * NF * 64) + lane;
-        f32x4 Bn[2][NF], An[2][2];
+        // B runs BD steps ahead of its use: vmcnt retires in order, so a B load also waits for the (HBM-latency)
+        // prefetch words issued before it; A (LDS) runs one step ahead
+        constexpr int BD = COUT <= 64 ? 3 : 1, NB = BD + 1;
+        f32x4 Bn[NB][NF], An[2][2];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) Bn[0][f] = wb[f * 64];
+        for (int b = 0; b < BD; ++b) {
+            const f32x4* w0 = wb + (size_t)(b / G4) * wstep + (b % G4) * (NF * 64);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) Bn[b][f] = w0[f * 64];
+        }
         An[0][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv0, khalf * 2));
         An[0][1] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv0 + 2 * HS, khalf * 2));
         // next block's words; in the last block every lane re-reads element 0 instead (one cached line, no branch)
@@ -152,16 +159,19 @@ __global__ __launch_bounds__(256, COUT <= 64 ? 3 : 2) void conv2d_mfma_kernel(co
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
-            if (s + 1 < NSTEP) {  // operands of step s+1
+            if (s + 1 < NSTEP) {  // A operands of step s+1
                 const int tap = (s + 1) / G4, g = (s + 1) % G4;
                 const int voff = ((tap / 3) * HS + (tap % 3)) * DIL;  // tap offset in halo pixels
                 int h0 = hv0;
                 asm volatile("" : "+v"(h0));  // keep the swizzled addresses out of long-lived registers
                 An[nxt][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(h0 + voff, khalf * 2 + g));
                 An[nxt][1] = *reinterpret_cast<const f32x4*>(lds + lds_slot(h0 + 2 * HS + voff, khalf * 2 + g));
+            }
+            if (s + BD < NSTEP) {  // B operands of step s+BD
+                const int tap = (s + BD) / G4, g = (s + BD) % G4;
                 const f32x4* wn = wb + (size_t)tap * wstep + g * (NF * 64);
 #pragma unroll
-                for (int f = 0; f < NF; ++f) Bn[nxt][f] = wn[f * 64];
+                for (int f = 0; f < NF; ++f) Bn[(s + BD) % NB][f] = wn[f * 64];
             }
             // one word of the NEXT channel block per step: x in steps 2 .. 2+NPF-1, the residual operand after it
             if constexpr (!RES) {   // registers to spare: a scalar branch skips the loads in the last block
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(256, COUT <= 64 ? 3 : 2) void conv2d_mfma_kernel(co
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int f = 0; f < NF; ++f)
-                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(An[cur][m][e], Bn[cur][f][e], acc[m][f], 0, 0, 0);
+                        acc[m][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(An[cur][m][e], Bn[s % NB][f][e], acc[m][f], 0, 0, 0);
         }
         __syncthreads();
     }

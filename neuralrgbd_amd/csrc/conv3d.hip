@@ -196,16 +196,22 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
         // ---- 27 taps x G4 k-groups; B operand streamed from L2 (packed: one 1 KB line per wave load) ----
         const f32x4* wb = reinterpret_cast<const f32x4*>(a.wp) + (size_t)cblk * (G4 * 2 * 64) + lane;
         constexpr int WSTEP = NCBLK * G4 * 2 * 64;  // f32x4 per tap
-        f32x4 Bn[2][2], An[2][2];
+        // B runs BD steps ahead of its use (L2 latency under load is about one step of two interleaved waves), A one
+        constexpr int BD = PF ? (RES ? 2 : 3) : 1, NB = BD + 1;
+        f32x4 Bn[NB][2], An[2][2];
         // next block's words; in the last block every lane re-reads element 0 instead (one cached line, no branch)
         const unsigned nb = (cblk + 1) * kCB, live = cblk + 1 < NCBLK ? ~0u : 0u;
-        Bn[0][0] = wb[0]; Bn[0][1] = wb[64];
+#pragma unroll
+        for (int b = 0; b < BD; ++b) {
+            const f32x4* w0 = wb + (size_t)(b / G4) * WSTEP + (b % G4) * (2 * 64);
+            Bn[b][0] = w0[0]; Bn[b][1] = w0[64];
+        }
         An[0][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv0, khalf * 2));
         An[0][1] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv1, khalf * 2));
 #pragma unroll
         for (int s = 0; s < 27 * G4; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
-            if (s + 1 < 27 * G4) {  // prefetch step s+1
+            if (s + 1 < 27 * G4) {  // A operands of step s+1
                 const int tap = (s + 1) / G4, g = (s + 1) % G4;
                 const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
                 const int voff = (kd * kHH + kh) * kHW + kw;  // tap offset in halo voxels
@@ -215,8 +221,11 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
                 asm volatile("" : "+v"(h0));
                 An[nxt][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(h0 + voff, khalf * 2 + g));
                 An[nxt][1] = *reinterpret_cast<const f32x4*>(lds + lds_slot(h0 + 2 * kHW + voff, khalf * 2 + g));
+            }
+            if (s + BD < 27 * G4) {  // B operands of step s+BD
+                const int tap = (s + BD) / G4, g = (s + BD) % G4;
                 const f32x4* wn = wb + (size_t)tap * WSTEP + g * (2 * 64);
-                Bn[nxt][0] = wn[0]; Bn[nxt][1] = wn[64];
+                Bn[(s + BD) % NB][0] = wn[0]; Bn[(s + BD) % NB][1] = wn[64];
             }
             if constexpr (PF) {  // one word of the NEXT channel block per step: x in steps 2 .. 2+NPF-1, then the residual
                 constexpr int PF0 = 2;
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(An[cur][m][e], Bn[cur][n][e], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(An[cur][m][e], Bn[s % NB][n][e], acc[m][n], 0, 0, 0);
         }
         __syncthreads();
     }
