@@ -151,6 +151,23 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
         }
     }
 
+    // B operand ring: runs BD steps ahead of its use — vmcnt retires in order, so a B load also waits for the
+    // (HBM-latency) prefetch words issued before it — and straight across channel-block boundaries, so the first steps
+    // of a block never wait for their weights.  A (LDS) runs one step ahead.
+    constexpr int NSTEP = 27 * G4;
+    constexpr int WSTEP = NCBLK * G4 * 2 * 64;  // f32x4 per tap
+    constexpr int BD = PF ? (RES ? 2 : 3) : 1, NB = BD + 1;
+    constexpr bool BCONT = !RES;   // the residual variant has no register left to carry the ring across the publish phase
+    f32x4 Bn[NB][2];
+    if constexpr (BCONT) {
+        const f32x4* w0 = reinterpret_cast<const f32x4*>(a.wp) + lane;
+#pragma unroll
+        for (int b = 0; b < BD; ++b) {
+            Bn[b][0] = w0[(size_t)(b / G4) * WSTEP + (b % G4) * (2 * 64)];
+            Bn[b][1] = w0[(size_t)(b / G4) * WSTEP + (b % G4) * (2 * 64) + 64];
+        }
+    }
+
     for (int cblk = 0; cblk < NCBLK; ++cblk) {
         if constexpr (PF) {
             // normalise / activate the prefetched words of this block and publish them to LDS
@@ -195,23 +212,23 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
 
         // ---- 27 taps x G4 k-groups; B operand streamed from L2 (packed: one 1 KB line per wave load) ----
         const f32x4* wb = reinterpret_cast<const f32x4*>(a.wp) + (size_t)cblk * (G4 * 2 * 64) + lane;
-        constexpr int WSTEP = NCBLK * G4 * 2 * 64;  // f32x4 per tap
-        // B runs BD steps ahead of its use (L2 latency under load is about one step of two interleaved waves), A one
-        constexpr int BD = PF ? (RES ? 2 : 3) : 1, NB = BD + 1;
-        f32x4 Bn[NB][2], An[2][2];
+        f32x4 An[2][2];
         // next block's words; in the last block every lane re-reads element 0 instead (one cached line, no branch)
         const unsigned nb = (cblk + 1) * kCB, live = cblk + 1 < NCBLK ? ~0u : 0u;
+        const f32x4* wbn = wb + (cblk + 1 < NCBLK ? G4 * 2 * 64 : 0);  // next block's stream (last block: a harmless re-read)
+        if constexpr (!BCONT) {
 #pragma unroll
-        for (int b = 0; b < BD; ++b) {
-            const f32x4* w0 = wb + (size_t)(b / G4) * WSTEP + (b % G4) * (2 * 64);
-            Bn[b][0] = w0[0]; Bn[b][1] = w0[64];
+            for (int b = 0; b < BD; ++b) {
+                Bn[b][0] = wb[(size_t)(b / G4) * WSTEP + (b % G4) * (2 * 64)];
+                Bn[b][1] = wb[(size_t)(b / G4) * WSTEP + (b % G4) * (2 * 64) + 64];
+            }
         }
         An[0][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv0, khalf * 2));
         An[0][1] = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv1, khalf * 2));
 #pragma unroll
-        for (int s = 0; s < 27 * G4; ++s) {
+        for (int s = 0; s < NSTEP; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
-            if (s + 1 < 27 * G4) {  // A operands of step s+1
+            if (s + 1 < NSTEP) {  // A operands of step s+1
                 const int tap = (s + 1) / G4, g = (s + 1) % G4;
                 const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
                 const int voff = (kd * kHH + kh) * kHW + kw;  // tap offset in halo voxels
@@ -222,9 +239,9 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
                 An[nxt][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(h0 + voff, khalf * 2 + g));
                 An[nxt][1] = *reinterpret_cast<const f32x4*>(lds + lds_slot(h0 + 2 * kHW + voff, khalf * 2 + g));
             }
-            if (s + BD < 27 * G4) {  // B operands of step s+BD
-                const int tap = (s + BD) / G4, g = (s + BD) % G4;
-                const f32x4* wn = wb + (size_t)tap * WSTEP + g * (2 * 64);
+            if (BCONT || s + BD < NSTEP) {   // B operands of step s+BD (of the next channel block once this one's stream is exhausted)
+                const int t = (s + BD) % NSTEP, tap = t / G4, g = t % G4;
+                const f32x4* wn = (s + BD < NSTEP ? wb : wbn) + (size_t)tap * WSTEP + g * (2 * 64);
                 Bn[(s + BD) % NB][0] = wn[0]; Bn[(s + BD) % NB][1] = wn[64];
             }
             if constexpr (PF) {  // one word of the NEXT channel block per step: x in steps 2 .. 2+NPF-1, then the residual
@@ -246,6 +263,13 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(An[cur][m][e], Bn[s % NB][n][e], acc[m][n], 0, 0, 0);
+        }
+        if constexpr (BCONT && NSTEP % NB != 0) {  // next block's steps 0..BD-1 sit in ring slots (NSTEP+b) % NB: move them to b
+            f32x4 t[BD][2];
+#pragma unroll
+            for (int b = 0; b < BD; ++b) { t[b][0] = Bn[(NSTEP + b) % NB][0]; t[b][1] = Bn[(NSTEP + b) % NB][1]; }
+#pragma unroll
+            for (int b = 0; b < BD; ++b) { Bn[b][0] = t[b][0]; Bn[b][1] = t[b][1]; }
         }
         __syncthreads();
     }
