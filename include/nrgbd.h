@@ -227,6 +227,12 @@ int nrgbd_bn2d_train_act(const float* x, const float* gamma, const float* beta, 
                          const float* residual, float* y, float* partial, float* mean_var,
                          int N, int C, long HW, void* stream);
 int nrgbd_avgpool8(const float* x, float* y, int NC, int H, int W, void* stream);
+/*
+ * nrgbd_bias_act_nchw — x = leaky_relu(x + bias[c], slope) in place on [N][C][HW] (HW % 4 == 0): the bias + LeakyReLU
+ * tail of the R-Net's conv2d_leakyRelu / conv2dTranspose_leakyRelu blocks (models/m_submodule.py:18-27,36-45) in one
+ * pass after a bias-free vendor convolution; slope = 1 is the plain bias add of Refine.py:71.
+ */
+int nrgbd_bias_act_nchw(float* x, const float* bias, float slope, int N, int C, long HW, void* stream);
 
 /*
  * Feature CNN (and R-Net form): 3x3 convolution, stride 1, padding = dilation, on the fp32 matrix cores with the

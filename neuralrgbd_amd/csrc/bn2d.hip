@@ -114,6 +114,26 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
     y[((size_t)nc * oh + oy) * ow + ox] = s / (float)(K * K);
 }
 
+
+// y = leaky(x + bias[c], slope) in place on [N][C][HW] — the R-Net's conv2d_leakyRelu / ConvTranspose2d + LeakyReLU
+// tail (models/m_submodule.py:18-27,36-45) as one pass instead of the vendor conv's separate bias-add kernel plus a
+// LeakyReLU kernel.  slope = 1 gives the plain bias add of the last layer (Refine.py:71).  grid (chunks, N*C).
+__global__ __launch_bounds__(256) void bias_act_nchw_kernel(float* __restrict__ x, const float* __restrict__ bias, float slope,
+                                                            int C, long HW) {
+    const int nc = blockIdx.y;
+    const float b = bias[nc % C];
+    const size_t base = (size_t)nc * HW;
+    const long hw4 = HW >> 2;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw4; i += stride) {
+        float4 v = reinterpret_cast<float4*>(x + base)[i];
+        v.x += b; v.y += b; v.z += b; v.w += b;
+        v.x = v.x > 0.f ? v.x : slope * v.x; v.y = v.y > 0.f ? v.y : slope * v.y;
+        v.z = v.z > 0.f ? v.z : slope * v.z; v.w = v.w > 0.f ? v.w : slope * v.w;
+        reinterpret_cast<float4*>(x + base)[i] = v;
+    }
+}
+
 }  // namespace nrgbd
 
 extern "C" int nrgbd_bn2d_partial_floats(int C) { return C > 0 ? C * nrgbd::kBnSplit * 2 : NRGBD_E_SHAPE; }
@@ -145,6 +165,18 @@ extern "C" int nrgbd_avgpool8(const float* x, float* y, int NC, int H, int W, vo
     if (reinterpret_cast<uintptr_t>(x) & 15) return NRGBD_E_ALIGN;
     dim3 grid(ceil_div(W / 8, 256), H / 8, NC);
     hipLaunchKernelGGL(avgpool_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, y, H, W);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+extern "C" int nrgbd_bias_act_nchw(float* x, const float* bias, float slope, int N, int C, long HW, void* stream) {
+    using namespace nrgbd;
+    if (!x || !bias) return NRGBD_E_NULL;
+    if (N <= 0 || C <= 0 || HW <= 0 || (HW & 3) || (long)N * C > 65535) return NRGBD_E_SHAPE;
+    if (reinterpret_cast<uintptr_t>(x) & 15) return NRGBD_E_ALIGN;
+    long want = (HW / 4 + 1023) / 1024;
+    const int chunks = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+    hipLaunchKernelGGL(bias_act_nchw_kernel, dim3(chunks, N * C), dim3(256), 0, (hipStream_t)stream, x, bias, slope, C, HW);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -578,7 +578,35 @@ class DPVUpsampleNet(nn.Module):
                 bil = (1 - abs(og[0] - center) / factor) * (1 - abs(og[1] - center) / factor)
                 m.weight.data.copy_(torch.from_numpy(bil))
 
+    def _forward_fused_tail(self, dpv_raw, img_features):
+        """Inference: same graph as forward(), vendor convolutions without their bias, then ONE hand-written pass for
+        bias + LeakyReLU (csrc/bn2d.hip::bias_act_nchw) instead of a bias-add kernel and a LeakyReLU kernel per layer;
+        the final bias add + log-softmax over D run on csrc/softmax.hip."""
+        from . import ops
+        quarter, half, full = (t.contiguous() for t in img_features)
+
+        def layer(m, x, slope=0.01):
+            c = m[0] if isinstance(m, nn.Sequential) else m
+            if isinstance(c, nn.ConvTranspose2d):
+                y = F.conv_transpose2d(x, c.weight, None, c.stride, c.padding)
+            else:
+                y = F.conv2d(x, c.weight, None, c.stride, c.padding)
+            if not y.is_contiguous():
+                y = y.contiguous()
+            return ops.bias_act_(y, c.bias.detach(), slope)
+
+        x = layer(self.conv0_1, layer(self.conv0, torch.cat([dpv_raw, quarter], dim=1)))
+        x = layer(self.trans_conv0, x)
+        x = layer(self.conv1_1, layer(self.conv1, torch.cat([x, half], dim=1)))
+        x = layer(self.trans_conv1, x)
+        x = layer(self.conv2_1, layer(self.conv2, torch.cat([x, full], dim=1)))
+        x = layer(self.conv2_2, x, slope=1.0)
+        return ops.logsoftmax_d(x[0]).unsqueeze(0)
+
     def forward(self, dpv_raw, img_features):
+        if dpv_raw.is_cuda and not torch.is_grad_enabled() and dpv_raw.shape[0] == 1 \
+                and (dpv_raw.shape[2] * dpv_raw.shape[3]) % 4 == 0:
+            return self._forward_fused_tail(dpv_raw, img_features)
         quarter, half, full = img_features
         x = self.conv0_1(self.conv0(torch.cat([dpv_raw, quarter], dim=1)))
         x = self.trans_conv0(x)

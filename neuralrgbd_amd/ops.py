@@ -377,3 +377,16 @@ def avgpool8(x):
         rc = _lib.load().nrgbd_avgpool8(_p(x), _p(y), N * C, H, W, _stream(x))
     _lib.check(rc, "nrgbd_avgpool8")
     return y
+
+
+def bias_act_(x, bias, slope):
+    """In place x = leaky_relu(x + bias[c], slope) on a contiguous [N,C,H,W] tensor (slope 1 = bias add only)."""
+    x = _need(x, "x", strided=True)
+    if not x.is_contiguous():
+        raise ValueError("bias_act_ needs a contiguous NCHW tensor")
+    N, C, H, W = x.shape
+    bias = _need(bias, "bias", (C,))
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_bias_act_nchw(_p(x), _p(bias), float(slope), N, C, H * W, _stream(x))
+    _lib.check(rc, "nrgbd_bias_act_nchw")
+    return x

@@ -114,3 +114,31 @@ def test_pack_nhwc_channels_last_input():
     b = ops.pack_nhwc(feat.permute(0, 2, 3, 1).contiguous(), rgb, channels_last=True)
     assert torch.equal(a, b)
 
+
+@pytest.mark.parametrize("h,w", [(16, 24), (30, 40)])
+def test_rnet_fused_tail_vs_torch_modules(h, w):
+    """DPVUpsampleNet inference path (bias-free vendor convs + one bias/LeakyReLU pass + our log-softmax) == the torch
+    module graph (taken under autograd)."""
+    from neuralrgbd_amd import nets, ops
+    torch.manual_seed(11)
+    net = nets.DPVUpsampleNet(64, 32, 3, D=64).to(DEV)
+    for m in net.modules():
+        if getattr(m, "bias", None) is not None:
+            torch.nn.init.normal_(m.bias, 0, 0.1)
+    dpv = torch.softmax(torch.randn(1, 64, h, w, device=DEV), dim=1)
+    feats = [torch.randn(1, 64, h, w, device=DEV), torch.randn(1, 32, 2 * h, 2 * w, device=DEV),
+             torch.rand(1, 3, 4 * h, 4 * w, device=DEV)]
+    with torch.enable_grad():
+        want = net(dpv, feats).detach()
+    with torch.no_grad():
+        got = net(dpv, feats)
+        feats_cl = [f.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) for f in feats[:2]] + [feats[2]]
+        got2 = net(dpv, feats_cl)       # channels-last feature views, as the matrix-core D-Net hands them over
+    err = (got - want).abs().max().item()
+    print("[parity] R-Net fused tail %dx%d max|d log p|=%.3e" % (h, w, err))
+    assert got.shape == want.shape and err < 1e-4
+    assert (got2 - got).abs().max().item() < 1e-4
+    x = torch.randn(2, 5, 6, 10, device=DEV)
+    b = torch.randn(5, device=DEV)
+    ref = F.leaky_relu(x + b.view(1, -1, 1, 1), 0.01)
+    assert torch.allclose(ops.bias_act_(x.clone(), b, 0.01), ref, atol=1e-7)
