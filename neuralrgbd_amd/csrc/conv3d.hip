@@ -50,6 +50,14 @@ struct Conv3dArgs {
     int xcd;              // re-map workgroups so each XCD owns a contiguous run of tiles (conv_tile.hpp)
 };
 
+// tile id -> tile coordinates.  order 0/1: x fastest, then y, then z; order 2: z fastest, then x, then y — the z halo is
+// the largest shared part of neighbouring tiles (4 input planes for 2 output planes), so consecutive ids then re-use it
+// from the XCD's L2 (with the contiguous-run XCD mapping of conv_tile.hpp).
+__device__ __forceinline__ void tile_coords(int t, int tiles_x, int tiles_y, int tiles_z, int order, int& tx, int& ty, int& tz) {
+    if (order == 2) { tz = t % tiles_z; t /= tiles_z; tx = t % tiles_x; ty = t / tiles_x; }
+    else            { tx = t % tiles_x; t /= tiles_x; ty = t % tiles_y; tz = t / tiles_y; }
+}
+
 // Stage the (4 x 10 x 18)-voxel halo tile of channel block `cblk` into LDS as [voxel][kSV]:
 //   in = act(x*s+t) [+ act(res*s'+t')] inside the volume, 0 outside (zero padding applies to the
 //   ACTIVATED tensor, exactly like F.conv3d(padding=1) on the materialised activation).
@@ -104,8 +112,8 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
     const int tiles_x = (a.W + kTW - 1) / kTW, tiles_y = (a.H + kTH - 1) / kTH;
     int t = xcd_tile(blockIdx.x, gridDim.x, a.xcd);
     const int tile_id = t;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y; const int tz = t / tiles_y;
+    int tx, ty, tz;
+    tile_coords(t, tiles_x, tiles_y, (a.D + kTD - 1) / kTD, a.xcd, tx, ty, tz);
     const int x0 = tx * kTW, y0 = ty * kTH, z0 = tz * kTD;
 
     // this lane's A rows: wave -> (dz, 4-row band); tile m -> 2 rows of the band
@@ -317,43 +325,129 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
     }
 }
 
-// Last K-Net layer (models/basic.py:92-94: Conv3d(64, 1, 3, padding=1, bias=False), no BatchNorm):
-// one output channel has nothing for the matrix cores (1 of 32 columns), so it is a VALU kernel on the
-// same staged halo tile: one thread = one output voxel, 27 taps x 64 channels of FMAs, the 1728 weights
-// are wave-uniform (scalar loads).  w1 is [27][64] (tap-major).  0.07 % of the K-Net FLOPs.
+// Last K-Net layer (models/basic.py:92-94: Conv3d(64, 1, 3, padding=1, bias=False), no BatchNorm).
+// One output channel leaves 31 of 32 MFMA columns empty if the taps are the K dimension, so the sum is re-associated:
+//     P[u][tap] = sum_c w[tap][c] * in[u][c]          a [halo voxels x 64] x [64 x 27(->32)] GEMM on the matrix cores
+//     out[v]    = sum_tap P[v + tap][tap]             27 scalar LDS reads per output voxel
+// i.e. every halo voxel is projected onto the 27 tap weights once (instead of 27 x 64 FMAs per output voxel fed by
+// 108 16-B LDS reads).  Tile and staging as in the main kernel; wave w owns the 32-voxel row tiles w, w+4, ...
+// of the 720-voxel halo (6 tiles = 96 accumulator VGPRs); P goes to LDS as [voxel][27] (odd stride: conflict-free for
+// lanes along x) over the staging buffer.  w1 is [27][64] (tap-major): a lane's B operand is 16 contiguous bytes of it.
 __global__ __launch_bounds__(256, 2) void conv3d_cout1_kernel(const Conv3dArgs a, const float* __restrict__ w1) {
-    constexpr int CIN = 64, NCBLK = CIN / kCB;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
+    constexpr int CIN = 64, NCBLK = CIN / kCB, G4 = kCB / 8;
+    constexpr int NT = (kHaloVox + 31) / 32;       // 23 row tiles
+    constexpr int TPW = (NT + 3) / 4;              // 6 per wave
+    constexpr int PS = 27;                         // P row stride (floats)
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // staging [kHaloVox][kSV], then P [kHaloVox][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tiles_x = (a.W + kTW - 1) / kTW, tiles_y = (a.H + kTH - 1) / kTH;
-    int t = blockIdx.x;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y; const int tz = t / tiles_y;
+    int tx, ty, tz;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x, a.xcd), tiles_x, tiles_y, (a.D + kTD - 1) / kTD, a.xcd, tx, ty, tz);
     const int x0 = tx * kTW, y0 = ty * kTH, z0 = tz * kTD;
-    const int ox = tid & 15, oy = (tid >> 4) & 7, oz = tid >> 7;
-    const int hv_base = (oz * kHH + oy) * kHW + ox;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+
+    const int i = lane & 31, khalf = lane >> 5;
+    int dy, px;
+    row_to_yx(i, dy, px);                          // MFMA row i <-> voxel 32*tile + 16*dy + px (16 consecutive voxels per lane group)
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+
+    // input words of a channel block: thread word u = halo voxel (tid>>2) + 64u, 16-B word tid&3 — all 12 loads of the
+    // next block are issued together right after the barrier and land while this block's MFMAs run
+    constexpr int NPF = (kHaloVox * (kCB / 4) + 255) / 256;
+    const int c4 = tid & 3;
+    unsigned pf_off[NPF], pf_ok = 0;
+    f32x4 pre[NPF];
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+        const int hv = (tid >> 2) + 64 * u;
+        const int hz = hv / (kHH * kHW), rem = hv - hz * (kHH * kHW);
+        const int hy = rem / kHW, hx = rem - hy * kHW;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = hv < kHaloVox && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        pf_off[u] = ok ? (unsigned)((((size_t)gz * a.H + gy) * a.W + gx) * CIN + c4 * 4) : (unsigned)(c4 * 4);
+        if (ok) pf_ok |= 1u << u;
+    }
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) pre[u] = *reinterpret_cast<const f32x4*>(a.x + pf_off[u]);
+
     for (int cblk = 0; cblk < NCBLK; ++cblk) {
-        stage_halo<CIN>(a, cblk, lds, tid, x0, y0, z0);
+        {
+            const int c = cblk * kCB + c4 * 4;
+            float ss[8] = {1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f};
+            if (a.x_ss) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss[e] = a.x_ss[2 * c + e];
+            }
+#pragma unroll
+            for (int u = 0; u < NPF; ++u) {
+                const int hv = (tid >> 2) + 64 * u;
+                if (hv >= kHaloVox) continue;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((pf_ok >> u) & 1u) {   // zero padding applies to the ACTIVATED tensor
+                    v = pre[u];
+                    v.x = __builtin_fmaf(v.x, ss[0], ss[1]); v.y = __builtin_fmaf(v.y, ss[2], ss[3]);
+                    v.z = __builtin_fmaf(v.z, ss[4], ss[5]); v.w = __builtin_fmaf(v.w, ss[6], ss[7]);
+                    if (a.x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                *reinterpret_cast<f32x4*>(lds + lds_slot(hv, c4)) = v;
+            }
+        }
+        f32x4 B[G4];
+#pragma unroll
+        for (int g = 0; g < G4; ++g)
+            B[g] = (i < 27) ? *reinterpret_cast<const f32x4*>(w1 + i * CIN + cblk * kCB + khalf * 8 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
+        if (cblk + 1 < NCBLK) {
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const int hv = hv_base + (kd * kHH + kh) * kHW + kw;
-            const float* pw = w1 + tap * CIN + cblk * kCB;
+            for (int u = 0; u < NPF; ++u) pre[u] = *reinterpret_cast<const f32x4*>(a.x + pf_off[u] + (cblk + 1) * kCB);
+        }
 #pragma unroll
-            for (int c4 = 0; c4 < kCB / 4; ++c4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv, c4));
-                acc0 = __builtin_fmaf(v.x, pw[c4 * 4 + 0], acc0);
-                acc1 = __builtin_fmaf(v.y, pw[c4 * 4 + 1], acc1);
-                acc2 = __builtin_fmaf(v.z, pw[c4 * 4 + 2], acc2);
-                acc3 = __builtin_fmaf(v.w, pw[c4 * 4 + 3], acc3);
+        for (int k = 0; k < TPW; ++k) {
+            const int tile = wv + 4 * k;
+            if (tile < NT) {   // wave-uniform
+                int hv = tile * 32 + dy * 16 + px;
+                hv = hv < kHaloVox ? hv : kHaloVox - 1;   // rows beyond the halo (last tile) are computed and dropped
+#pragma unroll
+                for (int g = 0; g < G4; ++g) {
+                    const f32x4 A = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv, khalf * 2 + g));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[e], B[g][e], acc[k], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
     }
+
+    // P -> LDS [voxel][27]
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const int tile = wv + 4 * k;
+        if (tile < NT && i < 27) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                int ry, rx;
+                row_to_yx(row, ry, rx);
+                const int hv = tile * 32 + ry * 16 + rx;
+                if (hv < kHaloVox) lds[hv * PS + i] = acc[k][r];
+            }
+        }
+    }
+    __syncthreads();
+    const int ox = tid & 15, oy = (tid >> 4) & 7, oz = tid >> 7;
+    const int hv_base = (oz * kHH + oy) * kHW + ox;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 27; tap += 3) {
+        const int kd = tap / 9, kh = (tap / 3) % 3;
+        const float* p = lds + (hv_base + (kd * kHH + kh) * kHW) * PS + tap;
+        s0 += p[0]; s1 += p[PS + 1]; s2 += p[2 * PS + 2];
+    }
     const int gz = z0 + oz, gy = y0 + oy, gx = x0 + ox;
-    if (gz < a.D && gy < a.H && gx < a.W) a.y[((size_t)gz * a.H + gy) * a.W + gx] = (acc0 + acc1) + (acc2 + acc3);
+    if (gz < a.D && gy < a.H && gx < a.W) a.y[((size_t)gz * a.H + gy) * a.W + gx] = (s0 + s1) + s2;
 }
 
 // weights [64][Cin][3][3][3] (torch layout) -> packed [tap][cblk][g][nfrag][lane = khalf*32 + j][4]
@@ -441,7 +535,10 @@ extern "C" int nrgbd_conv3d_3x3x3_f32(const float* x, const float* x_ss, int x_r
     const int nwg = ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
     const size_t lds = (size_t)kHaloVox * kSV * sizeof(float);  // 46,080 B (>= the 2 KB the statistics reuse)
     const bool prefetch = (Cin == 64) && ((long)D * H * W * Cin < (1L << 32)) && !getenv("NRGBD_CONV3D_NOPF");
-    if (Cin == 16)
+    const bool small = (long)D * H * W * Cin < (1L << 32);
+    if (Cin == 16 && small && !res)   // single channel block: batched unconditional loads only
+        hipLaunchKernelGGL((conv3d_mfma_kernel<16, true>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    else if (Cin == 16)
         hipLaunchKernelGGL((conv3d_mfma_kernel<16, false>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     else if (prefetch && res && !getenv("NRGBD_CONV3D_NOPFRES"))
         hipLaunchKernelGGL((conv3d_mfma_kernel<64, true, true>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
@@ -459,9 +556,16 @@ extern "C" int nrgbd_conv3d_3x3x3_cout1_f32(const float* x, const float* x_ss, i
     using namespace nrgbd;
     if (!x || !w_tap_major || !y) return NRGBD_E_NULL;
     if (D <= 0 || H <= 0 || W <= 0 || Cin != 64) return NRGBD_E_SHAPE;
-    Conv3dArgs a{x, x_ss, res, res_ss, nullptr, nullptr, y, nullptr, x_relu, res_relu, D, H, W, 0};
+    Conv3dArgs a{x, x_ss, res, res_ss, nullptr, nullptr, y, nullptr, x_relu, res_relu, D, H, W, getenv("NRGBD_XCD") ? atoi(getenv("NRGBD_XCD")) : 0};
     const int nwg = ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
-    const size_t lds = (size_t)kHaloVox * kSV * sizeof(float);
+    const size_t lds = (size_t)kHaloVox * 27 * sizeof(float);  // P [720][27] (77.8 KB) over the 46 KB staging buffer
+    static bool attr_set[64] = {};   // > 64 KB of dynamic LDS needs the opt-in, once per device
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_cout1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dev] = true;
+    }
     hipLaunchKernelGGL(conv3d_cout1_kernel, dim3(nwg), dim3(256), lds, (hipStream_t)stream, a, w_tap_major);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
