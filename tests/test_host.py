@@ -93,3 +93,27 @@ def test_synth_is_deterministic():
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     R = a[2][0, :, :3, :3].double()
     assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3, dtype=torch.float64).expand(4, 3, 3), atol=1e-6)
+
+
+def test_spp_autograd_forms_match_torch_ops():
+    """The training-path rewrites of the SPP branch (nets.PSMFeatures: pooling as crop+reshape+mean, bilinear
+    align_corners up-sampling as two matrix products) equal avg_pool2d / F.interpolate, values and gradients."""
+    import torch.nn.functional as F
+    from neuralrgbd_amd.nets import PSMFeatures
+    g = torch.Generator().manual_seed(0)
+    for (ph, pw, h, w) in [(1, 1, 64, 96), (2, 3, 64, 96), (4, 6, 64, 96), (8, 12, 64, 96), (3, 4, 120, 160)]:
+        y = torch.randn(2, 5, ph, pw, generator=g, requires_grad=True)
+        Ay, Ax = PSMFeatures._interp_matrix(h, ph, "cpu"), PSMFeatures._interp_matrix(w, pw, "cpu")
+        got = torch.matmul(torch.matmul(Ay, y), Ax.t())
+        want = F.interpolate(y, size=(h, w), mode="bilinear", align_corners=True)
+        assert (got - want).abs().max().item() < 2e-6
+        go = torch.randn(got.shape, generator=g)
+        g1, = torch.autograd.grad(got, y, go, retain_graph=True)
+        g2, = torch.autograd.grad(want, y, go)
+        assert (g1 - g2).abs().max().item() < 1e-4 * max(1.0, g2.abs().max().item())
+    d = torch.randn(2, 3, 64, 96, generator=g)
+    for k in (64, 32, 16, 8):
+        ph, pw = 64 // k, 96 // k
+        a = d[:, :, :ph * k, :pw * k].reshape(2, 3, ph, k, pw, k).mean((3, 5))
+        b = F.avg_pool2d(d, (k, k), stride=(k, k))
+        assert a.shape == b.shape and (a - b).abs().max().item() < 1e-6
