@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
     // of a block never wait for their weights.  A (LDS) runs one step ahead.
     constexpr int NSTEP = 27 * G4;
     constexpr int WSTEP = NCBLK * G4 * 2 * 64;  // f32x4 per tap
-    constexpr int BD = PF ? (RES ? 2 : 3) : 1, NB = BD + 1;
+    constexpr int BD = PF ? 3 : 1, NB = BD + 1;
     constexpr bool BCONT = !RES;   // the residual variant has no register left to carry the ring across the publish phase
     f32x4 Bn[NB][2];
     if constexpr (BCONT) {
