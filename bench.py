@@ -195,7 +195,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "config_id": args.config, "grid_hw": [h, w], "depth_candidates": D,
                        "views": V + 1, "streams_per_gpu": 1, "launch": "hipGraph replay" if stream._graph is not None else "eager",
-                       "parallelism": "replicas x%d (independent video streams)" % world},
+                       "parallelism": "replicas x%d (independent video streams)" % world,
+                       "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9},
             "roofline": {"bound": "hbm", "kernel": "costvol_lds<17,L2> + logsoftmax_d (fused warp + cost volume, log-softmax)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes": algo, "kernel_ms": k_ms, "launches_timed": n_k,
