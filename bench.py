@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--streams", type=int, default=1, help="independent video streams per GPU, each on its own HIP stream "
+                    "(a step is then one frame of EVERY stream; the extra streams fill the tails of each other's kernels)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,12 +156,22 @@ def main():
     ops.conv3d = knet_timer.wrap(ops.conv3d)
 
     # the streaming driver: same per-frame work as test_utils/test_KVNet.py::test (R_net=True), state resident,
-    # the update-branch frame captured into one hipGraph after an eager warm-up frame
-    stream = DepthStream(model, cam, d_candi, t_win_r=2, use_graph=not args.no_graph, device=dev)
+    # the update-branch frame captured into one hipGraph after an eager warm-up frame.  Extra streams per GPU are
+    # further independent videos with their own model replica, filter state, graph and HIP stream.
+    import copy
+    S = max(1, args.streams)
+    models = [model] + [copy.deepcopy(model) for _ in range(S - 1)]
+    hip_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+    streams = [DepthStream(m, cam, d_candi, t_win_r=2, use_graph=not args.no_graph, device=dev) for m in models]
+    stream = streams[0]
 
     def frame(i):
-        r, s, p = ring[i % len(ring)]
-        return stream.step(r, s, p)
+        out = None
+        for k in range(S):
+            r, s_, p = ring[(i + k) % len(ring)]
+            with torch.cuda.stream(hip_streams[k]):
+                out = streams[k].step(r, s_, p)
+        return out
 
     frame(0)                       # first window of the stream: D-Net only, creates the filter state
     for i in range(max(args.warmup, 2)):   # >= 2: one eager update frame, then the capture frame
@@ -190,11 +202,11 @@ def main():
         achieved = algo / (k_ms * 1e-3) / 1e9
         line = {
             "metric": "depth frames/sec @256x192x64cand, 5-view window; warp-kernel HBM GB/s vs peak",
-            "value": args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": args.steps * S * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "config_id": args.config, "grid_hw": [h, w], "depth_candidates": D,
-                       "views": V + 1, "streams_per_gpu": 1, "launch": "hipGraph replay" if stream._graph is not None else "eager",
+                       "views": V + 1, "streams_per_gpu": S, "launch": "hipGraph replay" if stream._graph is not None else "eager",
                        "parallelism": "replicas x%d (independent video streams)" % world,
                        "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9},
             "roofline": {"bound": "hbm", "kernel": "costvol_lds<17,L2> + logsoftmax_d (fused warp + cost volume, log-softmax)",
