@@ -17,7 +17,7 @@ struct CostvolArgs {
     int dist, align;
     int V, C, Cp, D, h, w;
     int nsingle;           // LDS generation: leading candidates that get a workgroup each (set by the launcher)
-    int debug;             // developer ablation bits (env NRGBD_ABLATE): 1 = no staging, 2 = no math
+    int debug;             // developer bits (env NRGBD_ABLATE): 1 = no staging, 2 = no math, 4 = XCD-owned tile order, 8 = singles on any grid, (g+1)<<8 = run candidate group g only
 };
 
 // costvol_lds.hip: LDS-staged generation (returns NRGBD_E_SHAPE when Cp/4 has no instantiation)

@@ -15,7 +15,7 @@
 //   homography maps the (convex) tile onto a convex quadrilateral — is copied HBM -> LDS one channel
 //   block at a time ([texel][9 x 16 B], stride 144 B), shared by as many of the 8 candidates as fit
 //   the 63 KB patch (far planes move the footprint by < 1 texel per candidate, so usually all 8).
-//   Candidates whose footprint does not fit even alone (extreme zoom) fall back to a direct gather.
+//   Candidates whose footprint does not fit even alone (zoom > ~1.1) fall back to a direct gather by all threads.
 // Two workgroups are resident per CU so one stages while the other computes.
 //
 // Arithmetic is identical to generation 1 (same helpers), so both satisfy the same parity tests.
@@ -33,16 +33,17 @@ constexpr int kPatchF4 = 4032;  // float4 slots of the source patch (63 KB)
 // block overlaps its predecessor instead of being short), so the LDS image of a block is the plain
 // linear array [texel][NS] whenever NS is odd — stride NS | 1 words = an odd number of 16-B words,
 // which spreads the 16 lanes of a ds_read_b128 lane group over 16 different bank quads.
+constexpr int kKB = 9;          // 16-byte words of a texel per channel block
 template <int CP4>
 struct LdsCfg {
-    static constexpr int NCB = (CP4 + 8) / 9;
-    static constexpr int NS = CP4 < 9 ? CP4 : 9;   // words staged per texel per block
+    static constexpr int NCB = (CP4 + kKB - 1) / kKB;
+    static constexpr int NS = CP4 < kKB ? CP4 : kKB;   // words staged per texel per block
     static constexpr int S4 = NS | 1;              // LDS texel stride in 16-B words (odd)
     static constexpr int PMAX = kPatchF4 / S4;     // texels that fit
     static constexpr int MAXIT = (kPatchF4 + 255) / 256;
-    static constexpr int w0(int cb) { return (cb * 9 < CP4 - NS) ? cb * 9 : CP4 - NS; }
-    static constexpr int first(int cb) { return cb * 9; }                                // first word computed
-    static constexpr int count(int cb) { return (CP4 - cb * 9 < 9) ? CP4 - cb * 9 : 9; }  // words computed
+    static constexpr int w0(int cb) { return (cb * kKB < CP4 - NS) ? cb * kKB : CP4 - NS; }
+    static constexpr int first(int cb) { return cb * kKB; }                                      // first word computed
+    static constexpr int count(int cb) { return (CP4 - cb * kKB < kKB) ? CP4 - cb * kKB : kKB; }  // words computed
 };
 
 template <int N, typename F>
@@ -54,10 +55,22 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // Direct-gather evaluation of one (pixel, candidate, view): sum_c dist(sample_c, ref_c) with 16-byte
-// loads straight from HBM/L2.  Last resort (a quarter-strip of the tile still overflows the patch).
+// loads straight from HBM/L2: the path of candidates whose tile footprint overflows the patch even alone.
 __device__ __noinline__ float gather_point(const float* __restrict__ sv, const float* __restrict__ refp,
                                            float ix, float iy, int w, int h, int Cp, int C, int dist) {
     const Bilinear b = bilinear_zeros(ix, iy, w, h);
+    const float4* rp0 = reinterpret_cast<const float4*>(refp);
+    if (b.nw == 0.f && b.ne == 0.f && b.sw == 0.f && b.se == 0.f) {   // all four taps out of view: distance to the zero vector
+        float acc0 = 0.f;
+        for (int i = 0; i < (Cp >> 2); ++i) {
+            const float4 rr = rp0[i];
+            const float s[4] = {0.f - rr.x, 0.f - rr.y, 0.f - rr.z, 0.f - rr.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * i + e < C) acc0 = (dist == NRGBD_DIST_L2) ? __builtin_fmaf(s[e], s[e], acc0) : acc0 + fabsf(s[e]);
+        }
+        return acc0;
+    }
     const float4* pnw = reinterpret_cast<const float4*>(sv + ((size_t)b.y0 * w + b.x0) * Cp);
     const float4* pne = reinterpret_cast<const float4*>(sv + ((size_t)b.y0 * w + b.x1) * Cp);
     const float4* psw = reinterpret_cast<const float4*>(sv + ((size_t)b.y1 * w + b.x0) * Cp);
@@ -128,15 +141,28 @@ __global__ __launch_bounds__(256, 2) void costvol_lds(const CostvolArgs a) {
 
     const int tid = threadIdx.x;
     const int tiles_x = (a.w + kTile - 1) / kTile;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    // Workgroup order.  The hardware deals workgroup ids round-robin to the 8 XCDs; the candidate groups of one tile
+    // stage almost the same source texels, so (order bit set, tile count divisible by 8) XCD k owns a contiguous eighth
+    // of the TILES and walks it group by group — nearest (most expensive) groups first, as in the plain order, but a
+    // tile's groups now run on one XCD within a few dozen workgroups of each other and share its L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((a.debug & 4) && (gridDim.x & 7) == 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = lin & 7, u = lin >> 3, tpx = gridDim.x >> 3;   // tiles per XCD
+        by = u / tpx;
+        bx = xcd * tpx + (u - by * tpx);
+    }
+    if ((a.debug >> 8) & 0xff) { if (by != ((a.debug >> 8) & 0xff) - 1) return; }   // developer: time one candidate group alone
+    const int tx = bx % tiles_x, ty = bx / tiles_x;
     // blockIdx.y -> candidate range.  On grids too small to fill the chip (tiles x D/8 < 4 workgroups per CU)
     // the first kSingles candidates — the nearest planes for an increasing d_candi: large, fast-moving
     // footprints that are staged one by one — get a workgroup each, so that this heavy serial work spreads
     // over idle CUs (config S: 264 -> 110 us).  On large grids the chip is throughput-bound and plain groups
     // of kKG share more staging.  A scheduling choice only: results do not depend on it.
     const int nsingle = a.nsingle;
-    const int k0 = ((int)blockIdx.y < nsingle) ? (int)blockIdx.y : nsingle + ((int)blockIdx.y - nsingle) * kKG;
-    const int nk = ((int)blockIdx.y < nsingle) ? 1 : min(kKG, a.D - k0);
+    const int k0 = (by < nsingle) ? by : nsingle + (by - nsingle) * kKG;
+    const int nk = (by < nsingle) ? 1 : min(kKG, a.D - k0);
+
     // Lane -> pixel map.  ds_read_b128 is serviced in four 16-lane groups {0-3,12-15,20-27},
     // {4-11,16-19,28-31}, {32-35,44-47,52-59}, {36-43,48-51,60-63} (MI355X_MICROARCH.md §LDS); each
     // group is given 16 consecutive pixels of ONE tile row, whose taps are (nearly) 16 consecutive
@@ -211,46 +237,18 @@ __global__ __launch_bounds__(256, 2) void costvol_lds(const CostvolArgs a) {
                 const long ar = (long)(xhi - xlo + 1) * (yhi - ylo + 1);
                 if (ar <= PMAX) { area = (int)ar; fits = true; break; }
             }
-            // A candidate whose whole-tile footprint overflows the patch (zoom > ~1.1: the nearest planes
-            // under forward motion) is processed region by region: the 4 wave-strips (16 x 4 pixels) of
-            // the tile, each strip split once more into halves if needed; only the pixels of the region
-            // do math, everybody stages.  A half-strip that still overflows (zoom > ~3) is gathered.
-            const bool split = !fits;
-            if (split) n = 1;
-            float dsplit = dk[0];
-            if (split) {
+            // A candidate whose whole-tile footprint overflows the patch even alone (zoom > ~1.1: the nearest planes
+            // under forward motion) is gathered straight from L2/HBM by all 256 threads; pixels whose four taps are
+            // all out of view (most of them on such planes) skip their loads.  Splitting the tile into strips and
+            // staging each strip's footprint was tried first: 1.5x slower on those candidates, the threads outside
+            // the strip idle through every stage.
+            if (!fits) {
 #pragma unroll
-                for (int j = 1; j < kKG; ++j) dsplit = (j == j0) ? dk[j] : dsplit;
+                for (int j = 0; j < kKG; ++j)
+                    if (j == j0) acc[j] += gather_point(sv, a.ref + p * a.Cp, ixs[j], iys[j], a.w, a.h, a.Cp, a.C, a.dist);
+                j0 += 1;
+                continue;
             }
-            for (int strip = 0; strip < (split ? 4 : 1); ++strip) {
-              bool strip_done = false;
-              for (int half = 0; half < 3 && !strip_done; ++half) {
-                bool active = true;
-                if (split) {
-                    const int ya = min(ty0 + 4 * strip, a.h - 1), yb = min(ty0 + 4 * strip + 3, a.h - 1);
-                    const int xa = min(tx0 + (half == 2 ? 8 : 0), a.w - 1), xb = min(tx0 + (half == 1 ? 7 : 15), a.w - 1);
-                    Box o;
-                    const int st_ = region_box(a, KRv, Ktv, dsplit, xa, xb, ya, yb, o);
-                    xlo = __builtin_amdgcn_readfirstlane(o.xlo); xhi = __builtin_amdgcn_readfirstlane(o.xhi);
-                    ylo = __builtin_amdgcn_readfirstlane(o.ylo); yhi = __builtin_amdgcn_readfirstlane(o.yhi);
-                    const long ar = (st_ == 0) ? 0 : (long)(xhi - xlo + 1) * (yhi - ylo + 1);
-                    active = ((tid >> 6) == strip) && (half == 0 || ((col >> 3) == half - 1));
-                    if (ar > PMAX) {
-                        if (half == 0) continue;  // try the two halves
-                        if (active) {
-#pragma unroll
-                            for (int j = 0; j < kKG; ++j)
-                                if (j == j0)
-                                    acc[j] += gather_point(sv, a.ref + p * a.Cp, ixs[j], iys[j], a.w, a.h, a.Cp, a.C, a.dist);
-                        }
-                        if (half == 2) strip_done = true;
-                        continue;
-                    }
-                    area = (int)ar;
-                    if (half == 0 || half == 2) strip_done = true;
-                } else {
-                    strip_done = true;
-                }
             const int cols = (area > 0) ? (xhi - xlo + 1) : 1;
             const unsigned magic = (cols > 1) ? (0xFFFFFFFFu / (unsigned)cols + 1u) : 0u;
 
@@ -294,7 +292,6 @@ __global__ __launch_bounds__(256, 2) void costvol_lds(const CostvolArgs a) {
 #pragma unroll
                 for (int j = 0; j < kKG; ++j) {
                     if (j < j0 || j >= j0 + n || (a.debug & 2)) continue;  // uniform
-                    if (!active) continue;                                 // pixels outside the region
                     float part = 0.f;
                     if (area > 0) {
                         float ix = ixs[j], iy = iys[j];
@@ -390,8 +387,6 @@ __global__ __launch_bounds__(256, 2) void costvol_lds(const CostvolArgs a) {
                 }
                 __syncthreads();
             });
-              }  // half
-            }      // strip
             j0 += n;
         }
 #pragma unroll
@@ -417,7 +412,7 @@ bool costvol_lds_supported(int cp4) {
 int launch_costvol_lds(const CostvolArgs& args, hipStream_t stream) {
     CostvolArgs a = args;
     const int tiles = ceil_div(a.w, kTile) * ceil_div(a.h, kTile);
-    const bool singles = (long)tiles * ceil_div(a.D, kKG) < 4 * 256;  // under-filled chip
+    const bool singles = (long)tiles * ceil_div(a.D, kKG) < 4 * 256 || (a.debug & 8);  // under-filled chip
     const int nsingle = singles ? (a.D < kSingles ? a.D : kSingles) : 0;
     a.nsingle = nsingle;
     const dim3 grid(tiles, nsingle + ceil_div(a.D - nsingle, kKG));
