@@ -44,10 +44,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (256 CUs x 256 FLOP/clk x 2.4 GHz)
 # HBM bytes per launch of the fused warp + cost-volume kernel at config B from the L2's fabric-side counters
 # (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes: tools/pmc_costvol.sh, summary in
-# profiles/r1_pmc_summary.txt): FETCH_SIZE 561,502 KB, doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950
+# profiles/r1_pmc_summary.txt, round-1 final kernel): FETCH_SIZE 665,420 KB, doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950
 # (calibrated in this access pattern on logsoftmax_d: 6,283 KB reported for the 12,583 KB it reads), WRITE_SIZE
 # 12,288 KB (= the cost volume exactly).  Counters cannot be read from inside this process, hence a constant.
-PMC_TRAFFIC_BYTES = {"B": 2 * 561502 * 1024 + 12288 * 1024}
+PMC_TRAFFIC_BYTES = {"B": 2 * 665420 * 1024 + 12288 * 1024}
 
 
 def costvol_bytes(V, C, D, h, w):
