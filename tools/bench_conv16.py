@@ -1,3 +1,4 @@
+"""Timing of the K-Net 16->64 first layer (conv3d_mfma<16>) at the config-B grid."""
 import torch, sys
 sys.path.insert(0,'.')
 from neuralrgbd_amd import ops

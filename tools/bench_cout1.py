@@ -1,3 +1,4 @@
+"""Timing of the K-Net 64->1 layer (conv3d_cout1: tap-projection GEMM + LDS tap sum) at the config-B grid."""
 import torch, sys
 sys.path.insert(0,'.')
 from neuralrgbd_amd import ops
