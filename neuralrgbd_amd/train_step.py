@@ -64,3 +64,59 @@ def train(nGPU, model_KV, optimizer_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, Sr
         dmap_kv_lowres = depth_val_regression(kv, d_candi, BV_log=True)
         dmap_kv_highres = depth_val_regression(dmap_refined.detach(), d_candi, BV_log=True)
     return r_dpv, BVs_predict_out, loss.detach(), dmap_kv_lowres, dmap_kv_highres
+
+
+class TrainGraph:
+    """The update-branch training iteration (forward under autograd, 4 NLL terms, backward, Adam, PREDICT) captured once
+    into a hipGraph and replayed: one training step launches ~1,300 kernels, and launched from Python the host, not the
+    GPU, sets the pace (tools/bench_train.py: 62 ms eager vs 58 ms of kernels).
+
+    Single-GPU form (the gradient all-reduce of a multi-GPU run stays outside a graph).  The optimizer must be built
+    with `capturable=True`.  Inputs are copied into static buffers; the pose inverse for PREDICT is computed outside
+    the graph (the solver may allocate).  `step()` returns (loss, BV_predict for the next window) as static tensors.
+    """
+
+    def __init__(self, model, optimizer, t_win_r, d_candi, cam_intrinsics):
+        self.model, self.opt, self.t_win_r, self.d_candi, self.cam = model, optimizer, t_win_r, d_candi, cam_intrinsics
+        self._graph = None
+        self._st = None
+
+    def _iteration(self, st):
+        model = self.model
+        r_cur, r_kv, d_dpv, kv_dpv = model(ref_frame=st["ref"], src_frames=st["src"], src_cam_poses=st["poses"],
+                                           BatchIdx=torch.zeros(1), cam_intrinsics=[self.cam], BV_predict=st["bv"],
+                                           dpv_valid=True)
+        loss = F.nll_loss(d_dpv, st["dmap"], ignore_index=0) + F.nll_loss(r_cur, st["dmap_full"], ignore_index=0) \
+            + F.nll_loss(kv_dpv, st["dmap"], ignore_index=0) + F.nll_loss(r_kv, st["dmap_full"], ignore_index=0)
+        loss.backward()
+        self.opt.step()
+        with torch.no_grad():
+            nxt = warp_homo.resample_vol_cuda(src_vol=kv_dpv.detach(), rel_extM=st["inv"], cam_intrinsic=self.cam,
+                                              d_candi=self.d_candi, padding_value=math.log(1. / float(len(self.d_candi))),
+                                              clamp=(-1000., 0.)).unsqueeze(0)
+        return loss.detach(), nxt
+
+    def step(self, ref_frame, src_frames, poses, dmap, dmap_full, bv_predict):
+        inv = torch.linalg.inv(poses[0, self.t_win_r])
+        if self._graph is None:
+            st = {"ref": ref_frame.clone(), "src": src_frames.clone(), "poses": poses.clone(), "dmap": dmap.clone(),
+                  "dmap_full": dmap_full.clone(), "bv": bv_predict.clone(), "inv": inv.clone()}
+            # per-trajectory constants (intrinsics, ray table, d_candi) are uploaded once and cached per dict: do it now,
+            # an upload inside the capture is not allowed
+            dev = ref_frame.device
+            for cam in (self.cam, getattr(self.model.d_net, "cam_intrinsics", self.cam)):
+                warp_homo._cam_dev(cam, dev)
+            for dc in (self.d_candi, getattr(self.model.d_net, "d_candi", self.d_candi), getattr(self.model, "d_candi", self.d_candi)):
+                warp_homo._d_candi_dev(dc, dev)
+            self.opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["out"] = self._iteration(st)      # gradients are allocated in the graph's pool and rewritten per replay
+            self._graph, self._st = g, st
+            # capture does not execute: fall through to the first replay with the same inputs
+        st = self._st
+        st["ref"].copy_(ref_frame); st["src"].copy_(src_frames); st["poses"].copy_(poses)
+        st["dmap"].copy_(dmap); st["dmap_full"].copy_(dmap_full); st["bv"].copy_(bv_predict); st["inv"].copy_(inv)
+        self._graph.replay()
+        return st["out"]

@@ -144,3 +144,48 @@ def test_knet_training_path_vs_fp64_autograd():
     assert w_mine < 1e-4
     for (n1, b1), (n2, b2) in zip(mine.named_buffers(), gold_net.named_buffers()):
         assert torch.allclose(b1.float().cpu(), b2.float(), rtol=1e-4, atol=1e-5), n1   # running statistics
+
+
+def test_graph_captured_iteration_equals_eager_iteration():
+    """train_step.TrainGraph (the iteration replayed as one hipGraph) against train() on an identical twin: same loss,
+    same predicted state, same updated weights (tolerance: the vendor library may pick other algorithms under capture)."""
+    import copy
+    import neuralrgbd_amd
+    from neuralrgbd_amd.train_step import TrainGraph, train
+    H, W, D = 256, 256, 8
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(0.1, 5, D)
+    model = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    model.load_state_dict(synth.seeded_state_dict(model, 0))
+    model = model.to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(.9, .999), capturable=True)
+    rng = np.random.RandomState(1)
+
+    def window(i):
+        r, s, p = synth.noise_window(70 + i, H, W)
+        return (r, s, p, torch.from_numpy(rng.randint(0, D, (1, H // 4, W // 4))), torch.from_numpy(rng.randint(0, D, (1, H, W))))
+
+    pred = None
+    for i in range(2):   # first frame + one update frame, eagerly: filter state, optimizer state, vendor find-mode
+        r, s, p, dm, dmf = window(i)
+        _, pred, _, _, _ = train(1, model, opt, 2, d_candi, [{"img": r, "dmap": dm, "dmap_imgsize_digit": dmf}],
+                                 [[{"img": s[0, v:v + 1]} for v in range(4)]], p, pred, [cam])
+    twin = copy.deepcopy(model)
+    opt2 = torch.optim.Adam(twin.parameters(), lr=1e-4, betas=(.9, .999), capturable=True)
+    opt2.load_state_dict(copy.deepcopy(opt.state_dict()))
+    r, s, p, dm, dmf = window(2)
+    _, pred_e, loss_e, _, _ = train(1, model, opt, 2, d_candi, [{"img": r, "dmap": dm, "dmap_imgsize_digit": dmf}],
+                                    [[{"img": s[0, v:v + 1]} for v in range(4)]], p, pred, [cam])
+    tg = TrainGraph(twin, opt2, 2, d_candi, cam)
+    loss_g, pred_g = tg.step(r.to(DEV), s.to(DEV), p.to(DEV), dm.to(DEV), dmf.to(DEV), pred)
+    torch.cuda.synchronize()
+    print("[parity] train graph vs eager: loss %.6f vs %.6f, max|d BV_predict|=%.2e" %
+          (float(loss_g), float(loss_e), (pred_g - pred_e).abs().max().item()))
+    assert abs(float(loss_g) - float(loss_e)) < 1e-3 * abs(float(loss_e))
+    assert (pred_g - pred_e).abs().mean().item() < 1e-3
+    wa, wb = model.kv_net.dres1[0][0].weight, twin.kv_net.dres1[0][0].weight
+    assert (wa - wb).abs().max().item() < 5e-4        # lr 1e-4 Adam steps: identical direction, same magnitude
+    # a second replay keeps working on new inputs
+    r, s, p, dm, dmf = window(3)
+    loss2, pred2 = tg.step(r.to(DEV), s.to(DEV), p.to(DEV), dm.to(DEV), dmf.to(DEV), pred_g.clone())
+    assert bool(torch.isfinite(loss2)) and bool(torch.isfinite(pred2).all())
