@@ -14,6 +14,13 @@ CPU under the installed torch.  Outputs (small, committed):
                    synth.seeded_state_dict — a checksum of both is stored)
   scene_small.npz  D-Net on a rendered textured scene (true cost minimum), BV_cur + argmax
   state_keys.json  the 459 state-dict keys and shapes of the reference KVNET
+  ops_c67.npz      est_swp_volume_v4 at the REAL channel count and candidate count of the path (C=67, D=64, V=4,
+                   48x64 grid = 12 tiles of the sampling kernel; inputs regenerated from the seed, cost stored at
+                   every second pixel + the full-resolution arg-min)
+  net_fp64.npz     the NET case evaluated in float64 (oracle/fp64_ref.py) at every second pixel, plus the measured
+                   |reference - fp64| of the reference's own fp32 outputs: the yardstick for "DPV within 1e-4"
+
+    python -m oracle.gen_golden [ops net scene ops67 fp64]      (default: all)
 """
 import json
 import math
@@ -33,6 +40,17 @@ OUT = os.path.join(ROOT, "tests", "golden")
 NET = dict(H=256, W=320, D=16, seeds=(3, 4), sigma=10.0, d_min=0.1, d_max=5.0, weight_seed=0)
 OPS = dict(h=24, w=40, D=16, V=4, C=11, seed=1, sigma=10.0)
 SCENE = dict(H=256, W=320, D=32, seed=11, sigma=10.0)
+OPS67 = dict(h=48, w=64, D=64, V=4, C=67, seed=5, sigma=10.0, d_min=0.1, d_max=5.0)
+
+
+def ops67_inputs():
+    """Seeded inputs of the C=67 fixture (shared by the generator and the tests)."""
+    o = OPS67
+    rng = np.random.RandomState(o["seed"])
+    feat_ref = rng.standard_normal((1, o["C"], o["h"], o["w"])).astype(np.float32)
+    feat_src = rng.standard_normal((1, o["V"], o["C"], o["h"], o["w"])).astype(np.float32)
+    poses = synth.random_poses(rng, o["V"])
+    return feat_ref, feat_src, poses, np.linspace(o["d_min"], o["d_max"], o["D"])
 
 
 def checksum(tensors):
@@ -129,15 +147,54 @@ def gen_scene(ref):
     print("scene_small: median |depth err| of the D-Net argmax", float(np.median(np.abs(est - depth[2::4, 2::4]))))
 
 
+def gen_ops67(ref):
+    o = OPS67
+    feat_ref, feat_src, poses, d_candi = ops67_inputs()
+    cam = camera.scannet_intrinsics(o["w"], o["h"])
+    poses = torch.from_numpy(poses)
+    R, t = poses[:, :3, :3].contiguous(), poses[:, :3, 3].contiguous()
+    cost = ref.homography.est_swp_volume_v4(torch.from_numpy(feat_ref), torch.from_numpy(feat_src), d_candi, R, t, cam,
+                                            o["sigma"])[0].numpy()
+    np.savez(os.path.join(OUT, "ops_c67.npz"), cost_sub=cost[:, ::2, ::2], argmin=cost.argmin(0).astype(np.uint8),
+             cost_sum=float(cost.astype(np.float64).sum()),
+             inputs_checksum=checksum([torch.from_numpy(feat_ref), torch.from_numpy(feat_src), poses]))
+    print("ops_c67: cost range", float(cost.min()), float(cost.max()))
+
+
+def gen_fp64(ref):
+    """The NET case in float64 + how far the reference's own fp32 outputs (net_small.npz) are from it."""
+    from oracle import fp64_ref
+    n = NET
+    H, W, D = n["H"], n["W"], n["D"]
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(n["d_min"], n["d_max"], D)
+    with ref_shim.quiet():
+        model = ref.KVNET.KVNET(64, cam, d_candi, n["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    sd = synth.seeded_state_dict(model, n["weight_seed"])
+    w1, w2 = (synth.noise_window(s, H, W) for s in n["seeds"])
+    o1 = fp64_ref.step(sd, *w1, cam, d_candi, n["sigma"], None)
+    o2 = fp64_ref.step(sd, *w2, cam, d_candi, n["sigma"], o1[3])
+    g = dict(np.load(os.path.join(OUT, "net_small.npz")))
+    out = {}
+    for key, t64 in (("bv_cur_f1", o1[2]), ("pred_f1", o1[3]), ("dpv_f2", o2[1]), ("pred_f2", o2[3])):
+        a = t64[0].numpy()
+        e = np.abs(g[key].astype(np.float64) - a)
+        out[key] = a[:, ::2, ::2]
+        out["ref_err_max_" + key] = e.max()
+        out["ref_err_mean_" + key] = e.mean()
+        print("fp64: reference %-10s |ref - fp64| max %.3e mean %.3e" % (key, e.max(), e.mean()))
+    np.savez(os.path.join(OUT, "net_fp64.npz"), **out)
+
+
 def main():
     if not ref_shim.available():
         raise SystemExit("reference not present: golden vectors can only be generated in the build container")
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shim.load()
     torch.manual_seed(0)
-    gen_ops(ref)
-    gen_net(ref)
-    gen_scene(ref)
+    which = sys.argv[1:] or ["ops", "net", "scene", "ops67", "fp64"]
+    for name in which:
+        {"ops": gen_ops, "net": gen_net, "scene": gen_scene, "ops67": gen_ops67, "fp64": gen_fp64}[name](ref)
 
 
 if __name__ == "__main__":

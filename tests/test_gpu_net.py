@@ -49,15 +49,16 @@ def test_two_frame_stream_vs_golden(golden_net, monkeypatch, cnn):
                             ("DPV f2", dpv2, g["dpv_f2"]), ("BV_predict f2", p2, g["pred_f2"])):
         got = got[0].cpu().numpy()
         res[name] = report("GPU path " + name + " vs reference", got, want) + (near_tie_mismatches(got, want, 1e-3),)
-    # D-Net output (convolutions by the vendor library + our fused warp/cost/log-softmax)
-    assert res["BV_cur f1"][0] < 2e-3 and res["BV_cur f1"][1] < 1e-4 and res["BV_cur f1"][3] == 0
-    assert res["BV_predict f1"][1] < 1e-4
-    # after the 12-layer K-Net (values down to -50) conv summation order dominates: L1 is the contract
-    assert res["DPV f2"][1] < 1e-3 and res["DPV f2"][3] == 0
-    assert res["BV_predict f2"][1] < 1e-3
+    # the contract (BASELINE.json): L1 < 1e-4 on every volume, arg-max depth index identical (res[.][2] = raw
+    # mismatch count, no near-tie allowance); max-abs is printed — tests/test_gpu_parity_configs.py::test_fp64_yardstick
+    # shows the reference's own output is ~2e-3 max away from exact arithmetic after the K-Net
+    for name in res:
+        assert res[name][1] < 1e-4, (name, res[name])
+        assert res[name][2] == 0, (name, res[name])
+    assert res["BV_cur f1"][0] < 2e-3
     sub = refined[0, :, ::4, ::4].cpu().numpy()
-    report("GPU path R(DPV) f2 vs reference", sub, g["refined_f2_sub"])
-    assert np.abs(sub - g["refined_f2_sub"]).mean() < 1e-3
+    _, r_mean, r_mism = report("GPU path R(DPV) f2 vs reference", sub, g["refined_f2_sub"])
+    assert r_mean < 1e-4 and r_mism == 0
 
 
 def test_update_frame_vs_cpu_oracle_config_S_small(monkeypatch):
@@ -74,8 +75,8 @@ def test_update_frame_vs_cpu_oracle_config_S_small(monkeypatch):
     a = report("GPU vs oracle BV_cur", bv1[0].cpu().numpy(), o1[2][0].numpy())
     b = report("GPU vs oracle DPV", dpv2[0].cpu().numpy(), o2[1][0].numpy())
     c = report("GPU vs oracle BV_predict", p2[0].cpu().numpy(), o2[3][0].numpy())
-    assert a[1] < 1e-4 and b[1] < 1e-3 and c[1] < 1e-3
-    assert near_tie_mismatches(dpv2[0].cpu().numpy(), o2[1][0].numpy(), 1e-3) == 0
+    assert a[1] < 1e-4 and b[1] < 1e-4 and c[1] < 1e-4
+    assert a[2] == 0 and b[2] == 0 and c[2] == 0
 
 
 @pytest.mark.parametrize("cnn", ["mfma", "vendor"])
@@ -91,7 +92,7 @@ def test_rendered_scene_vs_golden(golden_scene, monkeypatch, cnn):
         bv, _ = model.d_net(r.cuda(), sr.cuda(), p.cuda())
     got = bv[0].cpu().numpy()
     mx, mean, mism = report("GPU D-Net on rendered scene vs reference", got, g["bv_cur"])
-    assert mean < 1e-4 and near_tie_mismatches(got, g["bv_cur"], 1e-3) == 0
+    assert mean < 1e-4 and mism == 0
 
 
 def test_first_frame_and_invalid_state_fallbacks():

@@ -95,3 +95,44 @@ def test_rendered_scene(golden_scene):
         bv, _, _ = ko.dnet(sd, r, sr, p, cam, d_candi, s["sigma"])
     mx, mean, mism = report("oracle scene BV_cur", bv[0].numpy(), g["bv_cur"])
     assert mx < 5e-4 and mean < 1e-4 and mism == 0
+
+
+def test_costvol_c67_d64_vs_reference():
+    """The C oracle at the path's real channel / candidate count (C=67, D=64, V=4) against the reference's output."""
+    import os
+    from conftest import GOLDEN
+    o = gen_golden.OPS67
+    g = dict(np.load(os.path.join(GOLDEN, "ops_c67.npz")))
+    feat_ref, feat_src, poses, d_candi = gen_golden.ops67_inputs()
+    assert abs(gen_golden.checksum([torch.from_numpy(feat_ref), torch.from_numpy(feat_src), torch.from_numpy(poses)])
+               - float(g["inputs_checksum"])) < 1e-6 * float(g["inputs_checksum"])
+    cam = camera.scannet_intrinsics(o["w"], o["h"])
+    KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+    got = co.costvol(feat_ref[0], feat_src[0], KR, Kt, cam["unit_ray_array_2D"].numpy(), d_candi,
+                     cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2], o["sigma"])
+    mx, mean, _ = report("oracle costvol C=67 D=64", -got[:, ::2, ::2], -g["cost_sub"])
+    assert mx < 1e-4 and mean < 1e-5          # costs up to 62
+    assert (got.argmin(0) != g["argmin"]).sum() == 0
+
+
+def test_fp64_yardstick_is_the_same_graph(golden_net):
+    """oracle/fp64_ref.py evaluated in float32 must reproduce the reference (it is the same formulas); the stored
+    float64 results are then a yardstick for rounding noise, not a different algorithm."""
+    import os
+    from conftest import GOLDEN
+    from oracle import fp64_ref
+    n, g = gen_golden.NET, golden_net
+    cam, d_candi, sd = _net_setup(n)
+    w1 = synth.noise_window(n["seeds"][0], n["H"], n["W"])
+    old = fp64_ref.F64
+    try:
+        fp64_ref.F64 = torch.float32
+        o32 = fp64_ref.step(sd, *w1, cam, d_candi, n["sigma"], None)
+    finally:
+        fp64_ref.F64 = old
+    assert np.abs(o32[2][0].numpy() - g["bv_cur_f1"]).max() < 1e-5
+    o64 = fp64_ref.step(sd, *w1, cam, d_candi, n["sigma"], None)
+    g64 = dict(np.load(os.path.join(GOLDEN, "net_fp64.npz")))
+    assert np.abs(o64[2][0].numpy()[:, ::2, ::2] - g64["bv_cur_f1"]).max() < 1e-9
+    # the reference's own fp32 output sits ~1e-3 (max) from exact arithmetic already at the D-Net output
+    assert 1e-4 < float(g64["ref_err_max_dpv_f2"]) < 1e-2
