@@ -47,6 +47,20 @@ const char* nrgbd_version(void);
 const char* nrgbd_strerror(int code);
 
 /*
+ * nrgbd_homography_terms — the per-view constants of the plane sweep.
+ * Replaces: warping/homography.py:315-317 (term1 = IntM.matmul(t_v); left factor IntM.matmul(R_v) of term2), also
+ * :250-253 / :203-206 of the K-Net warps.  Summation order = the reference's CPU execution (fma chain for K R_v,
+ * (p1 + p2) + p0 for K t_v) so that sampling coordinates agree with it bit for bit.
+ *   K  [3][3]                 intrinsics at grid resolution
+ *   R  element (v,i,j) at R[v*r_view_stride + i*r_row_stride + j]   (e.g. poses[:, :3, :3]: 16, 4)
+ *   t  element (v,i)   at t[v*t_view_stride + i*t_elem_stride]      (e.g. poses[:, :3, 3]:  16, 4)
+ *   KR [V][9], Kt [V][3]      outputs
+ */
+int nrgbd_homography_terms(const float* K, const float* R, long r_view_stride, long r_row_stride,
+                           const float* t, long t_view_stride, long t_elem_stride, float* KR, float* Kt,
+                           int V, void* stream);
+
+/*
  * nrgbd_pack_nhwc — feature packing for the sampling kernels.
  * Replaces: models/basic.py:254-263 (F.avg_pool2d of the RGB frames + torch.cat onto the
  * CNN features) and the implicit NCHW layout handed to homography.py:293.

@@ -19,6 +19,7 @@ _L = _c.c_long
 SIGNATURES = {
     "nrgbd_version": (_c.c_char_p, []),
     "nrgbd_strerror": (_c.c_char_p, [_I]),
+    "nrgbd_homography_terms": (_I, [_P, _P, _L, _L, _P, _L, _L, _P, _P, _I, _P]),
     "nrgbd_pack_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_costvol_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P,
                                _I, _I, _I, _I, _I, _I, _P]),

@@ -22,17 +22,45 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+OBJ = os.path.join(CSRC, "_obj")
+
+
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+
+
 def stale():
     if not os.path.isfile(LIB):
         return True
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    deps = sources() + _headers()
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
+def _compile(src, verbose):
+    """One translation unit -> object file (only when the source or any header is newer)."""
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    newest = max(os.path.getmtime(d) for d in [src] + _headers())
+    if os.path.isfile(obj) and os.path.getmtime(obj) >= newest:
+        return obj
+    cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", "-I", INCLUDE, src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return obj
+
+
 def build(force=False, verbose=False):
+    """Per-file objects (compiled in parallel, re-used when unchanged) linked into libnrgbd_hip.so."""
     if not force and not stale():
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-I", INCLUDE] + sources() + ["-o", LIB + ".tmp"]
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in glob.glob(os.path.join(OBJ, "*.o")):
+            os.remove(f)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(lambda s_: _compile(s_, verbose), sources()))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -52,9 +52,7 @@ def clear_cache():
 
 def homography_terms(K, R, t):
     """term1 = K t_v and the left factor K R_v of term2 (homography.py:315-317), batched: [V,3], [V,3,3]."""
-    KR = torch.matmul(K.unsqueeze(0), R)
-    Kt = torch.matmul(t, K.transpose(0, 1))
-    return KR.contiguous(), Kt.contiguous()
+    return ops.homography_terms(K, R, t)
 
 
 def _stack(x):

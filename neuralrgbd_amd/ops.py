@@ -42,6 +42,26 @@ def padded_channels(C):
     return (C + 3) // 4 * 4
 
 
+def homography_terms(K, R, t):
+    """K [3,3], R [V,3,3] (any strides with unit column stride), t [V,3] (any strides) -> (KR [V,3,3], Kt [V,3])
+    in the reference's CPU summation order (nrgbd_homography_terms)."""
+    K = _need(K, "K", (3, 3))
+    R = _need(R, "R", strided=True)
+    t = _need(t, "t", strided=True)
+    V = R.shape[0]
+    if tuple(R.shape) != (V, 3, 3) or tuple(t.shape) != (V, 3):
+        raise ValueError("homography_terms: R %s / t %s, expected [V,3,3] / [V,3]" % (tuple(R.shape), tuple(t.shape)))
+    if R.stride(2) != 1:
+        R = R.contiguous()
+    KR = torch.empty((V, 3, 3), dtype=torch.float32, device=K.device)
+    Kt = torch.empty((V, 3), dtype=torch.float32, device=K.device)
+    with torch.cuda.device(K.device):
+        rc = _lib.load().nrgbd_homography_terms(_p(K), _p(R), R.stride(0), R.stride(1), _p(t), t.stride(0), t.stride(1),
+                                                _p(KR), _p(Kt), V, _stream(K))
+    _lib.check(rc, "nrgbd_homography_terms")
+    return KR, Kt
+
+
 def pack_nhwc(feat, rgb=None, Cp=None, channels_last=False):
     """feat [N,Cf,h,w] (or [N,h,w,Cf] if channels_last) (+ rgb [N,3,h*pool,w*pool]) -> texels [N,h,w,Cp] (nrgbd_pack_nhwc)."""
     feat = _need(feat, "feat")

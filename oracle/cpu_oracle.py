@@ -44,12 +44,14 @@ def set_threads(n):
 
 
 def homography_terms(K, R, t):
-    """(K R_v) and K t_v in fp32, as the reference's two torch.matmul (homography.py:315-317)."""
-    K = np.asarray(K, np.float32)
-    R = np.asarray(R, np.float32).reshape(-1, 3, 3)
-    t = np.asarray(t, np.float32).reshape(-1, 3)
-    KR = np.stack([K @ R[v] for v in range(R.shape[0])]).astype(np.float32)
-    Kt = np.stack([K @ t[v] for v in range(R.shape[0])]).astype(np.float32)
+    """(K R_v) and K t_v exactly as the reference computes them on CPU: torch `IntM.matmul(R[v])` and
+    `IntM.matmul(t[v])` (homography.py:315-317) — the summation order of these K=3 contractions is torch's."""
+    import torch
+    K = torch.from_numpy(np.ascontiguousarray(K, dtype=np.float32))
+    R = torch.from_numpy(np.ascontiguousarray(np.asarray(R, np.float32).reshape(-1, 3, 3)))
+    t = torch.from_numpy(np.ascontiguousarray(np.asarray(t, np.float32).reshape(-1, 3)))
+    KR = torch.stack([K.matmul(R[v]) for v in range(R.shape[0])]).numpy()
+    Kt = torch.stack([K.matmul(t[v]) for v in range(R.shape[0])]).numpy()
     return KR.reshape(-1, 9), Kt
 
 

@@ -308,3 +308,16 @@ def test_operator_surface_matches_reference_signatures(golden_ops):
     assert np.array_equal(pred.cpu().numpy(), g["pred"])
     with pytest.raises(Exception):
         Hm.est_swp_volume_v4(_dev(g["feat_ref"])[None], _dev(g["feat_src"])[None], g["d_candi"], R, t, cam, 1.0, feat_dist="cosine")
+
+
+def test_homography_terms_match_torch_cpu():
+    """nrgbd_homography_terms reproduces the reference's CPU matmuls bit for bit, on strided views of a pose tensor."""
+    from neuralrgbd_amd import ops
+    rng = np.random.RandomState(3)
+    cam = camera.scannet_intrinsics(96, 64)
+    K = cam["intrinsic_M_cuda"]
+    poses = torch.from_numpy(synth.random_poses(rng, 5))
+    KR, Kt = ops.homography_terms(K.cuda(), poses.cuda()[:, :3, :3], poses.cuda()[:, :3, 3])
+    want_KR = torch.stack([K.matmul(poses[v, :3, :3]) for v in range(5)])
+    want_Kt = torch.stack([K.matmul(poses[v, :3, 3]) for v in range(5)])
+    assert torch.equal(KR.cpu(), want_KR) and torch.equal(Kt.cpu(), want_Kt)
