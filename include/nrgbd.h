@@ -99,6 +99,17 @@ int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc,
                       float* out_cost, float* out_logp,
                       int V, int C, int Cp, int D, int h, int w, void* stream);
 
+/* The same operation with the kernel generation chosen by the caller (tests and A/B measurements):
+ * 0 = automatic (what nrgbd_costvol_fwd does), 1 = direct gather (any shape), 2 = LDS-staged, lane = pixel (Cp/4 in
+ * {1,2,3,4,8,9,16,17}), 3 = quad: 4 lanes per (pixel, candidate) (Cp = 68 with C > 64, or Cp = C = 64; V <= 8).
+ * A generation that does not support the shape returns NRGBD_E_SHAPE; nothing is substituted silently. */
+int nrgbd_costvol_fwd_gen(const float* ref_nhwc, const float* src_nhwc,
+                      const float* KR, const float* Kt, const float* rays,
+                      const float* d_candi, float cx, float cy, float sigma,
+                      int dist, int align_corners,
+                      float* out_cost, float* out_logp,
+                      int V, int C, int Cp, int D, int h, int w, int generation, void* stream);
+
 /*
  * nrgbd_costvol_bwd — backward of nrgbd_costvol_fwd with respect to the packed features (training).
  * Replaces: what autograd records for warping/homography.py:293-331 (grid_sample backward scatter-add,

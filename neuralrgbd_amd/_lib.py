@@ -23,6 +23,8 @@ SIGNATURES = {
     "nrgbd_pack_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_costvol_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P,
                                _I, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_costvol_fwd_gen": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P,
+                                   _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_costvol_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P, _P,
                                _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_warp_volume": (_I, [_P, _L, _L, _L, _L, _P, _L, _L, _L, _P, _P, _P, _P, _F, _F, _I,

@@ -19,7 +19,23 @@
         if (e__ != hipSuccess) return (int)e__;      \
     } while (0)
 
+#ifdef NRGBD_DEV
+#include <cstdlib>
+#endif
+
 namespace nrgbd {
+
+// Developer switches (tile order experiments, prefetch ablations) exist only in -DNRGBD_DEV builds: the product library
+// never reads the environment, so a stray variable cannot change what it computes.
+inline int dev_env_int(const char* name) {
+#ifdef NRGBD_DEV
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}
 
 constexpr int kWave = 64;  // gfx950 wavefront
 

@@ -388,7 +388,7 @@ extern "C" int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_rel
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB) return NRGBD_E_SHAPE;
     if ((long)N * H * W * Cin >= (1L << 32)) return NRGBD_E_SHAPE;  // 32-bit element offsets in the loader
     Conv2dArgs a{x, x_ss, res, res_ss, materialized, w_packed, bias, y, stats, x_relu, res_relu, out_lrelu, N, H, W, Cin,
-                 getenv("NRGBD_XCD") ? atoi(getenv("NRGBD_XCD")) : 0};
+                 dev_env_int("NRGBD_XCD")};
     const int nwg = ceil_div(W, kT2) * ceil_div(H, kT2) * N;
     hipStream_t st = (hipStream_t)stream;
     if (dilation == 1 && Cout == 32) launch_conv2d<32, 1>(a, nwg, st);

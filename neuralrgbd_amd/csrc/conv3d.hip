@@ -531,16 +531,16 @@ extern "C" int nrgbd_conv3d_3x3x3_f32(const float* x, const float* x_ss, int x_r
     if (!x || !w_packed || !y) return NRGBD_E_NULL;
     if (D <= 0 || H <= 0 || W <= 0) return NRGBD_E_SHAPE;
     if (Cout != kCout || (Cin != 16 && Cin != 64)) return NRGBD_E_SHAPE;
-    Conv3dArgs a{x, x_ss, res, res_ss, materialized, w_packed, y, stats, x_relu, res_relu, D, H, W, getenv("NRGBD_XCD") ? atoi(getenv("NRGBD_XCD")) : 0};
+    Conv3dArgs a{x, x_ss, res, res_ss, materialized, w_packed, y, stats, x_relu, res_relu, D, H, W, dev_env_int("NRGBD_XCD")};
     const int nwg = ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
     const size_t lds = (size_t)kHaloVox * kSV * sizeof(float);  // 46,080 B (>= the 2 KB the statistics reuse)
-    const bool prefetch = (Cin == 64) && ((long)D * H * W * Cin < (1L << 32)) && !getenv("NRGBD_CONV3D_NOPF");
+    const bool prefetch = (Cin == 64) && ((long)D * H * W * Cin < (1L << 32)) && !dev_env_int("NRGBD_CONV3D_NOPF");
     const bool small = (long)D * H * W * Cin < (1L << 32);
     if (Cin == 16 && small && !res)   // single channel block: batched unconditional loads only
         hipLaunchKernelGGL((conv3d_mfma_kernel<16, true>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     else if (Cin == 16)
         hipLaunchKernelGGL((conv3d_mfma_kernel<16, false>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
-    else if (prefetch && res && !getenv("NRGBD_CONV3D_NOPFRES"))
+    else if (prefetch && res && !dev_env_int("NRGBD_CONV3D_NOPFRES"))
         hipLaunchKernelGGL((conv3d_mfma_kernel<64, true, true>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     else if (prefetch && !res)
         hipLaunchKernelGGL((conv3d_mfma_kernel<64, true>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
@@ -556,16 +556,17 @@ extern "C" int nrgbd_conv3d_3x3x3_cout1_f32(const float* x, const float* x_ss, i
     using namespace nrgbd;
     if (!x || !w_tap_major || !y) return NRGBD_E_NULL;
     if (D <= 0 || H <= 0 || W <= 0 || Cin != 64) return NRGBD_E_SHAPE;
-    Conv3dArgs a{x, x_ss, res, res_ss, nullptr, nullptr, y, nullptr, x_relu, res_relu, D, H, W, getenv("NRGBD_XCD") ? atoi(getenv("NRGBD_XCD")) : 0};
+    // the tap-projection kernel has no residual operand (the reference's classify branch has none, basic.py:92-94):
+    // refuse one instead of silently ignoring it
+    if (res || res_ss || res_relu) return NRGBD_E_ARG;
+    Conv3dArgs a{x, x_ss, res, res_ss, nullptr, nullptr, y, nullptr, x_relu, res_relu, D, H, W, dev_env_int("NRGBD_XCD")};
     const int nwg = ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
     const size_t lds = (size_t)kHaloVox * 27 * sizeof(float);  // P [720][27] (77.8 KB) over the 46 KB staging buffer
-    static bool attr_set[64] = {};   // > 64 KB of dynamic LDS needs the opt-in, once per device
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_cout1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[dev] = true;
-    }
+    // > 64 KB of dynamic LDS needs the opt-in; it is idempotent and costs ~1 us, so it is simply repeated per call
+    // (no process-global flag: re-entrant from any thread on any device)
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_cout1_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return (int)ea;
     hipLaunchKernelGGL(conv3d_cout1_kernel, dim3(nwg), dim3(256), lds, (hipStream_t)stream, a, w_tap_major);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;

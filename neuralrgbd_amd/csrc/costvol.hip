@@ -158,11 +158,11 @@ static int launch_gather(const CostvolArgs& a, hipStream_t stream) {
 
 }  // namespace nrgbd
 
-extern "C" int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc, const float* KR,
-                                 const float* Kt, const float* rays, const float* d_candi,
-                                 float cx, float cy, float sigma, int dist, int align_corners,
-                                 float* out_cost, float* out_logp, int V, int C, int Cp, int D,
-                                 int h, int w, void* stream) {
+extern "C" int nrgbd_costvol_fwd_gen(const float* ref_nhwc, const float* src_nhwc, const float* KR,
+                                     const float* Kt, const float* rays, const float* d_candi,
+                                     float cx, float cy, float sigma, int dist, int align_corners,
+                                     float* out_cost, float* out_logp, int V, int C, int Cp, int D,
+                                     int h, int w, int generation, void* stream) {
     using namespace nrgbd;
     if (!ref_nhwc || !src_nhwc || !KR || !Kt || !rays || !d_candi) return NRGBD_E_NULL;
     if (!out_cost && !out_logp) return NRGBD_E_NULL;
@@ -170,15 +170,27 @@ extern "C" int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc, c
     if ((Cp & 3) || Cp < C || Cp - C > 3) return NRGBD_E_ALIGN;
     if ((reinterpret_cast<uintptr_t>(ref_nhwc) | reinterpret_cast<uintptr_t>(src_nhwc)) & 15) return NRGBD_E_ALIGN;
     if (dist != NRGBD_DIST_L2 && dist != NRGBD_DIST_L1) return NRGBD_E_ARG;
+    if (generation < NRGBD_GEN_AUTO || generation > NRGBD_GEN_QUAD) return NRGBD_E_ARG;
     CostvolArgs a{ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, out_cost, out_logp, cx, cy, sigma,
-                  dist, align_corners, V, C, Cp, D, h, w, 0, 0};
-    if (const char* ab = getenv("NRGBD_ABLATE")) a.debug = atoi(ab);
+                  dist, align_corners, V, C, Cp, D, h, w, 0, 0, 1, D, 0};
+#ifdef NRGBD_DEV
+    a.debug = dev_env_int("NRGBD_ABLATE");
+#endif
     hipStream_t s = (hipStream_t)stream;
-    // Generation 2 (LDS-staged) whenever Cp/4 has an instantiation; NRGBD_COSTVOL=gather forces
-    // generation 1 (kept as the general fallback and as the A/B baseline).
-    const char* force = getenv("NRGBD_COSTVOL");
-    const bool want_gather = force && force[0] == 'g';
-    if (!want_gather && costvol_lds_supported(Cp >> 2)) {
+    // AUTO: generation 3 (quad) for the path's own texel (64 feature channels [+ RGB word]); generation 2 (LDS, lane =
+    // pixel) for the other channel counts it instantiates; generation 1 (gather) for everything else.  An explicit
+    // generation that does not support the shape is an error, never a silent substitution.
+    if (generation == NRGBD_GEN_QUAD && !costvol_quad_supported(a)) return NRGBD_E_SHAPE;
+    if (generation == NRGBD_GEN_LDS && !costvol_lds_supported(Cp >> 2)) return NRGBD_E_SHAPE;
+    if (generation == NRGBD_GEN_QUAD || (generation == NRGBD_GEN_AUTO && costvol_quad_supported(a))) {
+        bool did_softmax = false;
+        int rc = launch_costvol_quad(a, s, &did_softmax);
+        if (rc != NRGBD_OK) return rc;
+        if (out_logp && !did_softmax)
+            return launch_logsoftmax_d(out_cost ? out_cost : out_logp, nullptr, -1.f, out_logp, D, (size_t)h * w, s);
+        return NRGBD_OK;
+    }
+    if (generation == NRGBD_GEN_LDS || (generation == NRGBD_GEN_AUTO && costvol_lds_supported(Cp >> 2))) {
         int rc = launch_costvol_lds(a, s);
         if (rc != NRGBD_OK) return rc;
         if (out_logp)  // log_softmax(-cost) over D (models/basic.py:299-300); in place when only logp is wanted
@@ -190,4 +202,13 @@ extern "C" int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc, c
     const long tiles64 = (long)ceil_div(w, 16) * ceil_div(h, 4);
     if (tiles64 >= 512) return launch_gather<16, 4, 1>(a, s);
     return launch_gather<8, 2, 4>(a, s);
+}
+
+extern "C" int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc, const float* KR,
+                                 const float* Kt, const float* rays, const float* d_candi,
+                                 float cx, float cy, float sigma, int dist, int align_corners,
+                                 float* out_cost, float* out_logp, int V, int C, int Cp, int D,
+                                 int h, int w, void* stream) {
+    return nrgbd_costvol_fwd_gen(ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, cx, cy, sigma, dist, align_corners, out_cost,
+                                 out_logp, V, C, Cp, D, h, w, nrgbd::NRGBD_GEN_AUTO, stream);
 }

@@ -146,13 +146,13 @@ __global__ __launch_bounds__(256, 2) void costvol_lds(const CostvolArgs a) {
     // of the TILES and walks it group by group — nearest (most expensive) groups first, as in the plain order, but a
     // tile's groups now run on one XCD within a few dozen workgroups of each other and share its L2.
     int bx = blockIdx.x, by = blockIdx.y;
-    if ((a.debug & 4) && (gridDim.x & 7) == 0) {
+    if (NRGBD_DBG(a, 4) && (gridDim.x & 7) == 0) {
         const int lin = blockIdx.y * gridDim.x + blockIdx.x;
         const int xcd = lin & 7, u = lin >> 3, tpx = gridDim.x >> 3;   // tiles per XCD
         by = u / tpx;
         bx = xcd * tpx + (u - by * tpx);
     }
-    if ((a.debug >> 8) & 0xff) { if (by != ((a.debug >> 8) & 0xff) - 1) return; }   // developer: time one candidate group alone
+    if (NRGBD_DBG(a, 0xff00)) { if (by != ((a.debug >> 8) & 0xff) - 1) return; }   // developer: time one candidate group alone
     const int tx = bx % tiles_x, ty = bx / tiles_x;
     // blockIdx.y -> candidate range.  On grids too small to fill the chip (tiles x D/8 < 4 workgroups per CU)
     // the first kSingles candidates — the nearest planes for an increasing d_candi: large, fast-moving
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void costvol_lds(const CostvolArgs a) {
                 constexpr int W0 = Cfg::w0(cb);                 // first word staged
                 constexpr int L0 = Cfg::first(cb) - W0;         // local index of the first word computed
                 constexpr int n4 = Cfg::count(cb);              // words computed
-                if (area > 0 && !(a.debug & 1)) {
+                if (area > 0 && !NRGBD_DBG(a, 1)) {
                     // ---- stage: HBM -> LDS, [texel][NS words]; consecutive lanes take consecutive 16-B
                     // words; every load is issued before the first LDS write (one memory round trip) ----
                     const int total = area * NS;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void costvol_lds(const CostvolArgs a) {
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < kKG; ++j) {
-                    if (j < j0 || j >= j0 + n || (a.debug & 2)) continue;  // uniform
+                    if (j < j0 || j >= j0 + n || NRGBD_DBG(a, 2)) continue;  // uniform
                     float part = 0.f;
                     if (area > 0) {
                         float ix = ixs[j], iy = iys[j];
@@ -412,7 +412,7 @@ bool costvol_lds_supported(int cp4) {
 int launch_costvol_lds(const CostvolArgs& args, hipStream_t stream) {
     CostvolArgs a = args;
     const int tiles = ceil_div(a.w, kTile) * ceil_div(a.h, kTile);
-    const bool singles = (long)tiles * ceil_div(a.D, kKG) < 4 * 256 || (a.debug & 8);  // under-filled chip
+    const bool singles = (long)tiles * ceil_div(a.D, kKG) < 4 * 256 || NRGBD_DBG(a, 8);  // under-filled chip
     const int nsingle = singles ? (a.D < kSingles ? a.D : kSingles) : 0;
     a.nsingle = nsingle;
     const dim3 grid(tiles, nsingle + ceil_div(a.D - nsingle, kKG));

@@ -1,0 +1,472 @@
+// costvol_quad.hip — generation 3 of the fused plane-sweep cost volume: FOUR LANES PER (pixel, candidate).
+//
+// Why (profiles/r1_pmc_summary.txt): generation 2 gives every lane one reference pixel and keeps its
+// 68-channel texel in 68 VGPRs; with the staging batch and the tap pipeline that is 246 VGPRs = 2 waves per SIMD, its
+// ds_read_b128 taps conflict on 25 % of the LDS cycles (16 lanes of a service group read 16 unrelated texels), and a
+// workgroup alternates stage -> barrier -> math -> barrier with nothing to overlap them.  Here the 64 feature channels of a
+// texel are split over the 4 lanes of a quad:
+//
+//   quad   = one reference pixel (8x8-pixel tile = 64 quads = 256 threads), walking the depth candidates;
+//   lane j = feature words {j, 4+j, 8+j, 12+j} of that pixel (16 VGPRs of reference instead of 68), visited in an order
+//            rotated by the quad's index: at step s quad i reads quarter (s + i) & 3 of its tap texel, so the four quads that
+//            one ds_read_b128 service group holds ({0-3,12-15,20-27}, ... = quads {0,3,5,6}, {1,2,4,7}) always read FOUR
+//            DIFFERENT 64-byte quarters => different banks whatever the four texels are: conflict-free BY CONSTRUCTION (LDS
+//            texel stride 256 B), not by the luck of the homography being close to a translation;
+//   the 4-tap interpolation of a lane's 16 channels needs no data from other lanes; the channel sum of (s - r)^2 is finished
+//   with two DPP quad-permute adds (the wavefront-shuffle reduction);
+//   the sampling coordinates (2 IEEE divisions each for x and y: the expensive scalar part) are computed ONCE per
+//   (pixel, candidate): lane j of the quad does candidate 4g+j, then the record (4 weights + patch address) is broadcast
+//   inside the quad with DPP quad_perm [i,i,i,i] while the four lanes evaluate candidate 4g+i together;
+//   the RGB word (channels 64..66) of candidate 4g+j is done by lane j alone from a separate 16-B plane of the patch.
+//
+// Source texels reach the LDS by global_load_lds (no VGPR round trip): a wave instruction drops 4 texels x 256 B in lane
+// order, which IS the patch layout.  The patch is the union footprint of a run of 2/4/8 candidates for one view, with a
+// one-texel apron that may lie outside the image (filled from the clamped coordinate; its weight is zero), so the four taps
+// of a pixel are {A, A+256, A+pitch, A+pitch+256}: one broadcast address per candidate instead of four clamped ones.
+// Candidates whose footprint does not fit even as a pair (nearest planes: large, fast-moving footprints) are evaluated
+// straight from L1/L2 with the same quad layout — a quad's taps are 64-byte contiguous runs, which the texture path serves at
+// 4 lanes/clk (the generation-1 gather paid 1 lane/clk) — so they need neither a patch nor a barrier.
+// ~100 VGPRs => 3 workgroups (12 waves) per CU; one workgroup owns ALL candidates of its tile (when the grid fills the chip),
+// so log_softmax over depth is taken in the same launch (models/basic.py:299-300).
+//
+// Arithmetic per tap / channel is the same as generations 1-2 (common.hpp helpers, same operation sequence for the
+// coordinates); only the order of the channel sum differs (16 channels per lane, then the quad), like any other reduction order.
+#include "costvol.hpp"
+
+namespace nrgbd {
+
+namespace {
+
+constexpr int kQT = 8;            // tile edge
+constexpr int kQRun = 8;          // candidates per staged run (two groups of 4)
+constexpr int kQMaxV = 8;         // views whose boxes fit the scratch (more views -> generation 2)
+constexpr int kQPatch = 192;      // texels of the patch (x 272 B = 51 KB): 3 workgroups per CU
+constexpr int kQFeatBytes = 256;  // feature plane: 16 words of 16 B per texel
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N, typename F>
+__device__ __forceinline__ void qstatic_for(F&& f) {
+    if constexpr (N > 0) {
+        qstatic_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+// quad_perm controls: broadcast lane I of every quad; butterfly partners
+template <int I> constexpr int kBcast = I * 0x55;
+constexpr int kXor1 = 0xB1;  // [1,0,3,2]
+constexpr int kXor2 = 0x4E;  // [2,3,0,1]
+
+struct QBox { int xlo, xhi, ylo, yhi; };   // inclusive texel range, may start at -1 / end at w (apron)
+
+// Footprint of the tile on the plane at depth dc in source view (KRv, Ktv): bounding box of the taps of the 4 corner pixels
+// (+1 texel of slack), kept inside [-1, w] x [-1, h].  Returns false when the plane crosses the source camera inside the
+// tile (then nothing bounds the taps: the caller evaluates from global memory).  See costvol_lds.hip::region_box for why
+// the corners bound the interior.
+__device__ __forceinline__ bool tile_box(const CostvolArgs& a, const float* KRv, const float* Ktv, float dc, int xa, int xb,
+                                         int ya, int yb, QBox& o) {
+    const size_t hw = (size_t)a.h * a.w;
+    const float wf = (float)a.w, hf = (float)a.h;
+    const int cxs[2] = {xa, xb}, cys[2] = {ya, yb};
+    float mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const size_t pc = (size_t)cys[c >> 1] * a.w + cxs[c & 1];
+        const SweepTerm sc = make_sweep_term(KRv, Ktv, a.rays[pc], a.rays[hw + pc], a.rays[2 * hw + pc]);
+        const float den = (sc.t1z + sc.t2z * dc) + 1e-10f;
+        float ix, iy;
+        sweep_sample_pos(sc, dc, a.cx, a.cy, wf, hf, a.align != 0, ix, iy);
+        ok = ok && (den > 0.f) && (fabsf(ix) < 1e8f) && (fabsf(iy) < 1e8f);
+        mnx = fminf(mnx, ix); mxx = fmaxf(mxx, ix);
+        mny = fminf(mny, iy); mxy = fmaxf(mxy, iy);
+    }
+    if (!ok) return false;
+    mnx = fmaxf(mnx, -4.f); mxx = fminf(mxx, wf + 4.f);
+    mny = fmaxf(mny, -4.f); mxy = fminf(mxy, hf + 4.f);
+    o.xlo = min(max((int)floorf(mnx) - 1, -1), a.w - 1);
+    o.xhi = min(max((int)floorf(mxx) + 2, o.xlo + 1), a.w);
+    o.ylo = min(max((int)floorf(mny) - 1, -1), a.h - 1);
+    o.yhi = min(max((int)floorf(mxy) + 2, o.ylo + 1), a.h);
+    return true;
+}
+
+struct TapW { float nw, ne, sw, se; };
+
+// weights with zeros padding (a corner outside the image contributes nothing) + the un-clamped integer corner
+__device__ __forceinline__ TapW tap_weights(float ix, float iy, float wf, float hf, float& x0f, float& y0f) {
+    x0f = floorf(ix); y0f = floorf(iy);
+    const float fx = ix - x0f, fy = iy - y0f, ex = 1.f - fx, ey = 1.f - fy;
+    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+    const bool vx0 = (x0f >= 0.f) && (x0f <= wf - 1.f), vx1 = (x1f >= 0.f) && (x1f <= wf - 1.f);
+    const bool vy0 = (y0f >= 0.f) && (y0f <= hf - 1.f), vy1 = (y1f >= 0.f) && (y1f <= hf - 1.f);
+    TapW t;
+    t.nw = (vx0 && vy0) ? ey * ex : 0.f; t.ne = (vx1 && vy0) ? ey * fx : 0.f;
+    t.sw = (vx0 && vy1) ? fy * ex : 0.f; t.se = (vx1 && vy1) ? fy * fx : 0.f;
+    return t;
+}
+
+// one 16-byte word of the 4 taps against the reference word: accumulate dist(sample - ref) of its 4 channels
+template <int DIST>
+__device__ __forceinline__ void word_acc(const f32x4 A, const f32x4 B, const f32x4 C, const f32x4 D, const f32x4 rr,
+                                         const f32x2 wnw, const f32x2 wne, const f32x2 wsw, const f32x2 wse, f32x2& pa,
+                                         f32x2& pb) {
+    f32x2 lo = A.xy * wnw, hi = A.zw * wnw;
+    lo = __builtin_elementwise_fma(B.xy, wne, lo); hi = __builtin_elementwise_fma(B.zw, wne, hi);
+    lo = __builtin_elementwise_fma(C.xy, wsw, lo); hi = __builtin_elementwise_fma(C.zw, wsw, hi);
+    lo = __builtin_elementwise_fma(D.xy, wse, lo); hi = __builtin_elementwise_fma(D.zw, wse, hi);
+    lo = lo - rr.xy; hi = hi - rr.zw;
+    if constexpr (DIST == NRGBD_DIST_L2) {
+        pa = __builtin_elementwise_fma(lo, lo, pa);
+        pb = __builtin_elementwise_fma(hi, hi, pb);
+    } else {
+        pa = pa + __builtin_elementwise_abs(lo);
+        pb = pb + __builtin_elementwise_abs(hi);
+    }
+}
+
+// the RGB word (channels 64.. : `tail` of them count) of one candidate, all four taps by one lane
+template <int DIST>
+__device__ __forceinline__ float rgb_word(const f32x4 A, const f32x4 B, const f32x4 C, const f32x4 D, const f32x4 rr,
+                                          const TapW t, int tail) {
+    float s[4];
+    s[0] = __builtin_fmaf(D.x, t.se, __builtin_fmaf(C.x, t.sw, __builtin_fmaf(B.x, t.ne, A.x * t.nw))) - rr.x;
+    s[1] = __builtin_fmaf(D.y, t.se, __builtin_fmaf(C.y, t.sw, __builtin_fmaf(B.y, t.ne, A.y * t.nw))) - rr.y;
+    s[2] = __builtin_fmaf(D.z, t.se, __builtin_fmaf(C.z, t.sw, __builtin_fmaf(B.z, t.ne, A.z * t.nw))) - rr.z;
+    s[3] = __builtin_fmaf(D.w, t.se, __builtin_fmaf(C.w, t.sw, __builtin_fmaf(B.w, t.ne, A.w * t.nw))) - rr.w;
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float term = (DIST == NRGBD_DIST_L2) ? s[e] * s[e] : fabsf(s[e]);
+        acc = acc + ((e < tail) ? term : 0.f);
+    }
+    return acc;
+}
+
+}  // namespace
+
+// EXTRA: the texel has a 17th word (Cp = 68: channels 64..66 = pooled RGB); otherwise Cp = 64.
+template <int DIST, bool EXTRA>
+__global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsF = smem;                                                  // [kQPatch][256 B]
+    char* ldsR = smem + kQPatch * kQFeatBytes;                          // [kQPatch][16 B]
+    int* bb = reinterpret_cast<int*>(ldsR + kQPatch * 16);              // [kQRun][kQMaxV][4] boxes, [.][.][0] = INT_MAX: unbounded
+    float* red = reinterpret_cast<float*>(smem);                        // softmax scratch (the patch is dead by then)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quad = tid >> 2, j = tid & 3, i3 = quad & 3;
+    // workgroup -> (tile, candidate chunk); XCD k (= blockIdx % 8) owns a contiguous eighth of the tile list so that the
+    // source rows a band of tiles samples stay in ONE 4 MB L2
+    int id = blockIdx.x;
+    if ((gridDim.x & 7) == 0) id = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tile = id / a.nchunk, chunk = id - tile * a.nchunk;
+    const int tiles_x = (a.w + kQT - 1) / kQT;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int kb = chunk * a.kchunk, ke = min(a.D, kb + a.kchunk);
+
+    const int x = tx * kQT + (quad & 7), y = ty * kQT + (quad >> 3);
+    const bool inside = (x < a.w) && (y < a.h);
+    const int xc = min(x, a.w - 1), yc = min(y, a.h - 1);
+    const size_t hw = (size_t)a.h * a.w;
+    const size_t p = (size_t)yc * a.w + xc;
+    const float wf = (float)a.w, hf = (float)a.h;
+    const bool align = a.align != 0;
+    const int tail = a.C - 64;   // valid channels of the RGB word (EXTRA)
+
+    // per-lane word order: step s -> byte offset of word ((s + i3) & 3) * 4 + j inside a texel's feature plane
+    int cofs[4];
+    f32x4 rr[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        cofs[s] = (((s + i3) & 3) * 4 + j) * 16;
+        rr[s] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.ref + p * a.Cp) + cofs[s]);
+    }
+    f32x4 rgbref = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EXTRA) rgbref = *reinterpret_cast<const f32x4*>(a.ref + p * a.Cp + 64);
+    const float rx = a.rays[p], ry = a.rays[hw + p], rz = a.rays[2 * hw + p];
+
+    const int tx0 = tx * kQT, tx1 = min(tx * kQT + kQT - 1, a.w - 1);
+    const int ty0 = ty * kQT, ty1 = min(ty * kQT + kQT - 1, a.h - 1);
+    float* out = a.out_cost ? a.out_cost : a.out_logp;
+
+    // ---- evaluation of one group of NI <= 4 candidates (lane j owns candidate k0 + j) for one view --------------------------
+    // STAGED: taps from the LDS patch (box xlo..: pitch = cols); otherwise straight from global memory.  The NI x 4
+    // (candidate, step) tap fetches run as one software pipeline, PD steps ahead of the math (LDS: 1, global memory: 3).
+    auto group = [&](auto staged_c, auto ni_c, const float* sv, const SweepTerm& st, int k0, int ncand, int xlo, int xhi,
+                     int ylo, int yhi, int cols) -> float {
+        constexpr bool STAGED = decltype(staged_c)::value;
+        constexpr int NI = decltype(ni_c)::value;
+        constexpr int PD = STAGED ? 1 : 3;
+        const int kc = min(k0 + j, k0 + ncand - 1);          // lanes beyond the group repeat its last candidate
+        float ix, iy, x0f, y0f;
+        sweep_sample_pos(st, a.d_candi[kc], a.cx, a.cy, wf, hf, align, ix, iy);
+        const TapW tw = tap_weights(ix, iy, wf, hf, x0f, y0f);
+        // tap addresses: STAGED one patch address (apron => the 3 other taps are +256, +pitch, +pitch+256);
+        // global: four clamped texel offsets
+        int adr[4];
+        if constexpr (STAGED) {
+            const int xi = (int)fminf(fmaxf(x0f, (float)xlo), (float)(xhi - 1)) - xlo;   // NaN -> xlo
+            const int yi = (int)fminf(fmaxf(y0f, (float)ylo), (float)(yhi - 1)) - ylo;
+            adr[0] = __mul24(yi, cols) + xi;                  // texel index in the patch
+            adr[1] = adr[2] = adr[3] = 0;
+        } else {
+            const int xa = (int)fminf(fmaxf(x0f, 0.f), wf - 1.f), xb = (int)fminf(fmaxf(x0f + 1.f, 0.f), wf - 1.f);
+            const int ya = (int)fminf(fmaxf(y0f, 0.f), hf - 1.f), yb = (int)fminf(fmaxf(y0f + 1.f, 0.f), hf - 1.f);
+            const int cpb = a.Cp * 4;
+            adr[0] = (ya * a.w + xa) * cpb; adr[1] = (ya * a.w + xb) * cpb;
+            adr[2] = (yb * a.w + xa) * cpb; adr[3] = (yb * a.w + xb) * cpb;
+        }
+        const int pitchB = cols * kQFeatBytes;
+        const char* gsv = reinterpret_cast<const char*>(sv);
+
+        // broadcast tap addresses of the NI candidates (item I = the candidate lane I of the quad prepared)
+        int ib[NI][STAGED ? 1 : 4];
+        qstatic_for<NI>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (STAGED) {
+                ib[I][0] = dpp_i<kBcast<I>>(adr[0]) * kQFeatBytes;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ib[I][t] = dpp_i<kBcast<I>>(adr[t]);
+            }
+        });
+        f32x4 buf[PD + 1][4];
+        auto issue = [&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            constexpr int I = S >> 2, s4 = S & 3, slot = S % (PD + 1);
+            if constexpr (STAGED) {
+                const char* t0 = ldsF + ib[I][0] + cofs[s4];
+                const char* t1 = t0 + pitchB;
+                buf[slot][0] = *reinterpret_cast<const f32x4*>(t0);
+                buf[slot][1] = *reinterpret_cast<const f32x4*>(t0 + kQFeatBytes);
+                buf[slot][2] = *reinterpret_cast<const f32x4*>(t1);
+                buf[slot][3] = *reinterpret_cast<const f32x4*>(t1 + kQFeatBytes);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    buf[slot][t] = *reinterpret_cast<const f32x4*>(gsv + (unsigned)(ib[I][t] + cofs[s4]));
+            }
+        };
+        qstatic_for<(PD < NI * 4 ? PD : NI * 4)>([&](auto sc) { issue(sc); });
+
+        // RGB word of this lane's own candidate (its four taps by this lane alone), overlapped with the first fetches
+        float rgbpart = 0.f;
+        if constexpr (EXTRA) {
+            f32x4 A, B, C, Dd;
+            if constexpr (STAGED) {
+                const char* r0 = ldsR + adr[0] * 16;
+                const char* r1 = r0 + cols * 16;
+                A = *reinterpret_cast<const f32x4*>(r0); B = *reinterpret_cast<const f32x4*>(r0 + 16);
+                C = *reinterpret_cast<const f32x4*>(r1); Dd = *reinterpret_cast<const f32x4*>(r1 + 16);
+            } else {
+                const char* g = gsv + kQFeatBytes;
+                A = *reinterpret_cast<const f32x4*>(g + (unsigned)adr[0]); B = *reinterpret_cast<const f32x4*>(g + (unsigned)adr[1]);
+                C = *reinterpret_cast<const f32x4*>(g + (unsigned)adr[2]); Dd = *reinterpret_cast<const f32x4*>(g + (unsigned)adr[3]);
+            }
+            rgbpart = rgb_word<DIST>(A, B, C, Dd, rgbref, tw, tail);
+        }
+
+        float keep = 0.f;
+        f32x2 wnw, wne, wsw, wse, pa, pb;
+        qstatic_for<NI * 4>([&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            constexpr int I = S >> 2, s4 = S & 3, slot = S % (PD + 1);
+            if constexpr (S + PD < NI * 4) issue(std::integral_constant<int, S + PD>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (s4 == 0) {
+                const float bnw = dpp_f<kBcast<I>>(tw.nw), bne = dpp_f<kBcast<I>>(tw.ne);
+                const float bsw = dpp_f<kBcast<I>>(tw.sw), bse = dpp_f<kBcast<I>>(tw.se);
+                wnw = f32x2{bnw, bnw}; wne = f32x2{bne, bne}; wsw = f32x2{bsw, bsw}; wse = f32x2{bse, bse};
+                pa = f32x2{0.f, 0.f}; pb = f32x2{0.f, 0.f};
+            }
+            word_acc<DIST>(buf[slot][0], buf[slot][1], buf[slot][2], buf[slot][3], rr[s4], wnw, wne, wsw, wse, pa, pb);
+            if constexpr (s4 == 3) {
+                const f32x2 pc = pa + pb;
+                float part = pc.x + pc.y;
+                part = part + dpp_f<kXor1>(part);              // quad reduction: all four lanes end with the channel sum
+                part = part + dpp_f<kXor2>(part);
+                keep = (j == I) ? part : keep;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        return keep + rgbpart;
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    using N2 = std::integral_constant<int, 2>; using N4 = std::integral_constant<int, 4>;
+
+    for (int j0 = kb; j0 < ke;) {
+        // ---- footprints of the next <= 8 candidates in every view (threads 0 .. 8V-1) ----
+        const int nmax = min(kQRun, ke - j0);
+        __syncthreads();   // previous run's readers of bb / the patch are done
+        if (tid < kQRun * a.V) {
+            const int c = tid / a.V, v = tid - c * a.V;
+            QBox o{0, 1, 0, 1};
+            bool ok = true;
+            if (c < nmax) ok = tile_box(a, a.KR + 9 * v, a.Kt + 3 * v, a.d_candi[j0 + c], tx0, tx1, ty0, ty1, o);
+            int* b4 = bb + (c * kQMaxV + v) * 4;
+            b4[0] = ok ? o.xlo : 0x7fffffff; b4[1] = o.xhi; b4[2] = o.ylo; b4[3] = o.yhi;
+        }
+        __syncthreads();
+        // largest run n in {8, 4, 2} whose united footprint fits the patch in EVERY view (block-uniform)
+        int n = 0;
+        for (int tryn = kQRun; tryn >= 2 && n == 0; tryn >>= 1) {
+            if (tryn > nmax) continue;
+            bool fits = true;
+            for (int v = 0; v < a.V && fits; ++v) {
+                int xlo = 1 << 30, xhi = -(1 << 30), ylo = 1 << 30, yhi = -(1 << 30);
+                for (int c = 0; c < tryn; ++c) {
+                    const int* b4 = bb + (c * kQMaxV + v) * 4;
+                    const int b0 = __builtin_amdgcn_readfirstlane(b4[0]);
+                    if (b0 == 0x7fffffff) { fits = false; break; }
+                    xlo = min(xlo, b0); xhi = max(xhi, __builtin_amdgcn_readfirstlane(b4[1]));
+                    ylo = min(ylo, __builtin_amdgcn_readfirstlane(b4[2])); yhi = max(yhi, __builtin_amdgcn_readfirstlane(b4[3]));
+                }
+                fits = fits && (long)(xhi - xlo + 1) * (yhi - ylo + 1) <= kQPatch;
+            }
+            if (fits) n = tryn;
+        }
+        const bool staged = n >= 2 && !NRGBD_DBG(a, 1);
+        if (!staged) n = min(4, nmax);                         // one group straight from global memory
+        const int ngroups = (n + 3) >> 2;
+
+        float tot[2] = {0.f, 0.f};
+        for (int v = 0; v < a.V; ++v) {
+            const float* KRv = a.KR + 9 * v;
+            const float* Ktv = a.Kt + 3 * v;
+            const float* sv = a.src + (size_t)v * hw * a.Cp;
+            const SweepTerm st = make_sweep_term(KRv, Ktv, rx, ry, rz);
+            float acc[2] = {0.f, 0.f};
+            if (staged) {
+                int xlo = 1 << 30, xhi = -(1 << 30), ylo = 1 << 30, yhi = -(1 << 30);
+                for (int c = 0; c < n; ++c) {
+                    const int* b4 = bb + (c * kQMaxV + v) * 4;
+                    xlo = min(xlo, __builtin_amdgcn_readfirstlane(b4[0])); xhi = max(xhi, __builtin_amdgcn_readfirstlane(b4[1]));
+                    ylo = min(ylo, __builtin_amdgcn_readfirstlane(b4[2])); yhi = max(yhi, __builtin_amdgcn_readfirstlane(b4[3]));
+                }
+                const int cols = xhi - xlo + 1, area = cols * (yhi - ylo + 1);
+                const unsigned magic = 0xFFFFFFFFu / (unsigned)cols + 1u;      // q / cols for q < 2^16, cols >= 2
+                if (v > 0) __syncthreads();                    // the previous view's taps have been read
+                // ---- stage: HBM/L2 -> LDS without touching VGPRs; a wave instruction = 4 texels x 256 B (feature plane)
+                // or 64 texels x 16 B (RGB plane), landing in lane order = patch order ----
+                for (int it = wave; it * 4 < area; it += 4) {
+                    const int q = min(it * 4 + (lane >> 4), area - 1);
+                    const int qy = (int)__umulhi((unsigned)q, magic), qx = q - qy * cols;
+                    const int gx = min(max(xlo + qx, 0), a.w - 1), gy = min(max(ylo + qy, 0), a.h - 1);
+                    const float* g = sv + ((size_t)gy * a.w + gx) * a.Cp + (lane & 15) * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),
+                                                     (__attribute__((address_space(3))) void*)(ldsF + it * 4 * kQFeatBytes),
+                                                     16, 0, 0);
+                }
+                if constexpr (EXTRA) {
+                    for (int it = wave; it * 64 < area; it += 4) {
+                        const int q = min(it * 64 + lane, area - 1);
+                        const int qy = (int)__umulhi((unsigned)q, magic), qx = q - qy * cols;
+                        const int gx = min(max(xlo + qx, 0), a.w - 1), gy = min(max(ylo + qy, 0), a.h - 1);
+                        const float* g = sv + ((size_t)gy * a.w + gx) * a.Cp + 64;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),
+                                                         (__attribute__((address_space(3))) void*)(ldsR + it * 64 * 16),
+                                                         16, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (!NRGBD_DBG(a, 2)) {
+                    if (n == 2) acc[0] = group(T_{}, N2{}, sv, st, j0, 2, xlo, xhi, ylo, yhi, cols);
+                    else acc[0] = group(T_{}, N4{}, sv, st, j0, 4, xlo, xhi, ylo, yhi, cols);
+                    if (ngroups > 1) acc[1] = group(T_{}, N4{}, sv, st, j0 + 4, 4, xlo, xhi, ylo, yhi, cols);
+                }
+            } else {
+                acc[0] = group(F_{}, N4{}, sv, st, j0, n, 0, 0, 0, 0, 0);
+            }
+            tot[0] = tot[0] + acc[0] / a.sigma;                // homography.py:325, views in order
+            tot[1] = tot[1] + acc[1] / a.sigma;
+        }
+        if (inside) {
+            if (j < n) out[(size_t)(j0 + j) * hw + p] = tot[0];
+            if (4 + j < n) out[(size_t)(j0 + 4 + j) * hw + p] = tot[1];
+        }
+        j0 += n;
+    }
+
+    if (!a.fuse_softmax) return;
+    // ---- log_softmax(-cost) over the D candidates of the tile's pixels (models/basic.py:299-300) ----
+    // thread = (pixel, quarter of the candidates); the costs were written by other lanes of THIS workgroup: make the stores
+    // visible (L2) and read them past the L1
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    {
+        const int pp = tid & 63, part = tid >> 6;
+        const int x2 = tx * kQT + (pp & 7), y2 = ty * kQT + (pp >> 3);
+        const bool in2 = (x2 < a.w) && (y2 < a.h);
+        const size_t p2 = (size_t)min(y2, a.h - 1) * a.w + min(x2, a.w - 1);
+        constexpr int KMAX = 32;                              // D <= 128
+        float col[KMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            const int k = part + 4 * t;
+            col[t] = (k < a.D) ? -__builtin_nontemporal_load(out + (size_t)k * hw + p2) : -INFINITY;
+            m = fmaxf(m, col[t]);
+        }
+        red[part * 64 + pp] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[pp], red[64 + pp]), fmaxf(red[128 + pp], red[192 + pp]));
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t)
+            if (part + 4 * t < a.D) s += expf(col[t] - m);
+        red[256 + part * 64 + pp] = s;
+        __syncthreads();
+        s = (red[256 + pp] + red[256 + 64 + pp]) + (red[256 + 128 + pp] + red[256 + 192 + pp]);
+        const float ls = logf(s);
+        if (in2) {
+#pragma unroll
+            for (int t = 0; t < KMAX; ++t) {
+                const int k = part + 4 * t;
+                if (k < a.D) a.out_logp[(size_t)k * hw + p2] = (col[t] - m) - ls;
+            }
+        }
+    }
+}
+
+bool costvol_quad_supported(const CostvolArgs& a) {
+    const bool extra = a.Cp == 68 && a.C > 64;
+    const bool plain = a.Cp == 64 && a.C == 64;
+    return (extra || plain) && a.V <= kQMaxV;
+}
+
+// Returns NRGBD_OK and sets *did_softmax when the launch also produced out_logp.
+int launch_costvol_quad(const CostvolArgs& args, hipStream_t stream, bool* did_softmax) {
+    CostvolArgs a = args;
+    const int tiles = ceil_div(a.w, kQT) * ceil_div(a.h, kQT);
+    // one workgroup per tile owns all D candidates when that fills the chip (3 workgroups per CU); smaller grids split the
+    // candidates into chunks (>= 8 each) so that every CU has work, and leave the log-softmax to its own launch
+    int nchunk = 1;
+    while (tiles * nchunk < 3 * 256 && ceil_div(a.D, nchunk * 2) >= 8) nchunk *= 2;
+    a.nchunk = nchunk;
+    a.kchunk = ceil_div(a.D, nchunk);
+    a.fuse_softmax = (nchunk == 1 && a.out_logp != nullptr && a.D <= 128) ? 1 : 0;
+    *did_softmax = a.fuse_softmax != 0;
+    const size_t lds = (size_t)kQPatch * (kQFeatBytes + 16) + kQRun * kQMaxV * 4 * sizeof(int);
+    const dim3 grid(tiles * nchunk);
+    const bool extra = a.Cp == 68;
+#define NRGBD_QUAD_LAUNCH(DIST, EX) hipLaunchKernelGGL((costvol_quad<DIST, EX>), grid, dim3(256), lds, stream, a)
+    if (a.dist == NRGBD_DIST_L2) { if (extra) NRGBD_QUAD_LAUNCH(NRGBD_DIST_L2, true); else NRGBD_QUAD_LAUNCH(NRGBD_DIST_L2, false); }
+    else { if (extra) NRGBD_QUAD_LAUNCH(NRGBD_DIST_L1, true); else NRGBD_QUAD_LAUNCH(NRGBD_DIST_L1, false); }
+#undef NRGBD_QUAD_LAUNCH
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+}  // namespace nrgbd

@@ -11,6 +11,7 @@ import torch
 from . import _lib
 
 DIST = {"L2": 0, "L1": 1}
+GENERATION = {None: 0, "auto": 0, "gather": 1, "lds": 2, "quad": 3}   # kernel generations of nrgbd_costvol_fwd_gen
 
 
 def _need(t, name, shape=None, strided=False):
@@ -88,8 +89,9 @@ def pack_nhwc(feat, rgb=None, Cp=None, channels_last=False):
 
 
 def costvol(ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, cx, cy, sigma, C, dist="L2",
-            align_corners=False, want_cost=True, want_logp=False):
-    """Fused warp + cost volume (+ log-softmax).  Returns (cost [D,h,w] | None, logp [D,h,w] | None)."""
+            align_corners=False, want_cost=True, want_logp=False, generation=None):
+    """Fused warp + cost volume (+ log-softmax).  Returns (cost [D,h,w] | None, logp [D,h,w] | None).
+    `generation` (None = automatic | "gather" | "lds" | "quad") pins the kernel generation for tests / A-B timing."""
     src_nhwc = _need(src_nhwc, "src_nhwc")
     V, h, w, Cp = src_nhwc.shape
     ref_nhwc = _need(ref_nhwc, "ref_nhwc", (h, w, Cp))
@@ -102,11 +104,11 @@ def costvol(ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, cx, cy, sigma, C, dist="L
     cost = torch.empty((D, h, w), dtype=torch.float32, device=dev) if want_cost else None
     logp = torch.empty((D, h, w), dtype=torch.float32, device=dev) if want_logp else None
     with torch.cuda.device(dev):
-        rc = _lib.load().nrgbd_costvol_fwd(_p(ref_nhwc), _p(src_nhwc), _p(KR), _p(Kt), _p(rays),
-                                           _p(d_candi), float(cx), float(cy), float(sigma),
-                                           DIST[dist], int(bool(align_corners)), _p(cost), _p(logp),
-                                           V, int(C), Cp, D, h, w, _stream(src_nhwc))
-    _lib.check(rc, "nrgbd_costvol_fwd")
+        rc = _lib.load().nrgbd_costvol_fwd_gen(_p(ref_nhwc), _p(src_nhwc), _p(KR), _p(Kt), _p(rays),
+                                               _p(d_candi), float(cx), float(cy), float(sigma),
+                                               DIST[dist], int(bool(align_corners)), _p(cost), _p(logp),
+                                               V, int(C), Cp, D, h, w, GENERATION[generation], _stream(src_nhwc))
+    _lib.check(rc, "nrgbd_costvol_fwd_gen")
     return cost, logp
 
 

@@ -27,18 +27,18 @@ def _setup(seed=0):
     return cam, tex, KR, Kt, rays, d, poses
 
 
-def test_two_kernel_generations_agree_and_are_deterministic(monkeypatch):
+def test_three_kernel_generations_agree_and_are_deterministic():
     from neuralrgbd_amd import ops
     cam, tex, KR, Kt, rays, d, _ = _setup()
     args = (tex[V_], tex[:V_], KR, Kt, rays, d, W_ / 2.0, H_ / 2.0, 10.0, 67)
-    monkeypatch.setenv("NRGBD_COSTVOL", "lds")
-    c1, l1 = ops.costvol(*args, want_cost=True, want_logp=True)
-    c1b, _ = ops.costvol(*args, want_cost=True, want_logp=False)
-    monkeypatch.setenv("NRGBD_COSTVOL", "gather")
-    c2, l2 = ops.costvol(*args, want_cost=True, want_logp=True)
+    c1, l1 = ops.costvol(*args, want_cost=True, want_logp=True, generation="quad")
+    c1b, _ = ops.costvol(*args, want_cost=True, want_logp=False, generation="quad")
+    c2, l2 = ops.costvol(*args, want_cost=True, want_logp=True, generation="gather")
+    c3, _ = ops.costvol(*args, want_cost=True, want_logp=False, generation="lds")
+    assert (c3 - c2).abs().max().item() < 1e-4 * max(1.0, c1.abs().max().item() / 10)
     assert torch.equal(c1, c1b)                                         # no races: bitwise reproducible
     err = (c1 - c2).abs().max().item()
-    print("[parity] full-size costvol: LDS generation vs gather generation max|d|=%.2e (cost up to %.1f)" % (err, c1.max().item()))
+    print("[parity] full-size costvol: quad generation vs gather generation max|d|=%.2e (cost up to %.1f)" % (err, c1.max().item()))
     assert err < 1e-4 * max(1.0, c1.abs().max().item() / 10)
     assert (l1 - l2).abs().max().item() < 2e-4
     # arg-max depth index: on pure-noise features ~0.25 % of the 49,152 pixels have their two best candidates within

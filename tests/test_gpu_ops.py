@@ -29,14 +29,15 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
 
 
-def _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, sigma, dist="L2", logp=False, align=False):
+def _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, sigma, dist="L2", logp=False, align=False,
+                 generation=None, want_cost=True):
     ops = _ops()
     V, C = feat_src.shape[:2]
     tex = ops.pack_nhwc(_dev(np.concatenate([feat_src, feat_ref[None]], 0)))
     cost, lp = ops.costvol(tex[V], tex[:V], _dev(KR), _dev(Kt), _dev(rays), _dev(d_candi), cx, cy, sigma, C,
-                           dist=dist, align_corners=align, want_cost=True, want_logp=logp)
+                           dist=dist, align_corners=align, want_cost=want_cost, want_logp=logp, generation=generation)
     torch.cuda.synchronize()
-    return cost.cpu().numpy(), (lp.cpu().numpy() if logp else None)
+    return (cost.cpu().numpy() if want_cost else None), (lp.cpu().numpy() if logp else None)
 
 
 def test_library_is_the_hip_build():
@@ -62,10 +63,10 @@ def test_golden_costvol_and_logsoftmax(golden_ops):
 
 
 @pytest.fixture(params=["lds", "gather"])
-def costvol_generation(request, monkeypatch):
-    """Both generations of the fused kernel must satisfy the same parity contract (NRGBD_COSTVOL is
-    read per call by nrgbd_costvol_fwd)."""
-    monkeypatch.setenv("NRGBD_COSTVOL", request.param)
+def costvol_generation(request):
+    """The general-shape generations of the fused kernel must satisfy the same parity contract (the generation is an
+    argument of nrgbd_costvol_fwd_gen; the quad generation, specific to the path's 64(+3)-channel texel, has its own
+    tests below)."""
     return request.param
 
 
@@ -89,7 +90,8 @@ def test_costvol_vs_oracle(h, w, D, V, C, seed, costvol_generation):
     cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
     want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0)
     want_lp = co.logsoftmax_d(want, scale=-1.0)
-    cost, lp = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, logp=True)
+    cost, lp = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, logp=True,
+                            generation=costvol_generation)
     mx, _, _ = report("HIP costvol %dx%dx%d V%d C%d" % (h, w, D, V, C), -cost, -want)
     assert mx < 1e-4
     mx, mean, _ = report("HIP BV_cur", lp, want_lp)
@@ -111,7 +113,8 @@ def test_costvol_out_of_view_and_align_corners(costvol_generation):
     cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
     for align in (False, True):
         want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 1.0, align_corners=align)
-        got, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 1.0, align=align)
+        got, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 1.0, align=align,
+                              generation=costvol_generation)
         assert np.abs(got - want).max() < 1e-4
 
 
@@ -321,3 +324,77 @@ def test_homography_terms_match_torch_cpu():
     want_KR = torch.stack([K.matmul(poses[v, :3, :3]) for v in range(5)])
     want_Kt = torch.stack([K.matmul(poses[v, :3, 3]) for v in range(5)])
     assert torch.equal(KR.cpu(), want_KR) and torch.equal(Kt.cpu(), want_Kt)
+
+
+# ----------------------------------------------------------------------------- generation 3 (quad) of the fused kernel
+@pytest.mark.parametrize("h,w,D,V,C,dist,rot,trans,seed", [
+    (64, 96, 64, 4, 67, "L2", 0.02, 0.05, 11),    # config S grid: candidate chunks + separate log-softmax
+    (192, 256, 64, 4, 67, "L2", 0.02, 0.05, 12),  # config B grid: one workgroup per tile, fused log-softmax
+    (33, 70, 64, 5, 67, "L2", 0.02, 0.05, 13),    # ragged tiles, 5 views
+    (17, 23, 5, 1, 67, "L1", 0.02, 0.05, 14),     # tiny, single view, L1 metric, D < 8
+    (40, 56, 130, 2, 67, "L2", 0.02, 0.05, 15),   # D > 128
+    (120, 160, 128, 4, 67, "L2", 0.02, 0.05, 16), # config H grid, D = 128
+    (24, 40, 16, 8, 64, "L2", 0.02, 0.05, 17),    # no RGB word (C = Cp = 64), 8 views
+    (24, 40, 16, 3, 65, "L1", 0.02, 0.05, 18),    # one valid channel in the RGB word
+    (48, 64, 32, 3, 67, "L2", 0.4, 1.0, 19),      # large motions: most taps out of view, planes crossing the camera
+    (48, 64, 32, 4, 67, "L2", 0.0, 0.3, 20),      # pure translation 0.3 m: strong zoom on the nearest planes
+])
+def test_costvol_quad_vs_oracle(h, w, D, V, C, dist, rot, trans, seed):
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(seed)
+    feat_ref = rng.standard_normal((C, h, w)).astype(np.float32)
+    feat_src = rng.standard_normal((V, C, h, w)).astype(np.float32)
+    poses = synth.random_poses(rng, V, rot_sigma=rot, trans_sigma=trans)
+    KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+    d_candi = np.linspace(0.1, 5, D)
+    rays = cam["unit_ray_array_2D"].numpy()
+    cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
+    co.set_threads(32)
+    want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist)
+    want_lp = co.logsoftmax_d(want, scale=-1.0)
+    cost, lp = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist, logp=True, generation="quad")
+    _, lp_only = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist, logp=True,
+                              generation="quad", want_cost=False)     # raw costs parked in out_logp, overwritten in place
+    mx, _, _ = report("quad costvol %dx%dx%d V%d C%d %s" % (h, w, D, V, C, dist), -cost, -want)
+    assert mx < 1e-5 * max(10.0, float(np.abs(want).max()))
+    mx, mean, _ = report("quad BV_cur", lp, want_lp)
+    assert mx < 1e-4 and mean < 1e-5
+    assert near_tie_mismatches(lp, want_lp, tol=1e-4) == 0
+    assert np.array_equal(lp, lp_only)
+    if C == 67:   # against generation 2 on the same inputs (independent decomposition of the same arithmetic)
+        c2, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist, generation="lds")
+        assert np.abs(c2 - cost).max() < 1e-5 * max(10.0, float(np.abs(want).max()))
+
+
+def test_costvol_quad_align_corners_and_determinism():
+    h, w, D, V, C = 40, 72, 24, 4, 67
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(31)
+    feat_ref = rng.standard_normal((C, h, w)).astype(np.float32)
+    feat_src = rng.standard_normal((V, C, h, w)).astype(np.float32)
+    poses = synth.random_poses(rng, V)
+    KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+    d_candi = np.linspace(0.1, 5, D)
+    rays = cam["unit_ray_array_2D"].numpy()
+    cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
+    for align in (False, True):
+        want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 3.0, align_corners=align)
+        a, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 3.0, align=align, generation="quad")
+        b, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 3.0, align=align, generation="quad")
+        assert np.array_equal(a, b)                      # no races, no atomics: bitwise reproducible
+        assert np.abs(a - want).max() < 1e-5 * max(10.0, float(want.max()))
+
+
+def test_costvol_generation_errors():
+    """An explicit generation that does not support the shape is refused (NRGBD_E_SHAPE), never substituted."""
+    from neuralrgbd_amd import _lib
+    h, w, D, V, C = 16, 16, 4, 2, 11
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(1)
+    feat_ref = rng.standard_normal((C, h, w)).astype(np.float32)
+    feat_src = rng.standard_normal((V, C, h, w)).astype(np.float32)
+    poses = synth.random_poses(rng, V)
+    KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+    with pytest.raises(_lib.NrgbdError):
+        _gpu_costvol(feat_ref, feat_src, KR, Kt, cam["unit_ray_array_2D"].numpy(), np.linspace(.1, 5, D), 8.0, 8.0, 10.0,
+                     generation="quad")

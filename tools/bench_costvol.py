@@ -38,8 +38,7 @@ def main():
     ap.add_argument("--only", default=None, help="costvol|pack|warpvol|resample|softmax")
     ap.add_argument("--dslice", default=None, help="a:b — keep only candidates a..b-1 of the depth set (experiments)")
     args = ap.parse_args()
-    if args.gen:
-        os.environ["NRGBD_COSTVOL"] = args.gen
+    gen = args.gen
     from neuralrgbd_amd import camera, ops, synth
     from neuralrgbd_amd import homography as H
     h, w, D = GRIDS[args.config]
@@ -65,9 +64,9 @@ def main():
     runs = {
         "pack": (lambda: ops.pack_nhwc(feats, frames), 4 * ((V + 1) * 64 * hw + (V + 1) * 3 * 16 * hw + (V + 1) * 68 * hw)),
         "costvol": (lambda: ops.costvol(tex[V], tex[:V], KR, Kt, rays, d_dev, cx, cy, 10.0, C, want_cost=True,
-                                        want_logp=False), 4 * ((V + 1) * C * hw + D * hw)),
+                                        want_logp=False, generation=gen), 4 * ((V + 1) * C * hw + D * hw)),
         "costvol+logsoftmax": (lambda: ops.costvol(tex[V], tex[:V], KR, Kt, rays, d_dev, cx, cy, 10.0, C,
-                                                   want_cost=False, want_logp=True), 4 * ((V + 1) * C * hw + D * hw)),
+                                                   want_cost=False, want_logp=True, generation=gen), 4 * ((V + 1) * C * hw + D * hw)),
         "warpvol": (lambda: ops.warp_volume(tex[:V, :, :, 64:], (hw * 68, 1, w * 68, 68), tex[V, :, :, 64:],
                                             (1, w * 68, 68), KR, Kt, rays, d_dev, cx, cy, V, 3, h, w, bv_cur=bv, bv_pred=bv),
                     4 * ((V + 1) * 3 * hw + 2 * D * hw + 16 * D * hw)),
