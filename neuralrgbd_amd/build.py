@@ -49,6 +49,17 @@ def _compile(src, verbose):
     return obj
 
 
+def build_dev(verbose=False):
+    """Developer variant libnrgbd_hip_dev.so (-DNRGBD_DEV: ablation bits and tile-order switches honoured, read from the
+    environment).  Used only by tools/ for kernel analysis; never loaded by the package."""
+    lib = os.path.join(CSRC, "libnrgbd_hip_dev.so")
+    cmd = [HIPCC] + FLAGS + ["-DNRGBD_DEV", "-I", INCLUDE] + sources() + ["-o", lib]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return lib
+
+
 def build(force=False, verbose=False):
     """Per-file objects (compiled in parallel, re-used when unchanged) linked into libnrgbd_hip.so."""
     if not force and not stale():
@@ -69,4 +80,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--dev" in sys.argv:
+        print(build_dev(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -38,8 +38,7 @@ namespace nrgbd {
 namespace {
 
 constexpr int kQT = 8;            // tile edge
-constexpr int kQRun = 8;          // candidates per staged run (two groups of 4)
-constexpr int kQMaxV = 8;         // views whose boxes fit the scratch (more views -> generation 2)
+constexpr int kQRun = 16;         // candidates per staged run (groups of 4)
 constexpr int kQPatch = 192;      // texels of the patch (x 272 B = 51 KB): 3 workgroups per CU
 constexpr int kQFeatBytes = 256;  // feature plane: 16 words of 16 B per texel
 
@@ -161,7 +160,6 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsF = smem;                                                  // [kQPatch][256 B]
     char* ldsR = smem + kQPatch * kQFeatBytes;                          // [kQPatch][16 B]
-    int* bb = reinterpret_cast<int*>(ldsR + kQPatch * 16);              // [kQRun][kQMaxV][4] boxes, [.][.][0] = INT_MAX: unbounded
     float* red = reinterpret_cast<float*>(smem);                        // softmax scratch (the patch is dead by then)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -305,98 +303,98 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
     using T_ = std::true_type; using F_ = std::false_type;
     using N2 = std::integral_constant<int, 2>; using N4 = std::integral_constant<int, 4>;
 
-    for (int j0 = kb; j0 < ke;) {
-        // ---- footprints of the next <= 8 candidates in every view (threads 0 .. 8V-1) ----
-        const int nmax = min(kQRun, ke - j0);
-        __syncthreads();   // previous run's readers of bb / the patch are done
-        if (tid < kQRun * a.V) {
-            const int c = tid / a.V, v = tid - c * a.V;
-            QBox o{0, 1, 0, 1};
-            bool ok = true;
-            if (c < nmax) ok = tile_box(a, a.KR + 9 * v, a.Kt + 3 * v, a.d_candi[j0 + c], tx0, tx1, ty0, ty1, o);
-            int* b4 = bb + (c * kQMaxV + v) * 4;
-            b4[0] = ok ? o.xlo : 0x7fffffff; b4[1] = o.xhi; b4[2] = o.ylo; b4[3] = o.yhi;
-        }
-        __syncthreads();
-        // largest run n in {8, 4, 2} whose united footprint fits the patch in EVERY view (block-uniform)
-        int n = 0;
-        for (int tryn = kQRun; tryn >= 2 && n == 0; tryn >>= 1) {
-            if (tryn > nmax) continue;
-            bool fits = true;
-            for (int v = 0; v < a.V && fits; ++v) {
-                int xlo = 1 << 30, xhi = -(1 << 30), ylo = 1 << 30, yhi = -(1 << 30);
-                for (int c = 0; c < tryn; ++c) {
-                    const int* b4 = bb + (c * kQMaxV + v) * 4;
-                    const int b0 = __builtin_amdgcn_readfirstlane(b4[0]);
-                    if (b0 == 0x7fffffff) { fits = false; break; }
-                    xlo = min(xlo, b0); xhi = max(xhi, __builtin_amdgcn_readfirstlane(b4[1]));
-                    ylo = min(ylo, __builtin_amdgcn_readfirstlane(b4[2])); yhi = max(yhi, __builtin_amdgcn_readfirstlane(b4[3]));
-                }
-                fits = fits && (long)(xhi - xlo + 1) * (yhi - ylo + 1) <= kQPatch;
+    // Loop order: views OUTER.  All workgroups of an XCD (one band of tiles) sweep the same source view at about the same
+    // time, so the band's footprint in ONE view (~2 MB) is what has to live in the 4 MB L2 — with the views inside the
+    // candidate loop it would be all V of them (~9 MB) and every patch fill would go to the fabric.  The price is that a
+    // candidate's cost is accumulated across views in memory: out[k][p] is written for view 0 and read-modify-written by
+    // the same quad for the others (L2-resident, 4 B per (pixel, candidate, view)).
+    for (int v = 0; v < a.V; ++v) {
+        const float* KRv = a.KR + 9 * v;
+        const float* Ktv = a.Kt + 3 * v;
+        const float* sv = a.src + (size_t)v * hw * a.Cp;
+        const SweepTerm st = make_sweep_term(KRv, Ktv, rx, ry, rz);
+        for (int j0 = kb; j0 < ke;) {
+            // ---- footprints of the next <= 16 candidates in this view: lane c of EVERY wave computes candidate j0 + c
+            // (redundantly per wave: no LDS, no barrier), an inclusive prefix union over the lanes gives the footprint of
+            // the first 2 / 4 / 8 / 16 candidates ----
+            const int nmax = min(kQRun, ke - j0);
+            int bxlo = 1 << 30, bxhi = -(1 << 30), bylo = 1 << 30, byhi = -(1 << 30), bad = 0;
+            if (lane < nmax) {
+                QBox o{0, 1, 0, 1};
+                const bool ok = tile_box(a, KRv, Ktv, a.d_candi[j0 + lane], tx0, tx1, ty0, ty1, o);
+                bxlo = o.xlo; bxhi = o.xhi; bylo = o.ylo; byhi = o.yhi; bad = ok ? 0 : 1;
             }
-            if (fits) n = tryn;
-        }
-        const bool staged = n >= 2 && !NRGBD_DBG(a, 1);
-        if (!staged) n = min(4, nmax);                         // one group straight from global memory
-        const int ngroups = (n + 3) >> 2;
-
-        float tot[2] = {0.f, 0.f};
-        for (int v = 0; v < a.V; ++v) {
-            const float* KRv = a.KR + 9 * v;
-            const float* Ktv = a.Kt + 3 * v;
-            const float* sv = a.src + (size_t)v * hw * a.Cp;
-            const SweepTerm st = make_sweep_term(KRv, Ktv, rx, ry, rz);
-            float acc[2] = {0.f, 0.f};
-            if (staged) {
-                int xlo = 1 << 30, xhi = -(1 << 30), ylo = 1 << 30, yhi = -(1 << 30);
-                for (int c = 0; c < n; ++c) {
-                    const int* b4 = bb + (c * kQMaxV + v) * 4;
-                    xlo = min(xlo, __builtin_amdgcn_readfirstlane(b4[0])); xhi = max(xhi, __builtin_amdgcn_readfirstlane(b4[1]));
-                    ylo = min(ylo, __builtin_amdgcn_readfirstlane(b4[2])); yhi = max(yhi, __builtin_amdgcn_readfirstlane(b4[3]));
+#pragma unroll
+            for (int sh = 1; sh < kQRun; sh <<= 1) {
+                const int uxlo = __shfl_up(bxlo, sh, kQRun), uxhi = __shfl_up(bxhi, sh, kQRun);
+                const int uylo = __shfl_up(bylo, sh, kQRun), uyhi = __shfl_up(byhi, sh, kQRun);
+                const int ubad = __shfl_up(bad, sh, kQRun);
+                if ((lane & (kQRun - 1)) >= sh) {
+                    bxlo = min(bxlo, uxlo); bxhi = max(bxhi, uxhi); bylo = min(bylo, uylo); byhi = max(byhi, uyhi); bad |= ubad;
                 }
-                const int cols = xhi - xlo + 1, area = cols * (yhi - ylo + 1);
-                const unsigned magic = 0xFFFFFFFFu / (unsigned)cols + 1u;      // q / cols for q < 2^16, cols >= 2
-                if (v > 0) __syncthreads();                    // the previous view's taps have been read
-                // ---- stage: HBM/L2 -> LDS without touching VGPRs; a wave instruction = 4 texels x 256 B (feature plane)
-                // or 64 texels x 16 B (RGB plane), landing in lane order = patch order ----
+            }
+            int n = 0, xlo = 0, xhi = 1, ylo = 0, yhi = 1;
+#pragma unroll
+            for (int tryn = kQRun; tryn >= 2; tryn >>= 1) {
+                const int l = tryn - 1;       // lane holding the union of candidates 0 .. tryn-1
+                const int uxlo = __builtin_amdgcn_readlane(bxlo, l), uxhi = __builtin_amdgcn_readlane(bxhi, l);
+                const int uylo = __builtin_amdgcn_readlane(bylo, l), uyhi = __builtin_amdgcn_readlane(byhi, l);
+                const int ubad = __builtin_amdgcn_readlane(bad, l);
+                if (n == 0 && tryn <= nmax && !ubad && (long)(uxhi - uxlo + 1) * (uyhi - uylo + 1) <= kQPatch) {
+                    n = tryn; xlo = uxlo; xhi = uxhi; ylo = uylo; yhi = uyhi;
+                }
+            }
+            const bool staged = n >= 2 && !NRGBD_DBG(a, 1);
+            if (!staged) n = min(4, nmax);                     // one group straight from global memory
+            const int ngroups = (n + 3) >> 2;
+            const int cols = xhi - xlo + 1;
+
+            if (staged) {
+                const int area = cols * (yhi - ylo + 1);
+                const float inv_cols = 1.0f / (float)cols;     // q / cols = (int)((q + 0.5) * inv_cols): exact for q, cols <= 192
+                const int cpb = a.Cp * 4;
+                const char* svb = reinterpret_cast<const char*>(sv);
+                __syncthreads();                               // the previous patch has been read by every wave
+                // ---- stage: L2 -> LDS without touching VGPRs; a wave instruction = 4 texels x 256 B (feature plane) or
+                // 64 texels x 16 B (RGB plane), landing in lane order = patch order ----
                 for (int it = wave; it * 4 < area; it += 4) {
                     const int q = min(it * 4 + (lane >> 4), area - 1);
-                    const int qy = (int)__umulhi((unsigned)q, magic), qx = q - qy * cols;
+                    const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
                     const int gx = min(max(xlo + qx, 0), a.w - 1), gy = min(max(ylo + qy, 0), a.h - 1);
-                    const float* g = sv + ((size_t)gy * a.w + gx) * a.Cp + (lane & 15) * 4;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),
+                    const unsigned off = (unsigned)((gy * a.w + gx) * cpb + (lane & 15) * 16);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
                                                      (__attribute__((address_space(3))) void*)(ldsF + it * 4 * kQFeatBytes),
                                                      16, 0, 0);
                 }
                 if constexpr (EXTRA) {
                     for (int it = wave; it * 64 < area; it += 4) {
                         const int q = min(it * 64 + lane, area - 1);
-                        const int qy = (int)__umulhi((unsigned)q, magic), qx = q - qy * cols;
+                        const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
                         const int gx = min(max(xlo + qx, 0), a.w - 1), gy = min(max(ylo + qy, 0), a.h - 1);
-                        const float* g = sv + ((size_t)gy * a.w + gx) * a.Cp + 64;
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g),
+                        const unsigned off = (unsigned)((gy * a.w + gx) * cpb + kQFeatBytes);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
                                                          (__attribute__((address_space(3))) void*)(ldsR + it * 64 * 16),
                                                          16, 0, 0);
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (!NRGBD_DBG(a, 2)) {
-                    if (n == 2) acc[0] = group(T_{}, N2{}, sv, st, j0, 2, xlo, xhi, ylo, yhi, cols);
-                    else acc[0] = group(T_{}, N4{}, sv, st, j0, 4, xlo, xhi, ylo, yhi, cols);
-                    if (ngroups > 1) acc[1] = group(T_{}, N4{}, sv, st, j0 + 4, 4, xlo, xhi, ylo, yhi, cols);
-                }
-            } else {
-                acc[0] = group(F_{}, N4{}, sv, st, j0, n, 0, 0, 0, 0, 0);
             }
-            tot[0] = tot[0] + acc[0] / a.sigma;                // homography.py:325, views in order
-            tot[1] = tot[1] + acc[1] / a.sigma;
+            if (!NRGBD_DBG(a, 2)) {
+#pragma unroll 1
+                for (int g = 0; g < ngroups; ++g) {
+                    const int k0 = j0 + 4 * g, nc = min(4, n - 4 * g);
+                    float* o = out + (size_t)min(k0 + j, a.D - 1) * hw + p;
+                    const float prev = (v > 0) ? *o : 0.f;     // this quad's own store of the previous view
+                    float acc;
+                    if (!staged) acc = group(F_{}, N4{}, sv, st, k0, nc, 0, 0, 0, 0, 0);
+                    else if (nc == 2) acc = group(T_{}, N2{}, sv, st, k0, 2, xlo, xhi, ylo, yhi, cols);
+                    else acc = group(T_{}, N4{}, sv, st, k0, 4, xlo, xhi, ylo, yhi, cols);
+                    if (inside && j < nc) *o = prev + acc / a.sigma;   // homography.py:325, views in order
+                }
+            }
+            j0 += n;
         }
-        if (inside) {
-            if (j < n) out[(size_t)(j0 + j) * hw + p] = tot[0];
-            if (4 + j < n) out[(size_t)(j0 + 4 + j) * hw + p] = tot[1];
-        }
-        j0 += n;
     }
 
     if (!a.fuse_softmax) return;
@@ -443,7 +441,7 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
 bool costvol_quad_supported(const CostvolArgs& a) {
     const bool extra = a.Cp == 68 && a.C > 64;
     const bool plain = a.Cp == 64 && a.C == 64;
-    return (extra || plain) && a.V <= kQMaxV;
+    return (extra || plain) && (long)a.h * a.w * a.Cp * 4 < (1L << 31);   // 32-bit byte offsets into a view
 }
 
 // Returns NRGBD_OK and sets *did_softmax when the launch also produced out_logp.
@@ -458,7 +456,7 @@ int launch_costvol_quad(const CostvolArgs& args, hipStream_t stream, bool* did_s
     a.kchunk = ceil_div(a.D, nchunk);
     a.fuse_softmax = (nchunk == 1 && a.out_logp != nullptr && a.D <= 128) ? 1 : 0;
     *did_softmax = a.fuse_softmax != 0;
-    const size_t lds = (size_t)kQPatch * (kQFeatBytes + 16) + kQRun * kQMaxV * 4 * sizeof(int);
+    const size_t lds = (size_t)kQPatch * (kQFeatBytes + 16);
     const dim3 grid(tiles * nchunk);
     const bool extra = a.Cp == 68;
 #define NRGBD_QUAD_LAUNCH(DIST, EX) hipLaunchKernelGGL((costvol_quad<DIST, EX>), grid, dim3(256), lds, stream, a)

@@ -44,15 +44,18 @@ def set_threads(n):
 
 
 def homography_terms(K, R, t):
-    """(K R_v) and K t_v exactly as the reference computes them on CPU: torch `IntM.matmul(R[v])` and
-    `IntM.matmul(t[v])` (homography.py:315-317) — the summation order of these K=3 contractions is torch's."""
-    import torch
-    K = torch.from_numpy(np.ascontiguousarray(K, dtype=np.float32))
-    R = torch.from_numpy(np.ascontiguousarray(np.asarray(R, np.float32).reshape(-1, 3, 3)))
-    t = torch.from_numpy(np.ascontiguousarray(np.asarray(t, np.float32).reshape(-1, 3)))
-    KR = torch.stack([K.matmul(R[v]) for v in range(R.shape[0])]).numpy()
-    Kt = torch.stack([K.matmul(t[v]) for v in range(R.shape[0])]).numpy()
-    return KR.reshape(-1, 9), Kt
+    """(K R_v) [V,9] and K t_v [V,3] in the summation order of the reference's CPU matmuls (homography.py:315-317),
+    written out in C (oracle_homography_terms) so that the result does not depend on the host's BLAS kernels."""
+    k, pk = _f(np.asarray(K, np.float32).reshape(3, 3))
+    r, pr = _f(np.asarray(R, np.float32).reshape(-1, 3, 3))
+    tt, pt = _f(np.asarray(t, np.float32).reshape(-1, 3))
+    V = r.shape[0]
+    KR = np.empty((V, 9), np.float32)
+    Kt = np.empty((V, 3), np.float32)
+    rc = lib().oracle_homography_terms(pk, pr, pt, V, KR.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                       Kt.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    assert rc == 0
+    return KR, Kt
 
 
 def costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, sigma, dist="L2",

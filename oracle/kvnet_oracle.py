@@ -100,11 +100,8 @@ def rnet(sd, p, dpv, feats):
 
 # ----------------------------------------------------------------------------- geometry
 def _terms(cam, poses):
-    K = cam["intrinsic_M_cuda"]
-    R, t = poses[:, :3, :3], poses[:, :3, 3]
-    KR = torch.stack([K.matmul(R[v]) for v in range(R.shape[0])]).reshape(-1, 9).numpy()   # homography.py:317
-    Kt = torch.stack([K.matmul(t[v]) for v in range(R.shape[0])]).numpy()                  # homography.py:315
-    return KR, Kt
+    """homography.py:315-317 (term1 = K t, left factor K R of term2) in the reference's CPU summation order."""
+    return co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3].numpy(), poses[:, :3, 3].numpy())
 
 
 def dnet(sd, ref, src, poses, cam, d_candi, sigma, feat_dist="L2"):

@@ -34,6 +34,26 @@ int oracle_set_threads(int n) {
 #endif
 }
 
+/* warping/homography.py:315-317: term1 = IntM.matmul(t_v), left factor IntM.matmul(R_v) of term2.  The order of these
+ * K = 3 contractions is the one torch 2.10's CPU kernels execute in the build container where the golden vectors were
+ * generated (checked against the live reference by tests/test_oracle_vs_reference.py): sgemm = fma chain over k,
+ * 3-element sgemv = (p1 + p2) + p0 with separately rounded products.  Written out so that it is the same on every host. */
+int oracle_homography_terms(const float* K, const float* R, const float* t, int V, float* KR, float* Kt) {
+    for (int v = 0; v < V; ++v) {
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) {
+                float s = K[3 * r] * R[9 * v + c];
+                s = fmaf(K[3 * r + 1], R[9 * v + 3 + c], s);
+                s = fmaf(K[3 * r + 2], R[9 * v + 6 + c], s);
+                KR[9 * v + 3 * r + c] = s;
+            }
+            float p0 = K[3 * r] * t[3 * v], p1 = K[3 * r + 1] * t[3 * v + 1], p2 = K[3 * r + 2] * t[3 * v + 2];
+            Kt[3 * v + r] = (p1 + p2) + p0;
+        }
+    }
+    return 0;
+}
+
 /* ATen GridSampler.h grid_sampler_unnormalize */
 static inline float unnormalize(float g, int size, int align_corners) {
     if (align_corners) return ((g + 1.f) / 2.f) * (float)(size - 1);

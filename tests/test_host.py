@@ -117,26 +117,3 @@ def test_spp_autograd_forms_match_torch_ops():
         a = d[:, :, :ph * k, :pw * k].reshape(2, 3, ph, k, pw, k).mean((3, 5))
         b = F.avg_pool2d(d, (k, k), stride=(k, k))
         assert a.shape == b.shape and (a - b).abs().max().item() < 1e-6
-
-
-def test_homography_terms_order():
-    """csrc/geom.hip computes K R_v as an fma chain over k and K t_v as (p1 + p2) + p0: the orders torch's CPU matmul
-    uses for these shapes (what the reference executes, homography.py:315-317).  Restated in numpy here and checked
-    against torch, so a torch upgrade that changes the order is noticed."""
-    import numpy as np
-    import torch
-    f32 = np.float32
-
-    def fma(a, b, c):
-        return f32(np.float64(a) * np.float64(b) + np.float64(c))   # the fp32 product is exact in fp64: one rounding
-    rng = np.random.RandomState(0)
-    for _ in range(200):
-        K = (rng.standard_normal((3, 3)) * 100).astype(f32)
-        R = rng.standard_normal((3, 3)).astype(f32)
-        t = rng.standard_normal(3).astype(f32)
-        KR = torch.from_numpy(K).matmul(torch.from_numpy(R)).numpy()
-        Kt = torch.from_numpy(K).matmul(torch.from_numpy(t)).numpy()
-        for i in range(3):
-            for j in range(3):
-                assert fma(K[i, 2], R[2, j], fma(K[i, 1], R[1, j], f32(K[i, 0] * R[0, j]))) == KR[i, j]
-            assert f32(f32(f32(K[i, 1] * t[1]) + f32(K[i, 2] * t[2])) + f32(K[i, 0] * t[0])) == Kt[i]

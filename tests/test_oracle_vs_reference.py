@@ -63,3 +63,18 @@ def test_state_dict_keys_match_live_reference():
     a = {k: tuple(v.shape) for k, v in m_ref.state_dict().items()}
     b = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
     assert a == b and len(a) == 459
+
+
+def test_homography_terms_order_is_what_torch_cpu_executes_here():
+    """oracle_homography_terms / csrc/geom.hip write out the order torch's CPU kernels use for IntM.matmul(R_v) and
+    IntM.matmul(t_v) IN THIS CONTAINER (where the golden vectors come from).  Other hosts' BLAS kernels may order a K=3
+    contraction differently (the MI355X node's does), which is why the order is pinned in code rather than delegated."""
+    rng = np.random.RandomState(0)
+    cam = camera.scannet_intrinsics(96, 64)
+    K = cam["intrinsic_M_cuda"]
+    for _ in range(50):
+        poses = torch.from_numpy(synth.random_poses(rng, 4, rot_sigma=0.3, trans_sigma=0.5))
+        KR, Kt = co.homography_terms(K.numpy(), poses[:, :3, :3].numpy(), poses[:, :3, 3].numpy())
+        want_KR = torch.stack([K.matmul(poses[v, :3, :3]) for v in range(4)]).reshape(4, 9).numpy()
+        want_Kt = torch.stack([K.matmul(poses[v, :3, 3]) for v in range(4)]).numpy()
+        assert np.array_equal(KR, want_KR) and np.array_equal(Kt, want_Kt)
