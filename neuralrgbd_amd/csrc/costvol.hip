@@ -172,7 +172,8 @@ extern "C" int nrgbd_costvol_fwd_gen(const float* ref_nhwc, const float* src_nhw
     if (dist != NRGBD_DIST_L2 && dist != NRGBD_DIST_L1) return NRGBD_E_ARG;
     if (generation < NRGBD_GEN_AUTO || generation > NRGBD_GEN_QUAD) return NRGBD_E_ARG;
     CostvolArgs a{ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, out_cost, out_logp, cx, cy, sigma,
-                  dist, align_corners, V, C, Cp, D, h, w, 0, 0, 1, D, 0};
+                  dist, align_corners, V, C, Cp, D, h, w, 0, 0, 1, D, 0,
+                  (float)(1.0 / (double)cx), (float)(1.0 / (double)cy), (float)(1.0 / (double)sigma)};
 #ifdef NRGBD_DEV
     a.debug = dev_env_int("NRGBD_ABLATE");
 #endif

@@ -20,6 +20,7 @@ struct CostvolArgs {
     int debug;             // developer bits, honoured only in -DNRGBD_DEV builds (env NRGBD_ABLATE): 1 = no staging, 2 = no math, 4 = XCD-owned tile order, 8 = singles on any grid, (g+1)<<8 = run candidate group g only
     int nchunk, kchunk;    // quad generation: candidate chunks per tile / candidates per chunk (set by the launcher)
     int fuse_softmax;      // quad generation: the workgroup owns all D candidates and also writes out_logp
+    float rcx, rcy, rsigma;  // quad generation: RN(1/cx), RN(1/cy), RN(1/sigma) (host, double precision) for div_by_const
 };
 
 // Developer ablation bits are compiled out of the product library: a stray environment variable must never change results.

@@ -144,3 +144,50 @@ def avgpool(img, pool):
     rc = lib().oracle_avgpool(pa, N, C, H, W, pool, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     assert rc == 0
     return out
+
+
+def export_depth_u16(logp, d_candi, depth_scale=1000.0, conf_scale=1000.0):
+    """export_res_img (export_res.py:43-75): -> (depth f32, conf f32 = exp(max logp), depth_u16, conf_u16)."""
+    lp, plp = _f(logp); dc, pdc = _f(d_candi)
+    D = lp.shape[0]
+    n = lp.size // D
+    depth = np.empty(lp.shape[1:], np.float32); conf = np.empty(lp.shape[1:], np.float32)
+    du = np.empty(lp.shape[1:], np.uint16); cu = np.empty(lp.shape[1:], np.uint16)
+    rc = lib().oracle_export_depth_u16(plp, pdc, D, ctypes.c_size_t(n), ctypes.c_float(depth_scale), ctypes.c_float(conf_scale),
+                                       depth.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                       conf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                       du.ctypes.data_as(ctypes.POINTER(ctypes.c_ushort)),
+                                       cu.ctypes.data_as(ctypes.POINTER(ctypes.c_ushort)))
+    assert rc == 0
+    return depth, conf, du, cu
+
+
+def warp_depth_fwd(src, dmap, K, R, t, rays):
+    """back_warp_th_Rt_msrc: src [N,C,H,W], dmap [H,W], K [3,3], R [N,3,3], t [N,3], rays [3,HW] -> [N,C,H,W]."""
+    s_, ps = _f(src); d_, pd = _f(dmap); k_, pk = _f(K); r_, pr = _f(np.asarray(R, np.float32).reshape(-1, 9))
+    t_, pt = _f(np.asarray(t, np.float32).reshape(-1, 3)); y_, py = _f(rays)
+    N, C, H, W = s_.shape
+    out = np.empty_like(s_)
+    rc = lib().oracle_warp_depth_fwd(ps, pd, pk, pr, pt, py, N, C, H, W, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    assert rc == 0
+    return out
+
+
+def warp_depth_bwd(src, dmap, K, R, t, rays, g_out):
+    """d sum(out * g_out) / d(R, t) of warp_depth_fwd -> (g_R [N,3,3], g_t [N,3])."""
+    s_, ps = _f(src); d_, pd = _f(dmap); k_, pk = _f(K); r_, pr = _f(np.asarray(R, np.float32).reshape(-1, 9))
+    t_, pt = _f(np.asarray(t, np.float32).reshape(-1, 3)); y_, py = _f(rays); g_, pg = _f(g_out)
+    N, C, H, W = s_.shape
+    gR = np.empty((N, 3, 3), np.float32); gt = np.empty((N, 3), np.float32)
+    rc = lib().oracle_warp_depth_bwd(ps, pd, pk, pr, pt, py, pg, N, C, H, W,
+                                     gR.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                     gt.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    assert rc == 0
+    return gR, gt
+
+
+def div_const_mismatches(c, stride=1):
+    """Dividends for which the kernels' 3-instruction division by the constant c differs from IEEE a / c (must be 0)."""
+    f = lib().oracle_div_const_mismatches
+    f.restype = ctypes.c_long
+    return int(f(ctypes.c_float(c), ctypes.c_long(stride)))

@@ -303,3 +303,149 @@ int oracle_avgpool(const float* img, int N, int C, int H, int W, int pool, float
             }
     return 0;
 }
+
+/* test_utils/export_res.py:43-75 export_res_img: expected depth (sum_k exp(BV_k) d_k), confidence exp(max_k BV_k) and the
+ * two uint16 maps the .pgm files hold: (map * scale).astype(np.uint16) = truncation toward zero of the fp32 product
+ * (values outside [0, 65535], which the reference's ranges never produce, are clamped here to keep the cast defined). */
+static inline unsigned short to_u16(float v) {
+    if (!(v > 0.f)) return 0;
+    if (v >= 65535.f) return 65535;
+    return (unsigned short)v;
+}
+int oracle_export_depth_u16(const float* logp, const float* d_candi, int D, size_t n, float depth_scale,
+                            float conf_scale, float* depth, float* conf, unsigned short* depth_u16,
+                            unsigned short* conf_u16) {
+    for (size_t p = 0; p < n; ++p) {
+        float acc = 0.f, m = -INFINITY;
+        for (int k = 0; k < D; ++k) {
+            float v = logp[(size_t)k * n + p];
+            acc = acc + expf(v) * d_candi[k];
+            m = v > m ? v : m;
+        }
+        float c = expf(m);
+        if (depth) depth[p] = acc;
+        if (conf) conf[p] = c;
+        if (depth_u16) depth_u16[p] = to_u16(acc * depth_scale);
+        if (conf_u16) conf_u16[p] = to_u16(c * conf_scale);
+    }
+    return 0;
+}
+
+/*
+ * warping/homography.py:479-528 back_warp_th_Rt_msrc (and :530-575 back_warp_th_Rt, its single-view form): warp N source
+ * images to the reference view through a per-pixel DEPTH MAP (not planes) and the rigid motions (R_n, t_n); caller
+ * ICP/opt_pose_numerical.py:245-294 (local bundle adjustment) differentiates the result w.r.t. R_n and t_n.
+ *   X = dmap[p] * ray_p;  Y = R_n X + t_n (the 4x4 [R t; 0 1] matmul: fma chain over k = 0..3);  P = K Y (4x4 with a zero
+ *   last row/column: fma chain over k = 0..2, the k = 3 term adds 0);  P /= P_z (no epsilon here, :510);
+ *   g = (u - cx)/cx, (v - cy)/cy with cx, cy from the fp32 intrinsic_M_cuda (:491);  F.grid_sample(bilinear, zeros,
+ *   align_corners default False).
+ *   src [N][C][H][W], dmap [HW], K [9], R [N][9], t [N][3], rays [3][HW] -> out [N][C][H][W]
+ */
+static inline void depth_warp_coords(const float* K, const float* R, const float* t, float rx, float ry, float rz, float d,
+                                     int W, int H, float* X, float* Y, float* P, float* ix, float* iy) {
+    X[0] = d * rx; X[1] = d * ry; X[2] = d * rz;
+    for (int i = 0; i < 3; ++i) {
+        float s = R[3 * i] * X[0];
+        s = fmaf(R[3 * i + 1], X[1], s);
+        s = fmaf(R[3 * i + 2], X[2], s);
+        Y[i] = fmaf(t[i], 1.0f, s);
+    }
+    for (int i = 0; i < 3; ++i) {
+        float s = K[3 * i] * Y[0];
+        s = fmaf(K[3 * i + 1], Y[1], s);
+        s = fmaf(K[3 * i + 2], Y[2], s);
+        P[i] = s;
+    }
+    float u = P[0] / P[2], v = P[1] / P[2];
+    float cx = K[2], cy = K[5];
+    float gx = (u - cx) / cx, gy = (v - cy) / cy;
+    *ix = unnormalize(gx, W, 0);
+    *iy = unnormalize(gy, H, 0);
+}
+
+int oracle_warp_depth_fwd(const float* src, const float* dmap, const float* K, const float* R, const float* t,
+                          const float* rays, int N, int C, int H, int W, float* out) {
+    size_t hw = (size_t)H * W;
+#pragma omp parallel for schedule(static)
+    for (long np_ = 0; np_ < (long)N * (long)hw; ++np_) {
+        int n = (int)(np_ / (long)hw);
+        size_t p = (size_t)(np_ - (long)n * (long)hw);
+        float X[3], Y[3], P[3], ix, iy;
+        depth_warp_coords(K, R + 9 * n, t + 3 * n, rays[p], rays[hw + p], rays[2 * hw + p], dmap[p], W, H, X, Y, P, &ix, &iy);
+        taps2d tp;
+        bilinear_taps(ix, iy, W, H, &tp);
+        for (int c = 0; c < C; ++c) {
+            const float* pl = src + ((size_t)n * C + c) * hw;
+            float s = 0.f;
+            for (int j = 0; j < 2; ++j)
+                for (int i = 0; i < 2; ++i)
+                    if (tp.vx[i] && tp.vy[j]) s = s + pl[(size_t)tp.y[j] * W + tp.x[i]] * (tp.wx[i] * tp.wy[j]);
+            out[((size_t)n * C + c) * hw + p] = s;
+        }
+    }
+    return 0;
+}
+
+/* Gradient of sum(out * g_out) w.r.t. R_n and t_n (what torch autograd returns for the reference's graph: grid_sample's
+ * bilinear backward w.r.t. the grid — ATen grid_sampler_2d_backward: taps outside the image contribute nothing, the
+ * un-normalisation contributes W/2, H/2 — chained through the two divisions and the two matmuls).  Accumulated in double. */
+int oracle_warp_depth_bwd(const float* src, const float* dmap, const float* K, const float* R, const float* t,
+                          const float* rays, const float* g_out, int N, int C, int H, int W, float* g_R, float* g_t) {
+    size_t hw = (size_t)H * W;
+    for (int n = 0; n < N; ++n) {
+        double aR[9] = {0}, at[3] = {0};
+        for (size_t p = 0; p < hw; ++p) {
+            float X[3], Y[3], P[3], ix, iy;
+            depth_warp_coords(K, R + 9 * n, t + 3 * n, rays[p], rays[hw + p], rays[2 * hw + p], dmap[p], W, H, X, Y, P, &ix, &iy);
+            taps2d tp;
+            bilinear_taps(ix, iy, W, H, &tp);
+            float x0 = floorf(ix), y0 = floorf(iy);
+            float fx = ix - x0, fy = iy - y0;
+            double gix = 0, giy = 0;
+            for (int c = 0; c < C; ++c) {
+                const float* pl = src + ((size_t)n * C + c) * hw;
+                float g = g_out[((size_t)n * C + c) * hw + p];
+                float v00 = (tp.vx[0] && tp.vy[0]) ? pl[(size_t)tp.y[0] * W + tp.x[0]] : 0.f;
+                float v01 = (tp.vx[1] && tp.vy[0]) ? pl[(size_t)tp.y[0] * W + tp.x[1]] : 0.f;
+                float v10 = (tp.vx[0] && tp.vy[1]) ? pl[(size_t)tp.y[1] * W + tp.x[0]] : 0.f;
+                float v11 = (tp.vx[1] && tp.vy[1]) ? pl[(size_t)tp.y[1] * W + tp.x[1]] : 0.f;
+                gix += (double)g * ((double)(v01 - v00) * (1.0 - fy) + (double)(v11 - v10) * fy);
+                giy += (double)g * ((double)(v10 - v00) * (1.0 - fx) + (double)(v11 - v01) * fx);
+            }
+            double cx = K[2], cy = K[5];
+            double du = gix * (W * 0.5) / cx, dv = giy * (H * 0.5) / cy;      /* d/du of ((g+1)W-1)/2 with g = (u-cx)/cx */
+            double pz = P[2];
+            double dP[3] = {du / pz, dv / pz, -(du * P[0] + dv * P[1]) / (pz * pz)};
+            double dY[3];
+            for (int i = 0; i < 3; ++i) dY[i] = K[i] * dP[0] + K[3 + i] * dP[1] + K[6 + i] * dP[2];   /* K^T dP */
+            for (int i = 0; i < 3; ++i) {
+                at[i] += dY[i];
+                for (int j2 = 0; j2 < 3; ++j2) aR[3 * i + j2] += dY[i] * X[j2];
+            }
+        }
+        for (int i = 0; i < 9; ++i) g_R[9 * n + i] = (float)aR[i];
+        for (int i = 0; i < 3; ++i) g_t[3 * n + i] = (float)at[i];
+    }
+    return 0;
+}
+
+/* Check of csrc/common.hpp::div_by_const (a / c for a loop-invariant c as q = a rc, r = fma(-q, c, a), q + r rc): number of
+ * finite fp32 dividends a (every `stride`-th bit pattern, |a| in [1e-30, 1e30] or 0) whose result differs from a / c. */
+long oracle_div_const_mismatches(float c, long stride) {
+    float rc = (float)(1.0 / (double)c);
+    long bad = 0;
+#pragma omp parallel for reduction(+:bad)
+    for (long b = 0; b < (1L << 32); b += stride) {
+        unsigned int u = (unsigned int)b;
+        float a;
+        __builtin_memcpy(&a, &u, 4);
+        if (!isfinite(a)) continue;
+        float fa = fabsf(a);
+        if (fa != 0.f && (fa < 1e-30f || fa > 1e30f)) continue;
+        float q = a * rc;
+        float r = fmaf(-q, c, a);
+        float q2 = fmaf(r, rc, q);
+        if (q2 != a / c) bad++;
+    }
+    return bad;
+}
