@@ -190,6 +190,35 @@ int nrgbd_depth_regress(const float* logp, const float* d_candi,
                         float* depth, float* conf, int D, long n, void* stream);
 
 /*
+ * nrgbd_export_depth_u16 — export epilogue of a (refined) log-DPV in one pass.
+ * Replaces: test_utils/export_res.py:43-75 export_res_img — a D-slice tensor of depth values, torch.sum(exp(BV) * vol),
+ * torch.max, two host round trips and `(map * scale).astype(np.uint16)` on the CPU.
+ *   logp [D][n]; d_candi [D]
+ *   depth [n] or NULL   sum_k exp(logp_k) d_k          conf [n] or NULL   exp(max_k logp_k)
+ *   depth_u16, conf_u16 [n] or NULL   (map * scale) truncated toward zero (numpy astype), clamped to [0, 65535]
+ */
+int nrgbd_export_depth_u16(const float* logp, const float* d_candi, float depth_scale, float conf_scale,
+                           float* depth, float* conf, unsigned short* depth_u16, unsigned short* conf_u16,
+                           int D, long n, void* stream);
+
+/*
+ * nrgbd_warp_depth_fwd / _bwd — photometric warp through a per-pixel depth map and its gradient w.r.t. the poses.
+ * Replaces: warping/homography.py:479-528 back_warp_th_Rt_msrc (N views) and :530-575 back_warp_th_Rt (N = 1), and the
+ * autograd graph ICP/opt_pose_numerical.py:245-294 differentiates (local bundle adjustment refines R_n, t_n).
+ *   src [N][C][H][W]; dmap [H][W]; K [3][3]; R [N][3][3]; t [N][3] (reference -> source n); rays [3][HW]
+ *   out [N][C][H][W]          out[n,c,p] = bilinear(src[n,c], K (R_n dmap[p] ray_p + t_n) / z), zeros padding
+ *   g_out [N][C][H][W]        upstream gradient
+ *   partial [N][nrgbd_warp_depth_bwd_workgroups(H, W)][12]   scratch (fixed-order reduction: reproducible)
+ *   g_R [N][3][3], g_t [N][3] d sum(out * g_out) / d(R_n, t_n)
+ */
+int nrgbd_warp_depth_fwd(const float* src, const float* dmap, const float* K, const float* R, const float* t,
+                         const float* rays, float* out, int N, int C, int H, int W, void* stream);
+int nrgbd_warp_depth_bwd_workgroups(int H, int W);
+int nrgbd_warp_depth_bwd(const float* src, const float* dmap, const float* K, const float* R, const float* t,
+                         const float* rays, const float* g_out, float* partial, float* g_R, float* g_t,
+                         int N, int C, int H, int W, void* stream);
+
+/*
  * K-Net: 3x3x3 convolution (stride 1, padding 1, no bias) on the fp32 matrix cores, with the
  * BatchNorm3d / ReLU / residual work of the reference fused around it.
  * Replaces, per layer of models/basic.py:71-94,113-132 (KV_NET_BASIC): nn.Conv3d + nn.BatchNorm3d

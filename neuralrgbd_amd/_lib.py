@@ -32,6 +32,10 @@ SIGNATURES = {
     "nrgbd_dpv_resample": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _I, _I, _P]),
     "nrgbd_logsoftmax_d": (_I, [_P, _P, _F, _P, _I, _L, _P]),
     "nrgbd_depth_regress": (_I, [_P, _P, _P, _P, _I, _L, _P]),
+    "nrgbd_export_depth_u16": (_I, [_P, _P, _F, _F, _P, _P, _P, _P, _I, _L, _P]),
+    "nrgbd_warp_depth_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "nrgbd_warp_depth_bwd_workgroups": (_I, [_I, _I]),
+    "nrgbd_warp_depth_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "nrgbd_conv3d_workgroups": (_I, [_I, _I, _I]),
     "nrgbd_conv3d_pack_weights": (_I, [_P, _P, _I, _P]),
     "nrgbd_conv3d_3x3x3_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -39,7 +39,8 @@ namespace {
 
 constexpr int kQT = 8;            // tile edge
 constexpr int kQRun = 16;         // candidates per staged run (groups of 4)
-constexpr int kQPatch = 192;      // texels of the patch (x 272 B = 51 KB): 3 workgroups per CU
+constexpr int kQPatch = 188;      // texels of the patch (x 272 B = 50 KB, + 20 B per candidate): 3 workgroups per CU
+constexpr int kQPatchR = 192;     // slots of the RGB plane (a wave instruction fills 64)
 constexpr int kQFeatBytes = 256;  // feature plane: 16 words of 16 B per texel
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -121,12 +122,16 @@ __device__ __forceinline__ float rgb_word(const f32x4 A, const f32x4 B, const f3
 
 }  // namespace
 
-// EXTRA: the texel has a 17th word (Cp = 68: channels 64..66 = pooled RGB); otherwise Cp = 64.
-template <int DIST, bool EXTRA>
+// TAIL: valid channels of the texel's 17th word (Cp = 68: channels 64..66 = pooled RGB => 3; -1 = a.C - 64 at run time);
+// 0 = no 17th word (Cp = 64).  ALIGN: grid_sample's align_corners.
+template <int DIST, int TAIL, bool ALIGN>
 __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
+    constexpr bool EXTRA = TAIL != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsF = smem;                                                  // [kQPatch][256 B]
-    char* ldsR = smem + kQPatch * kQFeatBytes;                          // [kQPatch][16 B]
+    char* ldsR = smem + kQPatch * kQFeatBytes;                          // [kQPatchR][16 B]
+    int4* boxes = reinterpret_cast<int4*>(ldsR + kQPatchR * 16);        // [D] footprint of the tile per candidate (this view)
+    float* dcand = reinterpret_cast<float*>(boxes + a.D);               // [D] depth candidates
     float* red = reinterpret_cast<float*>(smem);                        // softmax scratch (the patch is dead by then)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,8 +151,8 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
     const size_t hw = (size_t)a.h * a.w;
     const size_t p = (size_t)yc * a.w + xc;
     const float wf = (float)a.w, hf = (float)a.h;
-    const bool align = a.align != 0;
-    const int tail = a.C - 64;   // valid channels of the RGB word (EXTRA)
+    const int tail = TAIL >= 0 ? TAIL : a.C - 64;   // valid channels of the RGB word
+    for (int k = tid; k < a.D; k += 256) dcand[k] = a.d_candi[k];
 
     // per-lane word order: step s -> byte offset of word ((s + i3) & 3) * 4 + j inside a texel's feature plane
     int cofs[4];
@@ -167,15 +172,15 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
 
     // ---- evaluation of one group of NI <= 4 candidates (lane j owns candidate k0 + j) for one view --------------------------
     // STAGED: taps from the LDS patch (box xlo..: pitch = cols); otherwise straight from global memory.  The NI x 4
-    // (candidate, step) tap fetches run as one software pipeline, PD steps ahead of the math (LDS: 1, global memory: 3).
+    // (candidate, step) tap fetches run as one software pipeline, PD steps ahead of the math (LDS: 1, global memory: 2).
     auto group = [&](auto staged_c, auto ni_c, const float* sv, const SweepTerm& st, int k0, int ncand, int xlo, int xhi,
                      int ylo, int yhi, int cols) -> float {
         constexpr bool STAGED = decltype(staged_c)::value;
         constexpr int NI = decltype(ni_c)::value;
-        constexpr int PD = STAGED ? 1 : 3;
+        constexpr int PD = STAGED ? 1 : 2;
         const int kc = min(k0 + j, k0 + ncand - 1);          // lanes beyond the group repeat its last candidate
         float ix, iy, x0f, y0f;
-        sweep_sample_pos_rc(st, a.d_candi[kc], a.cx, a.cy, a.rcx, a.rcy, wf, hf, align, ix, iy);
+        sweep_sample_pos_fast<ALIGN>(st, dcand[kc], a.cx, a.cy, a.rcx, a.rcy, wf, hf, ix, iy);
         const TapW tw = tap_weights(ix, iy, wf, hf, x0f, y0f);
         // tap addresses: STAGED one patch address (apron => the 3 other taps are +256, +pitch, +pitch+256);
         // global: four clamped texel offsets
@@ -280,28 +285,25 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
         const float* Ktv = a.Kt + 3 * v;
         const float* sv = a.src + (size_t)v * hw * a.Cp;
         const SweepTerm st = make_sweep_term(KRv, Ktv, rx, ry, rz);
-        for (int j0 = kb; j0 < ke;) {
-            // ---- footprints of the next <= 16 candidates in this view: lane c of EVERY wave computes candidate j0 + c
-            // (redundantly per wave: no LDS, no barrier), an inclusive prefix union over the lanes gives the footprint of
-            // the first 2 / 4 / 8 / 16 candidates ----
-            const int nmax = min(kQRun, ke - j0);
-            // lane = 4 c + corner: the sampling position of ONE tile corner on candidate j0 + c (each wave redundantly, no
-            // LDS, no barrier); quad min/max = the candidate's footprint; prefix union over the candidates (lane stride 4)
-            float fxlo = INFINITY, fxhi = -INFINITY, fylo = INFINITY, fyhi = -INFINITY;
+        // ---- footprint of the tile on every candidate plane of this view: thread = (candidate, tile corner); the sampling
+        // positions of the 4 corner pixels bound the taps of the whole tile (a homography maps the convex tile onto a convex
+        // quadrilateral as long as the plane stays in front of the source camera: `bad` otherwise).  Box = their bounding
+        // box + 1 texel of slack, inside [-1, w] x [-1, h] (apron), at least 2 x 2 ----
+        __syncthreads();                                       // the previous view's boxes / the prologue's dcand
+        for (int c0 = kb; c0 < ke; c0 += 64) {
+            const int c = c0 + (tid >> 2), cr = tid & 3;
+            float fxlo = 0.f, fxhi = 0.f, fylo = 0.f, fyhi = 0.f;
             int bad = 0;
-            {
-                const int c = lane >> 2, cr = lane & 3;
-                if (c < nmax) {
-                    const int pxc = (cr & 1) ? tx1 : tx0, pyc = (cr & 2) ? ty1 : ty0;
-                    const size_t pc = (size_t)pyc * a.w + pxc;
-                    const SweepTerm sc = make_sweep_term(KRv, Ktv, a.rays[pc], a.rays[hw + pc], a.rays[2 * hw + pc]);
-                    const float dc = a.d_candi[j0 + c];
-                    const float den = (sc.t1z + sc.t2z * dc) + 1e-10f;
-                    float ix, iy;
-                    sweep_sample_pos_rc(sc, dc, a.cx, a.cy, a.rcx, a.rcy, wf, hf, align, ix, iy);
-                    bad = ((den > 0.f) && (fabsf(ix) < 1e8f) && (fabsf(iy) < 1e8f)) ? 0 : 1;
-                    fxlo = fxhi = ix; fylo = fyhi = iy;
-                }
+            if (c < ke) {
+                const int pxc = (cr & 1) ? tx1 : tx0, pyc = (cr & 2) ? ty1 : ty0;
+                const size_t pc = (size_t)pyc * a.w + pxc;
+                const SweepTerm sc = make_sweep_term(KRv, Ktv, a.rays[pc], a.rays[hw + pc], a.rays[2 * hw + pc]);
+                const float dc = dcand[c];
+                const float den = (sc.t1z + sc.t2z * dc) + 1e-10f;
+                float ix, iy;
+                sweep_sample_pos_fast<ALIGN>(sc, dc, a.cx, a.cy, a.rcx, a.rcy, wf, hf, ix, iy);
+                bad = ((den > 0.f) && (fabsf(ix) < 1e8f) && (fabsf(iy) < 1e8f)) ? 0 : 1;
+                fxlo = fxhi = ix; fylo = fyhi = iy;
             }
             fxlo = fminf(fxlo, dpp_f<kXor1>(fxlo)); fxhi = fmaxf(fxhi, dpp_f<kXor1>(fxhi));
             fylo = fminf(fylo, dpp_f<kXor1>(fylo)); fyhi = fmaxf(fyhi, dpp_f<kXor1>(fyhi));
@@ -309,35 +311,39 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
             fxlo = fminf(fxlo, dpp_f<kXor2>(fxlo)); fxhi = fmaxf(fxhi, dpp_f<kXor2>(fxhi));
             fylo = fminf(fylo, dpp_f<kXor2>(fylo)); fyhi = fmaxf(fyhi, dpp_f<kXor2>(fyhi));
             bad |= dpp_i<kXor2>(bad);
-            // the candidate's box: bounding box of the 4 corners' taps (a homography maps the convex tile onto a convex
-            // quadrilateral, so the corners bound the interior as long as the plane stays in front of the source camera:
-            // `bad` otherwise), +1 texel of slack, inside [-1, w] x [-1, h] (apron), at least 2 x 2
-            int bxlo = 1 << 30, bxhi = -(1 << 30), bylo = 1 << 30, byhi = -(1 << 30);
-            if ((lane >> 2) < nmax && !bad) {
+            if (c < ke && cr == 0) {
+                int4 b;
                 const float mnx = fmaxf(fxlo, -4.f), mxx = fminf(fxhi, wf + 4.f);
                 const float mny = fmaxf(fylo, -4.f), mxy = fminf(fyhi, hf + 4.f);
-                bxlo = min(max((int)floorf(mnx) - 1, -1), a.w - 1);
-                bxhi = min(max((int)floorf(mxx) + 2, bxlo + 1), a.w);
-                bylo = min(max((int)floorf(mny) - 1, -1), a.h - 1);
-                byhi = min(max((int)floorf(mxy) + 2, bylo + 1), a.h);
+                b.x = min(max((int)floorf(mnx) - 1, -1), a.w - 1);
+                b.y = min(max((int)floorf(mxx) + 2, b.x + 1), a.w);
+                b.z = min(max((int)floorf(mny) - 1, -1), a.h - 1);
+                b.w = min(max((int)floorf(mxy) + 2, b.z + 1), a.h);
+                if (bad) { b.x = -(1 << 20); b.y = 1 << 20; b.z = -(1 << 20); b.w = 1 << 20; }   // unbounded: never fits
+                boxes[c] = b;
             }
-#pragma unroll
-            for (int sh = 4; sh < 4 * kQRun; sh <<= 1) {
-                const int uxlo = __shfl_up(bxlo, sh, 64), uxhi = __shfl_up(bxhi, sh, 64);
-                const int uylo = __shfl_up(bylo, sh, 64), uyhi = __shfl_up(byhi, sh, 64);
-                const int ubad = __shfl_up(bad, sh, 64);
-                if (lane >= sh) {
-                    bxlo = min(bxlo, uxlo); bxhi = max(bxhi, uxhi); bylo = min(bylo, uylo); byhi = max(byhi, uyhi); bad |= ubad;
-                }
-            }
+        }
+        __syncthreads();
+        for (int j0 = kb; j0 < ke;) {
+            // ---- largest run of 16 / 8 / 4 / 2 candidates whose united footprint fits the patch: lane l < 16 of every wave
+            // holds candidate j0 + l, inclusive prefix union along the 16-lane DPP row ----
+            const int nmax = min(kQRun, ke - j0);
+            int4 bx = make_int4(1 << 30, -(1 << 30), 1 << 30, -(1 << 30));
+            if (lane < nmax) bx = boxes[j0 + lane];
+#define NRGBD_ROW_SHR_UNION(SH)                                                                                   \
+            bx.x = min(bx.x, __builtin_amdgcn_update_dpp(1 << 30, bx.x, 0x110 + SH, 0xf, 0xf, false));              \
+            bx.y = max(bx.y, __builtin_amdgcn_update_dpp(-(1 << 30), bx.y, 0x110 + SH, 0xf, 0xf, false));           \
+            bx.z = min(bx.z, __builtin_amdgcn_update_dpp(1 << 30, bx.z, 0x110 + SH, 0xf, 0xf, false));              \
+            bx.w = max(bx.w, __builtin_amdgcn_update_dpp(-(1 << 30), bx.w, 0x110 + SH, 0xf, 0xf, false));
+            NRGBD_ROW_SHR_UNION(1) NRGBD_ROW_SHR_UNION(2) NRGBD_ROW_SHR_UNION(4) NRGBD_ROW_SHR_UNION(8)
+#undef NRGBD_ROW_SHR_UNION
             int n = 0, xlo = 0, xhi = 1, ylo = 0, yhi = 1;
 #pragma unroll
             for (int tryn = kQRun; tryn >= 2; tryn >>= 1) {
-                const int l = 4 * tryn - 1;   // a lane holding the union of candidates 0 .. tryn-1
-                const int uxlo = __builtin_amdgcn_readlane(bxlo, l), uxhi = __builtin_amdgcn_readlane(bxhi, l);
-                const int uylo = __builtin_amdgcn_readlane(bylo, l), uyhi = __builtin_amdgcn_readlane(byhi, l);
-                const int ubad = __builtin_amdgcn_readlane(bad, l);
-                if (n == 0 && tryn <= nmax && !ubad && (long)(uxhi - uxlo + 1) * (uyhi - uylo + 1) <= kQPatch) {
+                const int l = tryn - 1;       // the lane holding the union of candidates j0 .. j0 + tryn - 1
+                const int uxlo = __builtin_amdgcn_readlane(bx.x, l), uxhi = __builtin_amdgcn_readlane(bx.y, l);
+                const int uylo = __builtin_amdgcn_readlane(bx.z, l), uyhi = __builtin_amdgcn_readlane(bx.w, l);
+                if (n == 0 && tryn <= nmax && (long)(uxhi - uxlo + 1) * (uyhi - uylo + 1) <= kQPatch) {
                     n = tryn; xlo = uxlo; xhi = uxhi; ylo = uylo; yhi = uyhi;
                 }
             }
@@ -449,16 +455,22 @@ int launch_costvol_quad(const CostvolArgs& args, hipStream_t stream, bool* did_s
     // candidates into chunks (>= 8 each) so that every CU has work, and leave the log-softmax to its own launch
     int nchunk = 1;
     while (tiles * nchunk < 3 * 256 && ceil_div(a.D, nchunk * 2) >= 8) nchunk *= 2;
+    if (const int forced = dev_env_int("NRGBD_QUAD_CHUNKS")) nchunk = forced;   // developer builds only
     a.nchunk = nchunk;
     a.kchunk = ceil_div(a.D, nchunk);
     a.fuse_softmax = (nchunk == 1 && a.out_logp != nullptr && a.D <= 128) ? 1 : 0;
     *did_softmax = a.fuse_softmax != 0;
-    const size_t lds = (size_t)kQPatch * (kQFeatBytes + 16);
+    const size_t lds = (size_t)kQPatch * kQFeatBytes + (size_t)kQPatchR * 16 + (size_t)a.D * (sizeof(int4) + sizeof(float));
     const dim3 grid(tiles * nchunk);
-    const bool extra = a.Cp == 68;
-#define NRGBD_QUAD_LAUNCH(DIST, EX) hipLaunchKernelGGL((costvol_quad<DIST, EX>), grid, dim3(256), lds, stream, a)
-    if (a.dist == NRGBD_DIST_L2) { if (extra) NRGBD_QUAD_LAUNCH(NRGBD_DIST_L2, true); else NRGBD_QUAD_LAUNCH(NRGBD_DIST_L2, false); }
-    else { if (extra) NRGBD_QUAD_LAUNCH(NRGBD_DIST_L1, true); else NRGBD_QUAD_LAUNCH(NRGBD_DIST_L1, false); }
+    const int tail = a.Cp == 68 ? (a.C - 64 == 3 ? 3 : -1) : 0;
+    const bool al = a.align != 0;
+#define NRGBD_QUAD_LAUNCH(DIST, TL, AL) hipLaunchKernelGGL((costvol_quad<DIST, TL, AL>), grid, dim3(256), lds, stream, a)
+#define NRGBD_QUAD_DISPATCH(DIST)                                                                   \
+    if (tail == 3) { if (al) NRGBD_QUAD_LAUNCH(DIST, 3, true); else NRGBD_QUAD_LAUNCH(DIST, 3, false); }        \
+    else if (tail == 0) { if (al) NRGBD_QUAD_LAUNCH(DIST, 0, true); else NRGBD_QUAD_LAUNCH(DIST, 0, false); }   \
+    else { if (al) NRGBD_QUAD_LAUNCH(DIST, -1, true); else NRGBD_QUAD_LAUNCH(DIST, -1, false); }
+    if (a.dist == NRGBD_DIST_L2) { NRGBD_QUAD_DISPATCH(NRGBD_DIST_L2) } else { NRGBD_QUAD_DISPATCH(NRGBD_DIST_L1) }
+#undef NRGBD_QUAD_DISPATCH
 #undef NRGBD_QUAD_LAUNCH
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;

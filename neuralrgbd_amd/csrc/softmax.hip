@@ -73,6 +73,33 @@ int launch_logsoftmax_d(const float* a, const float* b, float scale, float* out,
     return NRGBD_OK;
 }
 
+// export epilogue (test_utils/export_res.py:43-75): expected depth, confidence exp(max_k logp) and the two uint16 maps of the
+// .pgm files in ONE pass over the refined DPV: (map * scale) truncated toward zero, clamped to [0, 65535]
+__device__ __forceinline__ unsigned short to_u16(float v) {
+    if (!(v > 0.f)) return 0;
+    if (v >= 65535.f) return 65535;
+    return (unsigned short)v;
+}
+__global__ __launch_bounds__(256) void export_depth_u16_kernel(const float* __restrict__ logp,
+                                                               const float* __restrict__ d_candi, float depth_scale,
+                                                               float conf_scale, float* __restrict__ depth,
+                                                               float* __restrict__ conf, unsigned short* __restrict__ du,
+                                                               unsigned short* __restrict__ cu, int D, size_t n) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    float acc = 0.f, m = -INFINITY;
+    for (int k = 0; k < D; ++k) {
+        const float v = logp[(size_t)k * n + p];
+        acc = acc + expf(v) * d_candi[k];
+        m = fmaxf(m, v);
+    }
+    const float c = expf(m);
+    if (depth) depth[p] = acc;
+    if (conf) conf[p] = c;
+    if (du) du[p] = to_u16(acc * depth_scale);
+    if (cu) cu[p] = to_u16(c * conf_scale);
+}
+
 }  // namespace nrgbd
 
 extern "C" int nrgbd_logsoftmax_d(const float* a, const float* b, float scale, float* out, int D,
@@ -89,6 +116,18 @@ extern "C" int nrgbd_depth_regress(const float* logp, const float* d_candi, floa
     if (D <= 0 || n <= 0) return NRGBD_E_SHAPE;
     hipLaunchKernelGGL(depth_regress_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, logp, d_candi, depth, conf, D, (size_t)n);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+extern "C" int nrgbd_export_depth_u16(const float* logp, const float* d_candi, float depth_scale, float conf_scale,
+                                      float* depth, float* conf, unsigned short* depth_u16, unsigned short* conf_u16,
+                                      int D, long n, void* stream) {
+    if (!logp || !d_candi) return NRGBD_E_NULL;
+    if (!depth && !conf && !depth_u16 && !conf_u16) return NRGBD_E_NULL;
+    if (D <= 0 || n <= 0) return NRGBD_E_SHAPE;
+    hipLaunchKernelGGL(nrgbd::export_depth_u16_kernel, dim3(nrgbd::ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       logp, d_candi, depth_scale, conf_scale, depth, conf, depth_u16, conf_u16, D, (size_t)n);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

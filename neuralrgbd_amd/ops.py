@@ -212,6 +212,55 @@ def depth_regress(logp, d_candi, want_conf=True):
     return depth, conf
 
 
+def export_depth_u16(logp, d_candi, depth_scale=1000.0, conf_scale=1000.0):
+    """logp [D, ...] -> (depth f32, conf f32 = exp(max logp), depth_u16, conf_u16 [as int16 storage viewed uint16])."""
+    logp = _need(logp, "logp")
+    D = logp.shape[0]
+    n = logp.numel() // D
+    d_candi = _need(d_candi, "d_candi", (D,))
+    shp = logp.shape[1:]
+    depth = torch.empty(shp, dtype=torch.float32, device=logp.device)
+    conf = torch.empty_like(depth)
+    du = torch.empty(shp, dtype=torch.uint16, device=logp.device)
+    cu = torch.empty(shp, dtype=torch.uint16, device=logp.device)
+    with torch.cuda.device(logp.device):
+        rc = _lib.load().nrgbd_export_depth_u16(_p(logp), _p(d_candi), float(depth_scale), float(conf_scale), _p(depth),
+                                                 _p(conf), _p(du), _p(cu), D, n, _stream(logp))
+    _lib.check(rc, "nrgbd_export_depth_u16")
+    return depth, conf, du, cu
+
+
+def warp_depth_fwd(src, dmap, K, R, t, rays):
+    """src [N,C,H,W], dmap [H,W], K [3,3], R [N,3,3], t [N,3], rays [3,HW] -> warped [N,C,H,W] (nrgbd_warp_depth_fwd)."""
+    src = _need(src, "src")
+    N, C, H, W = src.shape
+    dmap = _need(dmap, "dmap").reshape(H, W)
+    K = _need(K, "K", (3, 3)); R = _need(R, "R", (N, 3, 3)); t = _need(t, "t", (N, 3)); rays = _need(rays, "rays", (3, H * W))
+    out = torch.empty_like(src)
+    with torch.cuda.device(src.device):
+        rc = _lib.load().nrgbd_warp_depth_fwd(_p(src), _p(dmap), _p(K), _p(R), _p(t), _p(rays), _p(out), N, C, H, W, _stream(src))
+    _lib.check(rc, "nrgbd_warp_depth_fwd")
+    return out
+
+
+def warp_depth_bwd(src, dmap, K, R, t, rays, g_out):
+    """Gradient of sum(warp_depth_fwd(...) * g_out) w.r.t. (R [N,3,3], t [N,3])."""
+    src = _need(src, "src")
+    N, C, H, W = src.shape
+    dmap = _need(dmap, "dmap").reshape(H, W)
+    K = _need(K, "K", (3, 3)); R = _need(R, "R", (N, 3, 3)); t = _need(t, "t", (N, 3)); rays = _need(rays, "rays", (3, H * W))
+    g_out = _need(g_out, "g_out", src.shape)
+    nwg = int(_lib.load().nrgbd_warp_depth_bwd_workgroups(H, W))
+    partial = torch.empty((N, nwg, 12), dtype=torch.float32, device=src.device)
+    g_R = torch.empty((N, 3, 3), dtype=torch.float32, device=src.device)
+    g_t = torch.empty((N, 3), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = _lib.load().nrgbd_warp_depth_bwd(_p(src), _p(dmap), _p(K), _p(R), _p(t), _p(rays), _p(g_out), _p(partial),
+                                               _p(g_R), _p(g_t), N, C, H, W, _stream(src))
+    _lib.check(rc, "nrgbd_warp_depth_bwd")
+    return g_R, g_t
+
+
 # ----------------------------------------------------------------------------- K-Net convolutions
 def conv3d_workgroups(D, H, W):
     return int(_lib.load().nrgbd_conv3d_workgroups(D, H, W))
