@@ -43,6 +43,25 @@ class PlaneSweepCost(torch.autograd.Function):
         return (torch.cat((g_src, g_ref.unsqueeze(0)), dim=0),) + (None,) * 10
 
 
+class DepthWarp(torch.autograd.Function):
+    """Warp of N source images through a per-pixel depth map (warping/homography.py:479-528), differentiable w.r.t. the
+    rigid motions (R [N,3,3], t [N,3]) the local bundle adjustment refines (ICP/opt_pose_numerical.py:245-294):
+    forward = nrgbd_warp_depth_fwd, backward = nrgbd_warp_depth_bwd.  No gradient is produced for the images or the depth
+    map (the reference's caller never asks for one)."""
+
+    @staticmethod
+    def forward(ctx, src, dmap, K, R, t, rays):
+        R, t = R.contiguous(), t.contiguous()
+        ctx.save_for_backward(src, dmap, K, R, t, rays)
+        return ops.warp_depth_fwd(src, dmap, K, R, t, rays)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        src, dmap, K, R, t, rays = ctx.saved_tensors
+        g_R, g_t = ops.warp_depth_bwd(src, dmap, K, R, t, rays, g_out.contiguous())
+        return None, None, None, g_R, g_t, None
+
+
 class Conv3dCL(torch.autograd.Function):
     """3x3x3 convolution (stride 1, padding 1, no bias, 64 outputs) on channels-last activations, both directions on
     the fp32 matrix cores: forward = csrc/conv3d.hip; data gradient = the same kernel on the output gradient with

@@ -360,24 +360,50 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
                 __syncthreads();                               // the previous patch has been read by every wave
                 // ---- stage: L2 -> LDS without touching VGPRs; a wave instruction = 4 texels x 256 B (feature plane) or
                 // 64 texels x 16 B (RGB plane), landing in lane order = patch order ----
-                for (int it = wave; it * 4 < area; it += 4) {
-                    const int q = min(it * 4 + (lane >> 4), area - 1);
-                    const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
-                    const int gx = min(max(xlo + qx, 0), a.w - 1), gy = min(max(ylo + qy, 0), a.h - 1);
-                    const unsigned off = (unsigned)((gy * a.w + gx) * cpb + (lane & 15) * 16);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
-                                                     (__attribute__((address_space(3))) void*)(ldsF + it * 4 * kQFeatBytes),
-                                                     16, 0, 0);
-                }
-                if constexpr (EXTRA) {
-                    for (int it = wave; it * 64 < area; it += 4) {
-                        const int q = min(it * 64 + lane, area - 1);
+                // a patch wholly inside the image (the common case) needs no coordinate clamps: texel (qx, qy) of the patch
+                // is at base + qy * row pitch + qx * texel pitch
+                const bool interior = xlo >= 0 && ylo >= 0 && xhi <= a.w - 1 && yhi <= a.h - 1;   // block-uniform
+                const int rowb = a.w * cpb;
+                const unsigned base = (unsigned)((ylo * a.w + xlo) * cpb);
+                if (interior) {
+                    for (int it = wave; it * 4 < area; it += 4) {
+                        const int q = min(it * 4 + (lane >> 4), area - 1);
+                        const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
+                        const unsigned off = base + (unsigned)(qy * rowb + qx * cpb + (lane & 15) * 16);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
+                                                         (__attribute__((address_space(3))) void*)(ldsF + it * 4 * kQFeatBytes),
+                                                         16, 0, 0);
+                    }
+                    if constexpr (EXTRA) {
+                        for (int it = wave; it * 64 < area; it += 4) {
+                            const int q = min(it * 64 + lane, area - 1);
+                            const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
+                            const unsigned off = base + (unsigned)(qy * rowb + qx * cpb + kQFeatBytes);
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
+                                                             (__attribute__((address_space(3))) void*)(ldsR + it * 64 * 16),
+                                                             16, 0, 0);
+                        }
+                    }
+                } else {
+                    for (int it = wave; it * 4 < area; it += 4) {
+                        const int q = min(it * 4 + (lane >> 4), area - 1);
                         const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
                         const int gx = min(max(xlo + qx, 0), a.w - 1), gy = min(max(ylo + qy, 0), a.h - 1);
-                        const unsigned off = (unsigned)((gy * a.w + gx) * cpb + kQFeatBytes);
+                        const unsigned off = (unsigned)((gy * a.w + gx) * cpb + (lane & 15) * 16);
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
-                                                         (__attribute__((address_space(3))) void*)(ldsR + it * 64 * 16),
+                                                         (__attribute__((address_space(3))) void*)(ldsF + it * 4 * kQFeatBytes),
                                                          16, 0, 0);
+                    }
+                    if constexpr (EXTRA) {
+                        for (int it = wave; it * 64 < area; it += 4) {
+                            const int q = min(it * 64 + lane, area - 1);
+                            const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
+                            const int gx = min(max(xlo + qx, 0), a.w - 1), gy = min(max(ylo + qy, 0), a.h - 1);
+                            const unsigned off = (unsigned)((gy * a.w + gx) * cpb + kQFeatBytes);
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
+                                                             (__attribute__((address_space(3))) void*)(ldsR + it * 64 * 16),
+                                                             16, 0, 0);
+                        }
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -9,6 +9,8 @@ neuralrgbd_amd.ops; tensors must be on the GPU.
   warp_img_feats_v3      <- homography.py:234-280
   warp_img_feats_mgpu    <- homography.py:183-232
   resample_vol_cuda      <- homography.py:654-723   (analytic point grid, no host loop / H2D / sync)
+  back_warp_th_Rt_msrc   <- homography.py:479-528   (LBA photometric warp through a depth map; differentiable in R, t)
+  back_warp_th_Rt        <- homography.py:530-575   (its single-view form)
   get_rel_extrinsicM     <- homography.py:904-906
 """
 import math
@@ -145,6 +147,28 @@ def resample_vol_cuda(src_vol, rel_extM, cam_intrinsic=None, d_candi=None, d_can
     T = rel_extM.to(device=dev, dtype=torch.float32)
     return ops.dpv_resample(src_vol[0], T, rays, _d_candi_dev(d_candi, dev), math.tan(hhfov),
                             math.tan(hvfov), z_half, z_radius, padding_value, clamp=clamp)
+
+
+def back_warp_th_Rt_msrc(imgs_src, dmap, Rs, ts, cam_intrinsic):
+    """Warp the N source frames imgs_src [N,C,H,W] to the reference view given the reference depth map dmap [H,W] and
+    the motions Rs [N,3,3], ts [N,3] (reference -> source): [N,C,H,W].  Differentiable w.r.t. Rs and ts
+    (the local bundle adjustment of ICP/opt_pose_numerical.py optimises them)."""
+    assert isinstance(imgs_src, torch.Tensor)
+    from .autograd import DepthWarp
+    npts = dmap.numel()
+    assert cam_intrinsic['unit_ray_array_2D'].shape[1] == npts
+    dev = imgs_src.device
+    K, rays = _cam_dev(cam_intrinsic, dev)
+    dm = dmap.to(device=dev, dtype=torch.float32).reshape(imgs_src.shape[2], imgs_src.shape[3])
+    Rs = Rs.to(device=dev, dtype=torch.float32).reshape(-1, 3, 3)
+    ts = ts.to(device=dev, dtype=torch.float32).reshape(-1, 3)
+    return DepthWarp.apply(imgs_src.to(torch.float32).contiguous(), dm.contiguous(), K, Rs, ts, rays)
+
+
+def back_warp_th_Rt(img_src, dmap, R, t, cam_intrinsic):
+    """Single-view form: img_src [1,C,H,W], R [3,3], t [3] -> [1,C,H,W]."""
+    assert isinstance(R, torch.Tensor) and isinstance(t, torch.Tensor), 'R,t should be torch tensors'
+    return back_warp_th_Rt_msrc(img_src, dmap, R.reshape(1, 3, 3), t.reshape(1, 3), cam_intrinsic)
 
 
 def get_rel_extrinsicM(ext_ref, ext_src):

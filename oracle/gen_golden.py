@@ -20,7 +20,12 @@ CPU under the installed torch.  Outputs (small, committed):
   net_fp64.npz     the NET case evaluated in float64 (oracle/fp64_ref.py) at every second pixel, plus the measured
                    |reference - fp64| of the reference's own fp32 outputs: the yardstick for "DPV within 1e-4"
 
-    python -m oracle.gen_golden [ops net scene ops67 fp64]      (default: all)
+  net_fp64_S.npz   config S (256x384, D=64), two frames, in float64 at every 4th pixel + the CPU oracle's distance from it
+  lba_small.npz    back_warp_th_Rt_msrc (LBA photometric warp through a depth map): warped images and torch autograd's
+                   gradients w.r.t. (R, t), for a generic upstream gradient and for the masked L1 loss of opt_pose_numerical.py
+  export_small.npz export_res_img run through the reference's own function; its two .pgm files read back
+
+    python -m oracle.gen_golden [ops net scene ops67 fp64 fp64S lba export]      (default: all)
 """
 import json
 import math
@@ -186,6 +191,69 @@ def gen_fp64(ref):
     np.savez(os.path.join(OUT, "net_fp64.npz"), **out)
 
 
+LBA = dict(N=3, C=3, H=48, W=64, seed=41, rot_sigma=0.03, trans_sigma=0.08)
+EXPORT = dict(D=16, H=24, W=40, seed=43, d_min=0.1, d_max=5.0)
+
+
+def lba_inputs():
+    """Seeded inputs of the LBA warp fixture (shared with the tests)."""
+    o = LBA
+    rng = np.random.RandomState(o["seed"])
+    src = rng.standard_normal((o["N"], o["C"], o["H"], o["W"])).astype(np.float32)
+    ref_img = rng.standard_normal((1, o["C"], o["H"], o["W"])).astype(np.float32)
+    dmap = (0.5 + 4.0 * rng.rand(o["H"], o["W"])).astype(np.float32)
+    poses = synth.random_poses(rng, o["N"], rot_sigma=o["rot_sigma"], trans_sigma=o["trans_sigma"])
+    G = rng.standard_normal(src.shape).astype(np.float32)
+    return src, ref_img, dmap, poses, G
+
+
+def export_inputs():
+    o = EXPORT
+    rng = np.random.RandomState(o["seed"])
+    bv = torch.log_softmax(torch.from_numpy(rng.standard_normal((1, o["D"], o["H"], o["W"])).astype(np.float32)) * 3, 1)
+    img = torch.from_numpy(rng.standard_normal((1, 3, o["H"], o["W"])).astype(np.float32))
+    return bv, img, np.linspace(o["d_min"], o["d_max"], o["D"])
+
+
+def gen_lba(ref):
+    """back_warp_th_Rt_msrc forward + torch autograd's gradients w.r.t. (R, t): for a generic upstream gradient and for
+    the masked L1 photometric loss of ICP/opt_pose_numerical.py:262-270."""
+    o = LBA
+    src, ref_img, dmap, poses, G = (torch.from_numpy(x) for x in lba_inputs())
+    cam = camera.scannet_intrinsics(o["W"], o["H"])
+    Rs = poses[:, :3, :3].clone().requires_grad_(True)
+    ts = poses[:, :3, 3].clone().requires_grad_(True)
+    out = ref.homography.back_warp_th_Rt_msrc(src, dmap, Rs, ts, cam)
+    (out * G).sum().backward()
+    gR, gt = Rs.grad.clone(), ts.grad.clone()
+    Rs.grad = None; ts.grad = None
+    out2 = ref.homography.back_warp_th_Rt_msrc(src, dmap, Rs, ts, cam)
+    mask = 1.0 - (out2 == 0).type_as(out2)
+    loss = torch.nn.L1Loss()(out2 * mask.detach(), ref_img * mask.detach())
+    loss.backward()
+    single = ref.homography.back_warp_th_Rt(src[:1], dmap, poses[0, :3, :3], poses[0, :3, 3], cam)
+    np.savez(os.path.join(OUT, "lba_small.npz"), warped=out.detach().numpy(), g_R=gR.numpy(), g_t=gt.numpy(),
+             loss=float(loss), g_R_loss=Rs.grad.numpy(), g_t_loss=ts.grad.numpy(), single=single.numpy(),
+             inputs_checksum=checksum([src, ref_img, dmap, poses, G]))
+    print("lba_small: loss", float(loss), "|g_t|", float(gt.abs().max()))
+
+
+def gen_export(ref):
+    """export_res_img through the reference's own function and files: the two .pgm images are read back."""
+    import tempfile
+    import PIL.Image as image
+    import test_utils.export_res as er
+    bv, img, d_candi = export_inputs()
+    with tempfile.TemporaryDirectory() as tmp:
+        er.export_res_img({"img": img}, bv, d_candi, tmp, 7)
+        d16 = np.array(image.open(os.path.join(tmp, "d_00007.pgm"))).astype(np.uint16)
+        c16 = np.array(image.open(os.path.join(tmp, "conf_00007.pgm"))).astype(np.uint16)
+    depth = ref.misc.depth_val_regression(bv, d_candi, BV_log=True)[0].numpy()
+    np.savez(os.path.join(OUT, "export_small.npz"), depth_u16=d16, conf_u16=c16, depth=depth,
+             conf=torch.exp(bv.max(1)[0])[0].numpy(), inputs_checksum=checksum([bv, img]))
+    print("export_small: depth range", d16.min(), d16.max(), "conf range", c16.min(), c16.max())
+
+
 FP64_S = dict(H=256, W=384, D=64, seeds=(101, 102), sigma=10.0, d_min=0.1, d_max=5.0, weight_seed=0)   # = config S test
 
 
@@ -225,9 +293,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shim.load()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["ops", "net", "scene", "ops67", "fp64", "fp64S"]
+    which = sys.argv[1:] or ["ops", "net", "scene", "ops67", "fp64", "fp64S", "lba", "export"]
     for name in which:
-        {"ops": gen_ops, "net": gen_net, "scene": gen_scene, "ops67": gen_ops67, "fp64": gen_fp64, "fp64S": gen_fp64_S}[name](ref)
+        {"ops": gen_ops, "net": gen_net, "scene": gen_scene, "ops67": gen_ops67, "fp64": gen_fp64, "fp64S": gen_fp64_S, "lba": gen_lba, "export": gen_export}[name](ref)
 
 
 if __name__ == "__main__":

@@ -398,3 +398,89 @@ def test_costvol_generation_errors():
     with pytest.raises(_lib.NrgbdError):
         _gpu_costvol(feat_ref, feat_src, KR, Kt, cam["unit_ray_array_2D"].numpy(), np.linspace(.1, 5, D), 8.0, 8.0, 10.0,
                      generation="quad")
+
+
+# ----------------------------------------------------------------------------- LBA depth warp (f4) and export epilogue (f2)
+def test_lba_depth_warp_vs_reference_golden():
+    """nrgbd_warp_depth_fwd/_bwd through the reference-named operator (autograd) vs the reference's output and torch
+    autograd's gradients w.r.t. the poses (tests/golden/lba_small.npz), incl. the masked-L1 loss of opt_pose_numerical.py."""
+    import os
+    from conftest import GOLDEN
+    from neuralrgbd_amd import homography as Hm
+    o = gen_golden.LBA
+    g = dict(np.load(os.path.join(GOLDEN, "lba_small.npz")))
+    src, ref_img, dmap, poses, G = (torch.from_numpy(x).to(DEV) for x in gen_golden.lba_inputs())
+    cam = camera.scannet_intrinsics(o["W"], o["H"])
+    Rs = poses[:, :3, :3].clone().requires_grad_(True)
+    ts = poses[:, :3, 3].clone().requires_grad_(True)
+    out = Hm.back_warp_th_Rt_msrc(src, dmap, Rs, ts, cam)
+    err = (out.detach().cpu().numpy() - g["warped"])
+    print("[parity] LBA warp vs reference max|d|=%.2e" % np.abs(err).max())
+    assert np.abs(err).max() < 2e-5
+    (out * G).sum().backward()
+    eR = np.abs(Rs.grad.cpu().numpy() - g["g_R"]).max() / np.abs(g["g_R"]).max()
+    et = np.abs(ts.grad.cpu().numpy() - g["g_t"]).max() / np.abs(g["g_t"]).max()
+    print("[parity] LBA warp gradients vs torch autograd: rel dR %.2e dt %.2e" % (eR, et))
+    assert eR < 1e-4 and et < 1e-4
+    Rs.grad = None; ts.grad = None
+    out2 = Hm.back_warp_th_Rt_msrc(src, dmap, Rs, ts, cam)
+    mask = 1.0 - (out2 == 0).type_as(out2)
+    loss = torch.nn.L1Loss()(out2 * mask.detach(), ref_img * mask.detach())
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    assert np.abs(Rs.grad.cpu().numpy() - g["g_R_loss"]).max() < 1e-3 * np.abs(g["g_R_loss"]).max()
+    assert np.abs(ts.grad.cpu().numpy() - g["g_t_loss"]).max() < 1e-3 * np.abs(g["g_t_loss"]).max()
+    single = Hm.back_warp_th_Rt(src[:1], dmap, poses[0, :3, :3], poses[0, :3, 3], cam)
+    assert np.abs(single.cpu().numpy() - g["single"]).max() < 2e-5
+
+
+def test_lba_depth_warp_vs_oracle_full_res_and_deterministic():
+    """A full-resolution frame (480x640, 4 sources) against the C oracle; the gradient reduction is bitwise reproducible."""
+    from neuralrgbd_amd import ops
+    N, C, H, W = 4, 3, 480, 640
+    rng = np.random.RandomState(8)
+    cam = camera.scannet_intrinsics(W, H)
+    src = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    dmap = (0.4 + 4.0 * rng.rand(H, W)).astype(np.float32)
+    poses = synth.random_poses(rng, N, rot_sigma=0.02, trans_sigma=0.05)
+    G = rng.standard_normal(src.shape).astype(np.float32)
+    K, rays = cam["intrinsic_M_cuda"].numpy(), cam["unit_ray_array_2D"].numpy()
+    R, t = np.ascontiguousarray(poses[:, :3, :3]), np.ascontiguousarray(poses[:, :3, 3])
+    want = co.warp_depth_fwd(src, dmap, K, R, t, rays)
+    wR, wt = co.warp_depth_bwd(src, dmap, K, R, t, rays, G)
+    a = [_dev(x) for x in (src, dmap, K, R, t, rays)]
+    got = ops.warp_depth_fwd(*a)
+    assert np.abs(got.cpu().numpy() - want).max() < 2e-5
+    gR, gt = ops.warp_depth_bwd(*a, _dev(G))
+    gR2, gt2 = ops.warp_depth_bwd(*a, _dev(G))
+    assert torch.equal(gR, gR2) and torch.equal(gt, gt2)
+    assert np.abs(gR.cpu().numpy() - wR).max() < 1e-4 * np.abs(wR).max()
+    assert np.abs(gt.cpu().numpy() - wt).max() < 1e-4 * np.abs(wt).max()
+
+
+def test_export_epilogue_vs_reference_files_and_oracle(tmp_path):
+    """nrgbd_export_depth_u16 vs the .pgm images the reference's export_res_img wrote (golden) and vs the oracle at full
+    resolution; the drop-in export_res_img writes readable 16-bit files with the same content."""
+    import os
+    import PIL.Image as image
+    from conftest import GOLDEN
+    from neuralrgbd_amd import export_res
+    g = dict(np.load(os.path.join(GOLDEN, "export_small.npz")))
+    bv, img, d_candi = gen_golden.export_inputs()
+    depth, conf, du, cu = export_res.depth_conf_u16(bv.to(DEV), d_candi)
+    assert np.abs(depth.cpu().numpy() - g["depth"]).max() < 1e-5 and np.abs(conf.cpu().numpy() - g["conf"]).max() < 1e-6
+    du_n, cu_n = du.cpu().numpy(), cu.cpu().numpy()
+    assert (np.abs(du_n.astype(np.int32) - g["depth_u16"].astype(np.int32)) > 1).sum() == 0
+    assert (du_n != g["depth_u16"]).mean() < 2e-3 and (cu_n != g["conf_u16"]).mean() < 2e-3
+    export_res.export_res_img({"img": img}, bv.to(DEV), d_candi, str(tmp_path), 7)
+    assert np.array_equal(np.array(image.open(str(tmp_path / "d_00007.pgm"))).astype(np.uint16), du_n)
+    assert np.array_equal(np.array(image.open(str(tmp_path / "conf_00007.pgm"))).astype(np.uint16), cu_n)
+    # full resolution, D = 64: bit-identical to the C oracle (same sequential sum)
+    rng = np.random.RandomState(2)
+    big = torch.log_softmax(torch.from_numpy(rng.standard_normal((64, 768, 1024)).astype(np.float32)) * 3, 0)
+    d64 = np.linspace(0.1, 5.0, 64)
+    from neuralrgbd_amd import ops
+    dg, cg, dug, cug = ops.export_depth_u16(big.to(DEV), _dev(d64))
+    do, co_, duo, cuo = co.export_depth_u16(big.numpy(), d64)
+    assert np.abs(dg.cpu().numpy() - do).max() < 2e-6
+    assert (dug.cpu().numpy() != duo).mean() < 1e-4 and (cug.cpu().numpy() != cuo).mean() < 1e-4

@@ -136,3 +136,40 @@ def test_fp64_yardstick_is_the_same_graph(golden_net):
     assert np.abs(o64[2][0].numpy()[:, ::2, ::2] - g64["bv_cur_f1"]).max() < 1e-9
     # the reference's own fp32 output sits ~1e-3 (max) from exact arithmetic already at the D-Net output
     assert 1e-4 < float(g64["ref_err_max_dpv_f2"]) < 1e-2
+
+
+def test_lba_depth_warp_forward_and_pose_gradients():
+    """oracle_warp_depth_fwd/_bwd vs the reference's back_warp_th_Rt_msrc and torch autograd's dR, dt (lba_small.npz)."""
+    import os
+    from conftest import GOLDEN
+    o = gen_golden.LBA
+    g = dict(np.load(os.path.join(GOLDEN, "lba_small.npz")))
+    src, ref_img, dmap, poses, G = gen_golden.lba_inputs()
+    cam = camera.scannet_intrinsics(o["W"], o["H"])
+    K, rays = cam["intrinsic_M_cuda"].numpy(), cam["unit_ray_array_2D"].numpy()
+    out = co.warp_depth_fwd(src, dmap, K, poses[:, :3, :3], poses[:, :3, 3], rays)
+    assert np.abs(out - g["warped"]).max() < 2e-5
+    assert np.abs(out[:1] - g["single"]).max() < 2e-5
+    gR, gt = co.warp_depth_bwd(src, dmap, K, poses[:, :3, :3], poses[:, :3, 3], rays, G)
+    assert np.abs(gR - g["g_R"]).max() < 1e-5 * np.abs(g["g_R"]).max()
+    assert np.abs(gt - g["g_t"]).max() < 1e-5 * np.abs(g["g_t"]).max()
+    # the LBA loss (ICP/opt_pose_numerical.py:262-270): L1 over pixels the warp reached, upstream gradient = sign / count
+    mask = (out != 0).astype(np.float32)
+    diff = out * mask - ref_img * mask
+    assert abs(float(np.abs(diff).mean()) - float(g["loss"])) < 1e-6
+    gR2, gt2 = co.warp_depth_bwd(src, dmap, K, poses[:, :3, :3], poses[:, :3, 3], rays, np.sign(diff) * mask / diff.size)
+    assert np.abs(gR2 - g["g_R_loss"]).max() < 1e-4 * np.abs(g["g_R_loss"]).max()
+    assert np.abs(gt2 - g["g_t_loss"]).max() < 1e-4 * np.abs(g["g_t_loss"]).max()
+
+
+def test_export_epilogue_vs_reference_files():
+    """oracle_export_depth_u16 vs the uint16 .pgm images written by the reference's export_res_img (export_small.npz)."""
+    import os
+    from conftest import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "export_small.npz")))
+    bv, _, d_candi = gen_golden.export_inputs()
+    depth, conf, du, cu = co.export_depth_u16(bv[0].numpy(), d_candi)
+    assert np.abs(depth - g["depth"]).max() < 1e-5 and np.abs(conf - g["conf"]).max() < 1e-6
+    # truncation of (map * 1000): a last-ulp difference of the fp32 sum flips a value only when it sits on an integer
+    assert (np.abs(du.astype(np.int32) - g["depth_u16"].astype(np.int32)) > 1).sum() == 0
+    assert (du != g["depth_u16"]).mean() < 2e-3 and (cu != g["conf_u16"]).mean() < 2e-3
