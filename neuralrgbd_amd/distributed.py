@@ -52,15 +52,22 @@ def max_over_ranks(seconds, device=None):
 
 
 class GradAllReduce:
-    """Bucketed gradient all-reduce for data-parallel training of KVNET.
+    """Bucketed gradient all-reduce for data-parallel training of KVNET, overlapped with backward.
 
-    Parameters that share storage (the feature CNN is registered twice) are reduced once.  Gradients are
-    packed into contiguous fp32 buckets of `bucket_mb`, all-reduced (sum) asynchronously, divided by the world
-    size and scattered back.  Parameters without a gradient (unused in the step) contribute zeros, so every
-    rank issues the same collectives.
+    Parameters that share storage (the feature CNN is registered twice) are reduced once.  Every bucket owns ONE
+    persistent flat fp32 buffer and the parameters' `.grad` are views into it, so autograd accumulates straight into the
+    message (no per-step torch.cat / scatter-back copies).  Buckets are filled in reverse registration order — the order
+    backward produces gradients — and a bucket's all-reduce (sum, asynchronous) is launched from a post-accumulate hook
+    the moment its last gradient lands, i.e. while backward is still running on the earlier layers; `__call__()` (after
+    backward) launches whatever did not fire (parameters unused in the step contribute zeros, so every rank issues the
+    same collectives), waits, and divides by the world size.  Few large buckets: xGMI is point-to-point and a ring
+    all-reduce is per-link bound (21.15 MB of fp32 gradient -> one or two messages at the default 32 MB).
+
+    Use:  reducer.prepare(); loss.backward(); reducer(); optimizer.step()
+    (`prepare` re-attaches the views — optimizers' zero_grad(set_to_none=True) drops them — and zeroes the buffers.)
     """
 
-    def __init__(self, module, bucket_mb=32.0):
+    def __init__(self, module, bucket_mb=32.0, overlap=True):
         seen, self.params = set(), []
         for p in module.parameters():
             if p.requires_grad and p.data_ptr() not in seen:
@@ -68,7 +75,7 @@ class GradAllReduce:
                 self.params.append(p)
         limit = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets, cur, n = [], [], 0
-        for p in self.params:
+        for p in reversed(self.params):            # backward order: last layers first
             if cur and n + p.numel() > limit:
                 self.buckets.append(cur)
                 cur, n = [], 0
@@ -76,27 +83,66 @@ class GradAllReduce:
             n += p.numel()
         if cur:
             self.buckets.append(cur)
+        self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device) for b in self.buckets]
+        self._views, self._bucket_of = {}, {}
+        for bi, (b, flat) in enumerate(zip(self.buckets, self.flat)):
+            off = 0
+            for p in b:
+                self._views[p] = flat[off:off + p.numel()].view_as(p)
+                self._bucket_of[p] = bi
+                off += p.numel()
+        self._pending = [0] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self.overlap = overlap
+        self.launched_in_backward = 0              # buckets whose collective started from a hook in the last step
+        if overlap and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+        self.prepare()
 
     @property
     def numel(self):
         return sum(p.numel() for p in self.params)
 
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def prepare(self):
+        """Before backward: zero the messages and make every .grad a view into its bucket."""
+        for flat in self.flat:
+            flat.zero_()
+        for p in self.params:
+            p.grad = self._views[p]
+        self._pending = [len(b) for b in self.buckets]
+        self._work = [None] * len(self.buckets)
+        self.launched_in_backward = 0
+
+    def _launch(self, bi):
+        if self._work[bi] is None and self._active():
+            self._work[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p):
+        bi = self._bucket_of.get(p)
+        if bi is None:
+            return
+        if p.grad is not self._views[p]:           # autograd replaced the tensor (first accumulation into a None grad)
+            self._views[p].copy_(p.grad)
+            p.grad = self._views[p]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0 and self.overlap and self._active():
+            self._launch(bi)
+            self.launched_in_backward += 1
+
     def __call__(self):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self._active():
             return
         world = dist.get_world_size()
-        work = []
-        for bucket in self.buckets:
-            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
-            work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
-        for handle, flat, bucket in work:
-            handle.wait()
-            flat.div_(world)
-            off = 0
-            for p in bucket:
-                g = flat[off:off + p.numel()].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                off += p.numel()
+        for p in self.params:                      # no hook support / a replaced grad tensor: fold it into the message
+            if p.grad is not None and p.grad is not self._views[p] and self._work[self._bucket_of[p]] is None:
+                self._views[p].copy_(p.grad)
+                p.grad = self._views[p]
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        for bi, w in enumerate(self._work):
+            w.wait()
+            self.flat[bi].div_(world)

@@ -32,7 +32,10 @@ def train(nGPU, model_KV, optimizer_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, Sr
     src_frames = torch.cat(tuple(torch.cat(tuple(f['img'] for f in traj), dim=0).unsqueeze(0) for traj in Src_Dats),
                            dim=0).to(dev)
     poses = Src_CamPoses.to(dev)
-    optimizer_KV.zero_grad()
+    if grad_reducer is not None and hasattr(grad_reducer, "prepare"):
+        grad_reducer.prepare()         # .grad = zeroed views into the all-reduce buckets (no per-step flatten / scatter)
+    else:
+        optimizer_KV.zero_grad()
 
     valid = valid_dpv(BVs_predict) if isinstance(BVs_predict, torch.Tensor) else False
     dmap_cur_refined, dmap_refined, d_dpv, kv_dpv = model_KV(
@@ -50,7 +53,8 @@ def train(nGPU, model_KV, optimizer_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, Sr
 
     loss.backward()
     if grad_reducer is not None:
-        grad_reducer()                 # RCCL all-reduce (sum / world) of the 21 MB fp32 gradient
+        grad_reducer()                 # RCCL all-reduce (sum / world) of the 21 MB fp32 gradient: buckets whose gradients
+                                       # were complete started from backward hooks; this waits for all of them
     optimizer_KV.step()
 
     # PREDICT on the detached DPV (train_KVNet.py:155-171)
@@ -73,13 +77,32 @@ class TrainGraph:
 
     Single-GPU form (the gradient all-reduce of a multi-GPU run stays outside a graph).  The optimizer must be built
     with `capturable=True`.  Inputs are copied into static buffers; the pose inverse for PREDICT is computed outside
-    the graph (the solver may allocate).  `step()` returns (loss, BV_predict for the next window) as static tensors.
+    the graph (the solver may allocate).  `step()` returns (loss, BV_predict for the next window); once the graph is
+    active these are static tensors that the next step() overwrites.
+
+    Capture needs state that only an executed iteration creates: Adam's exp_avg / exp_avg_sq / step (created inside a
+    capture they would become graph nodes that reset the moments at every replay), the packed-weight and interpolation
+    caches (their first use uploads from the host) and the vendor convolutions' algorithm choice.  Therefore the first
+    `warmup` calls of step() (default 1) are ordinary EAGER training iterations on their own windows — real steps, not
+    duplicates — and the graph is captured at the first call after them, when every parameter has optimizer state
+    (checked; a RuntimeError names the parameter otherwise).
     """
 
-    def __init__(self, model, optimizer, t_win_r, d_candi, cam_intrinsics):
+    def __init__(self, model, optimizer, t_win_r, d_candi, cam_intrinsics, warmup=1):
         self.model, self.opt, self.t_win_r, self.d_candi, self.cam = model, optimizer, t_win_r, d_candi, cam_intrinsics
         self._graph = None
         self._st = None
+        self._warmup = max(0, int(warmup))
+        self._eager_steps = 0
+
+    def _optimizer_ready(self):
+        """Every trainable parameter has populated optimizer state (else capture would record its creation)."""
+        names = {p: n for n, p in self.model.named_parameters()}
+        for group in self.opt.param_groups:
+            for p in group["params"]:
+                if p.requires_grad and not self.opt.state.get(p):
+                    return names.get(p, "<unnamed %s>" % (tuple(p.shape),))
+        return None
 
     def _iteration(self, st):
         model = self.model
@@ -98,6 +121,16 @@ class TrainGraph:
 
     def step(self, ref_frame, src_frames, poses, dmap, dmap_full, bv_predict):
         inv = torch.linalg.inv(poses[0, self.t_win_r])
+        if self._graph is None and (self._eager_steps < self._warmup or self._optimizer_ready() is not None):
+            if self._eager_steps >= max(self._warmup, 2):
+                raise RuntimeError("TrainGraph: parameter %s still has no optimizer state after %d eager iterations "
+                                   "(unused in the loss?): the iteration cannot be captured" %
+                                   (self._optimizer_ready(), self._eager_steps))
+            self.opt.zero_grad(set_to_none=True)
+            out = self._iteration({"ref": ref_frame, "src": src_frames, "poses": poses, "dmap": dmap,
+                                   "dmap_full": dmap_full, "bv": bv_predict, "inv": inv})
+            self._eager_steps += 1
+            return out
         if self._graph is None:
             st = {"ref": ref_frame.clone(), "src": src_frames.clone(), "poses": poses.clone(), "dmap": dmap.clone(),
                   "dmap_full": dmap_full.clone(), "bv": bv_predict.clone(), "inv": inv.clone()}

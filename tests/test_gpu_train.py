@@ -176,7 +176,7 @@ def test_graph_captured_iteration_equals_eager_iteration():
     r, s, p, dm, dmf = window(2)
     _, pred_e, loss_e, _, _ = train(1, model, opt, 2, d_candi, [{"img": r, "dmap": dm, "dmap_imgsize_digit": dmf}],
                                     [[{"img": s[0, v:v + 1]} for v in range(4)]], p, pred, [cam])
-    tg = TrainGraph(twin, opt2, 2, d_candi, cam)
+    tg = TrainGraph(twin, opt2, 2, d_candi, cam, warmup=0)   # optimizer state and caches exist: capture immediately
     loss_g, pred_g = tg.step(r.to(DEV), s.to(DEV), p.to(DEV), dm.to(DEV), dmf.to(DEV), pred)
     torch.cuda.synchronize()
     print("[parity] train graph vs eager: loss %.6f vs %.6f, max|d BV_predict|=%.2e" %
@@ -189,3 +189,46 @@ def test_graph_captured_iteration_equals_eager_iteration():
     r, s, p, dm, dmf = window(3)
     loss2, pred2 = tg.step(r.to(DEV), s.to(DEV), p.to(DEV), dm.to(DEV), dmf.to(DEV), pred_g.clone())
     assert bool(torch.isfinite(loss2)) and bool(torch.isfinite(pred2).all())
+
+
+def test_train_graph_from_a_fresh_optimizer_warms_up_eagerly():
+    """TrainGraph on a FRESH capturable Adam (no state): the first step() must run eagerly (creating exp_avg / exp_avg_sq /
+    step outside any capture), the second captures — and both must match the plain eager loop on a twin.  Capturing the
+    state creation would make every replay reset Adam's moments."""
+    import copy
+    import neuralrgbd_amd
+    from neuralrgbd_amd.train_step import TrainGraph, train
+    H, W, D = 256, 256, 8
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(0.1, 5, D)
+    model = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    model.load_state_dict(synth.seeded_state_dict(model, 0))
+    model = model.to(DEV)
+    twin = copy.deepcopy(model)
+    rng = np.random.RandomState(2)
+
+    def window(i):
+        r, s, p = synth.noise_window(90 + i, H, W)
+        return (r, s, p, torch.from_numpy(rng.randint(0, D, (1, H // 4, W // 4))), torch.from_numpy(rng.randint(0, D, (1, H, W))))
+
+    wins = [window(i) for i in range(4)]
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(.9, .999), capturable=True)
+    opt2 = torch.optim.Adam(twin.parameters(), lr=1e-4, betas=(.9, .999), capturable=True)
+    # a filter state for the update branch (D-Net only first frame, no optimizer involvement)
+    with torch.no_grad():
+        from neuralrgbd_amd.test_step import test as infer
+        r, s, p, _, _ = wins[0]
+        _, pred = infer(model, d_candi, [cam], 2, [{"img": r}], [[{"img": s[0, v:v + 1]} for v in range(4)]], p, None)
+    pred_e, pred_g = pred.clone(), pred.clone()
+    tg = TrainGraph(twin, opt2, 2, d_candi, cam)
+    for i in (1, 2, 3):
+        r, s, p, dm, dmf = wins[i]
+        _, pred_e, loss_e, _, _ = train(1, model, opt, 2, d_candi, [{"img": r, "dmap": dm, "dmap_imgsize_digit": dmf}],
+                                        [[{"img": s[0, v:v + 1]} for v in range(4)]], p, pred_e, [cam])
+        loss_g, nxt = tg.step(r.to(DEV), s.to(DEV), p.to(DEV), dm.to(DEV), dmf.to(DEV), pred_g)
+        pred_g = nxt.clone()
+        assert (tg._graph is None) == (i == 1)          # eager warm-up on the first call only
+        print("[parity] fresh-optimizer train graph step %d: loss %.6f vs eager %.6f" % (i, float(loss_g), float(loss_e)))
+        assert abs(float(loss_g) - float(loss_e)) < 2e-3 * abs(float(loss_e))
+    st = opt2.state[next(iter(twin.kv_net.parameters()))]
+    assert float(st["step"]) == 3.0                      # the moments were not reset by the replays
