@@ -141,6 +141,9 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
     int id = blockIdx.x;
     if ((gridDim.x & 7) == 0) id = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int tile = id / a.nchunk, chunk = id - tile * a.nchunk;
+    // co-resident workgroups of a CU are consecutive in an XCD's dispatch order (u, u+1, u+2) or 32 apart (round robin)
+    const int uq = blockIdx.x >> 3;
+    const bool rev = (((uq ^ (uq >> 5)) & 1) != 0) && !NRGBD_DBG(a, 16);
     const int tiles_x = (a.w + kQT - 1) / kQT;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int kb = chunk * a.kchunk, ke = min(a.D, kb + a.kchunk);
@@ -324,12 +327,16 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
             }
         }
         __syncthreads();
-        for (int j0 = kb; j0 < ke;) {
+        // Every other workgroup walks its candidates far -> near instead of near -> far (`rev`).  The near planes are
+        // staging-bound (short runs, large footprints), the far planes math-bound (runs of 16 on one patch); workgroups that
+        // start together stay phase-locked, so without this all co-resident workgroups would stage at the same time (VALU
+        // idle) and then compute at the same time (patch fills idle).
+        for (int lo = kb, hi = ke; lo < hi;) {
             // ---- largest run of 16 / 8 / 4 / 2 candidates whose united footprint fits the patch: lane l < 16 of every wave
-            // holds candidate j0 + l, inclusive prefix union along the 16-lane DPP row ----
-            const int nmax = min(kQRun, ke - j0);
+            // holds the l-th next candidate, inclusive prefix union along the 16-lane DPP row ----
+            const int nmax = min(kQRun, hi - lo);
             int4 bx = make_int4(1 << 30, -(1 << 30), 1 << 30, -(1 << 30));
-            if (lane < nmax) bx = boxes[j0 + lane];
+            if (lane < nmax) bx = boxes[rev ? hi - 1 - lane : lo + lane];
 #define NRGBD_ROW_SHR_UNION(SH)                                                                                   \
             bx.x = min(bx.x, __builtin_amdgcn_update_dpp(1 << 30, bx.x, 0x110 + SH, 0xf, 0xf, false));              \
             bx.y = max(bx.y, __builtin_amdgcn_update_dpp(-(1 << 30), bx.y, 0x110 + SH, 0xf, 0xf, false));           \
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
             int n = 0, xlo = 0, xhi = 1, ylo = 0, yhi = 1;
 #pragma unroll
             for (int tryn = kQRun; tryn >= 2; tryn >>= 1) {
-                const int l = tryn - 1;       // the lane holding the union of candidates j0 .. j0 + tryn - 1
+                const int l = tryn - 1;       // the lane holding the union of the next tryn candidates
                 const int uxlo = __builtin_amdgcn_readlane(bx.x, l), uxhi = __builtin_amdgcn_readlane(bx.y, l);
                 const int uylo = __builtin_amdgcn_readlane(bx.z, l), uyhi = __builtin_amdgcn_readlane(bx.w, l);
                 if (n == 0 && tryn <= nmax && (long)(uxhi - uxlo + 1) * (uyhi - uylo + 1) <= kQPatch) {
@@ -349,6 +356,7 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
             }
             const bool staged = n >= 2 && !NRGBD_DBG(a, 1);
             if (!staged) n = min(4, nmax);                     // one group straight from global memory
+            const int j0 = rev ? hi - n : lo;                  // the run: candidates j0 .. j0 + n - 1
             const int ngroups = (n + 3) >> 2;
             const int cols = xhi - xlo + 1;
 
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
             if (!NRGBD_DBG(a, 2)) {
 #pragma unroll 1
                 for (int g = 0; g < ngroups; ++g) {
-                    const int k0 = j0 + 4 * g, nc = min(4, n - 4 * g);
+                    const int k0 = j0 + 4 * g, nc = min(4, n - 4 * g);   // candidates j0 .. j0 + n - 1 = this run
                     float* o = out + (size_t)min(k0 + j, a.D - 1) * hw + p;
                     const float prev = (v > 0) ? *o : 0.f;     // this quad's own store of the previous view
                     float acc;
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
                     if (inside && j < nc) *o = prev + div_by_const(acc, a.sigma, a.rsigma);   // homography.py:325 (/ sigma), views in order
                 }
             }
-            j0 += n;
+            if (rev) hi -= n; else lo += n;
         }
     }
 

@@ -24,6 +24,8 @@ CPU under the installed torch.  Outputs (small, committed):
   lba_small.npz    back_warp_th_Rt_msrc (LBA photometric warp through a depth map): warped images and torch autograd's
                    gradients w.r.t. (R, t), for a generic upstream gradient and for the masked L1 loss of opt_pose_numerical.py
   export_small.npz export_res_img run through the reference's own function; its two .pgm files read back
+  train_small.npz  two iterations of the reference's train() (first-frame + update branch, SGD): losses, predicted states,
+                   weight deltas (= lr x gradient) of six probe tensors
 
     python -m oracle.gen_golden [ops net scene ops67 fp64 fp64S lba export]      (default: all)
 """
@@ -254,6 +256,55 @@ def gen_export(ref):
     print("export_small: depth range", d16.min(), d16.max(), "conf range", c16.min(), c16.max())
 
 
+TRAIN = dict(H=256, W=256, D=8, seeds=(61, 62), sigma=10.0, lr=1e-3, weight_seed=0, label_seed=7,
+             probes=("kv_net.classify.2.weight", "kv_net.dres0.0.0.weight", "feature_extractor.feature_extraction.firstconv.0.0.weight",
+                     "feature_extractor.feature_extraction.lastconv.2.weight", "r_net.conv2_2.weight", "r_net.trans_conv0.0.weight"))
+
+
+def train_inputs():
+    """Seeded windows + integer depth-bin labels (0 = ignore) of the training fixture."""
+    t = TRAIN
+    rng = np.random.RandomState(t["label_seed"])
+    out = []
+    for sd_ in t["seeds"]:
+        r, s_, p = synth.noise_window(sd_, t["H"], t["W"])
+        dm = torch.from_numpy(rng.randint(0, t["D"], (1, t["H"] // 4, t["W"] // 4)))
+        dmf = torch.from_numpy(rng.randint(0, t["D"], (1, t["H"], t["W"])))
+        out.append((r, s_, p, dm, dmf))
+    return out
+
+
+def gen_train(ref):
+    """Two iterations of the reference's own train() (train_utils/train_KVNet.py:20-203) on CPU: first-frame branch, then the
+    update branch (4 NLL terms), plain SGD so that the weight change IS the gradient (lr * dL/dw).  Stored: both losses,
+    the predicted state after each iteration, and the weight deltas of six probe tensors across the four sub-networks."""
+    import train_utils.train_KVNet as tk
+    t = TRAIN
+    cam = camera.scannet_intrinsics(t["W"] // 4, t["H"] // 4)
+    d_candi = np.linspace(0.1, 5, t["D"])
+    with ref_shim.quiet():
+        model = ref.KVNET.KVNET(64, cam, d_candi, t["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    model.load_state_dict(synth.seeded_state_dict(model, t["weight_seed"]))
+    opt = torch.optim.SGD(model.parameters(), lr=t["lr"])
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    pred, out = None, {}
+    for it, (r, s_, p, dm, dmf) in enumerate(train_inputs()):
+        Rd = [{"img": r, "dmap": dm, "dmap_imgsize_digit": dmf, "dmap_raw": torch.zeros(1, t["H"] // 4, t["W"] // 4),
+               "dmap_imgsize": torch.zeros(1, t["H"], t["W"])}]
+        Sd = [[{"img": s_[0, v:v + 1]} for v in range(4)]]
+        before = {k: model.state_dict()[k].detach().clone() for k in t["probes"]}
+        with ref_shim.quiet():
+            _, pred, loss, _, _ = tk.train(1, model, opt, 2, d_candi, Rd, Sd, p, pred, [cam])
+        out["loss_%d" % it] = float(loss)
+        out["pred_%d" % it] = pred[0].detach().numpy()
+        for k in t["probes"]:
+            out["delta_%d_%s" % (it, k)] = (model.state_dict()[k].detach() - before[k]).numpy()
+        pred = pred.detach()
+        print("train_small: iteration %d loss %.6f" % (it, float(loss)))
+    out["weights_checksum"] = checksum(sd0.values())
+    np.savez(os.path.join(OUT, "train_small.npz"), **out)
+
+
 FP64_S = dict(H=256, W=384, D=64, seeds=(101, 102), sigma=10.0, d_min=0.1, d_max=5.0, weight_seed=0)   # = config S test
 
 
@@ -293,9 +344,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shim.load()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["ops", "net", "scene", "ops67", "fp64", "fp64S", "lba", "export"]
+    which = sys.argv[1:] or ["ops", "net", "scene", "ops67", "fp64", "fp64S", "lba", "export", "train"]
     for name in which:
-        {"ops": gen_ops, "net": gen_net, "scene": gen_scene, "ops67": gen_ops67, "fp64": gen_fp64, "fp64S": gen_fp64_S, "lba": gen_lba, "export": gen_export}[name](ref)
+        {"ops": gen_ops, "net": gen_net, "scene": gen_scene, "ops67": gen_ops67, "fp64": gen_fp64, "fp64S": gen_fp64_S, "lba": gen_lba, "export": gen_export, "train": gen_train}[name](ref)
 
 
 if __name__ == "__main__":

@@ -232,3 +232,44 @@ def test_train_graph_from_a_fresh_optimizer_warms_up_eagerly():
         assert abs(float(loss_g) - float(loss_e)) < 2e-3 * abs(float(loss_e))
     st = opt2.state[next(iter(twin.kv_net.parameters()))]
     assert float(st["step"]) == 3.0                      # the moments were not reset by the replays
+
+
+def test_training_iterations_vs_reference_golden():
+    """Two iterations of the drop-in train() (first-frame branch, then the update branch with 4 NLL terms) against the
+    reference's own train() run on CPU (tests/golden/train_small.npz, oracle/gen_golden.py::gen_train): loss, predicted
+    filter state, and the SGD weight change (= lr x gradient) of six probe tensors across feature CNN, K-Net and R-Net."""
+    import os
+    from conftest import GOLDEN
+    import neuralrgbd_amd
+    from neuralrgbd_amd.train_step import train
+    from oracle import gen_golden
+    t = gen_golden.TRAIN
+    g = dict(np.load(os.path.join(GOLDEN, "train_small.npz")))
+    cam = camera.scannet_intrinsics(t["W"] // 4, t["H"] // 4)
+    d_candi = np.linspace(0.1, 5, t["D"])
+    model = neuralrgbd_amd.KVNET(64, cam, d_candi, t["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    sd = synth.seeded_state_dict(model, t["weight_seed"])
+    assert abs(gen_golden.checksum(sd.values()) - float(g["weights_checksum"])) < 1e-6 * float(g["weights_checksum"])
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    opt = torch.optim.SGD(model.parameters(), lr=t["lr"])
+    pred = None
+    for it, (r, s, p, dm, dmf) in enumerate(gen_golden.train_inputs()):
+        before = {k: model.state_dict()[k].detach().clone() for k in t["probes"]}
+        _, pred, loss, _, _ = train(1, model, opt, 2, d_candi, [{"img": r, "dmap": dm, "dmap_imgsize_digit": dmf}],
+                                    [[{"img": s[0, v:v + 1]} for v in range(4)]], p, pred, [cam])
+        want = float(g["loss_%d" % it])
+        e_pred = (pred[0].cpu().numpy() - g["pred_%d" % it])
+        print("[parity] train iteration %d: loss %.6f vs reference %.6f; BV_predict mean|d| %.2e max %.2e" %
+              (it, float(loss), want, np.abs(e_pred).mean(), np.abs(e_pred).max()))
+        assert abs(float(loss) - want) < 2e-5 * want
+        assert np.abs(e_pred).mean() < 1e-4
+        for k in t["probes"]:
+            delta = (model.state_dict()[k].detach() - before[k]).cpu().numpy()
+            ref_d = g["delta_%d_%s" % (it, k)]
+            if it == 0 and np.abs(ref_d).max() == 0:      # the K-Net receives no gradient on the first frame
+                assert np.abs(delta).max() == 0
+                continue
+            rel = np.abs(delta - ref_d).max() / np.abs(ref_d).max()
+            print("[parity]   d %-62s rel err %.2e (|lr grad| max %.2e)" % (k, rel, np.abs(ref_d).max()))
+            assert rel < 2e-2, (k, rel)
