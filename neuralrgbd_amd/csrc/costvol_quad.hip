@@ -141,9 +141,11 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
     int id = blockIdx.x;
     if ((gridDim.x & 7) == 0) id = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int tile = id / a.nchunk, chunk = id - tile * a.nchunk;
-    // co-resident workgroups of a CU are consecutive in an XCD's dispatch order (u, u+1, u+2) or 32 apart (round robin)
+    // Developer switch (NRGBD_ABLATE bit 16): every other workgroup walks its candidates far -> near, to de-phase the
+    // staging-bound (near planes) and math-bound (far planes) parts of co-resident workgroups.  Measured: 288 us with,
+    // 277 us without at config B — the workgroups are not phase-locked; kept off.
     const int uq = blockIdx.x >> 3;
-    const bool rev = (((uq ^ (uq >> 5)) & 1) != 0) && !NRGBD_DBG(a, 16);
+    const bool rev = NRGBD_DBG(a, 16) && (((uq ^ (uq >> 5)) & 1) != 0);
     const int tiles_x = (a.w + kQT - 1) / kQT;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int kb = chunk * a.kchunk, ke = min(a.D, kb + a.kchunk);
@@ -327,10 +329,6 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
             }
         }
         __syncthreads();
-        // Every other workgroup walks its candidates far -> near instead of near -> far (`rev`).  The near planes are
-        // staging-bound (short runs, large footprints), the far planes math-bound (runs of 16 on one patch); workgroups that
-        // start together stay phase-locked, so without this all co-resident workgroups would stage at the same time (VALU
-        // idle) and then compute at the same time (patch fills idle).
         for (int lo = kb, hi = ke; lo < hi;) {
             // ---- largest run of 16 / 8 / 4 / 2 candidates whose united footprint fits the patch: lane l < 16 of every wave
             // holds the l-th next candidate, inclusive prefix union along the 16-lane DPP row ----

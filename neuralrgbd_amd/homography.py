@@ -22,7 +22,17 @@ from . import ops
 
 # Device-resident copies of the per-trajectory constants.  The reference re-uploads the
 # intrinsics, the ray table and d_candi on every call (homography.py:309-311, 247-249).
-_const_cache = {}
+import collections
+
+_const_cache = collections.OrderedDict()   # LRU: a long run builds a new intrinsics dict per trajectory / epoch
+_CONST_CACHE_MAX = 64
+
+
+def _cache_put(key, value):
+    _const_cache[key] = value
+    _const_cache.move_to_end(key)
+    while len(_const_cache) > _CONST_CACHE_MAX:
+        _const_cache.popitem(last=False)
 
 
 def _d_candi_dev(d_candi, device):
@@ -31,12 +41,20 @@ def _d_candi_dev(d_candi, device):
     hit = _const_cache.get(key)
     if hit is None:
         hit = torch.from_numpy(d32).to(device)
-        _const_cache[key] = hit
+        _cache_put(key, hit)
+    else:
+        _const_cache.move_to_end(key)
     return hit
 
 
 def _cam_dev(cam_intrinsic, device):
-    """(K [3,3], rays [3,hw]) on `device`, cached per intrinsics dict."""
+    """(K [3,3], rays [3,hw]) on `device`, cached per intrinsics dict (bounded LRU).  Dicts that carry only the
+    reference's minimal keys ('unit_ray_array' [h,w,3] + 'intrinsic_M') get the 2-D / fp32 forms built here."""
+    if "unit_ray_array_2D" not in cam_intrinsic and "unit_ray_array" in cam_intrinsic:
+        ura = np.asarray(cam_intrinsic["unit_ray_array"])
+        cam_intrinsic["unit_ray_array_2D"] = torch.from_numpy(ura.reshape(-1, 3).T.astype(np.float32).copy())
+    if "intrinsic_M_cuda" not in cam_intrinsic and "intrinsic_M" in cam_intrinsic:
+        cam_intrinsic["intrinsic_M_cuda"] = torch.from_numpy(np.asarray(cam_intrinsic["intrinsic_M"])[:3, :3].astype(np.float32))
     src = cam_intrinsic["unit_ray_array_2D"]
     key = ("cam", id(src), str(device))
     hit = _const_cache.get(key)
@@ -44,7 +62,9 @@ def _cam_dev(cam_intrinsic, device):
         K = cam_intrinsic["intrinsic_M_cuda"].to(device=device, dtype=torch.float32).contiguous()
         rays = src.to(device=device, dtype=torch.float32).contiguous()
         hit = (src, K, rays)
-        _const_cache[key] = hit
+        _cache_put(key, hit)
+    else:
+        _const_cache.move_to_end(key)
     return hit[1], hit[2]
 
 

@@ -136,6 +136,11 @@ class KVNET(nn.Module):
             self.r_net = nets.DPVUpsampleNet(int(feature_dim), int(feature_dim / 2), 3,
                                              D=len(d_candi), upsample_D=if_upsample_d)
 
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        nets.invalidate_packed_weights(self)      # packed B-operand streams are keyed on tensor versions (nets.py)
+        return out
+
     def _refine(self, dpv_log, features):
         return self.r_net(torch.exp(dpv_log), img_features=features)
 

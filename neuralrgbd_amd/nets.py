@@ -83,6 +83,29 @@ def _packed_weights(owner, conv):
     return hit[1]
 
 
+def invalidate_packed_weights(module):
+    """Drop every cached packed-weight stream below `module`.  The caches are keyed on (data_ptr, tensor version), which an
+    update through `.data` (`w.data.copy_()`, EMA, manual surgery) does not bump — call this after such an update.
+    `load_state_dict` and `_apply` (.to / .cuda / .float) of the networks below call it themselves."""
+    for m in module.modules():
+        m.__dict__.pop("_wp_cache", None)
+        m.__dict__.pop("_pk_cache", None)
+
+
+class _PackedWeightsMixin(object):
+    """nn.Module mixin: invalidate the packed-weight caches whenever the parameters are replaced wholesale."""
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        invalidate_packed_weights(self)
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        invalidate_packed_weights(self)
+        return out
+
+
 def _bn_scale_shift(bn, stats, count):
     """(scale, shift) [C,2] of a BatchNorm: batch statistics from the conv epilogue's partials in train mode (the
     reference never leaves it) incl. the running-statistics side effect; running statistics in eval mode."""
@@ -149,7 +172,7 @@ class ResBlock2d(nn.Module):
         return _conv_bn_act(y, self.conv2, relu=False, residual=skip)
 
 
-class PSMFeatures(nn.Module):
+class PSMFeatures(_PackedWeightsMixin, nn.Module):
     """PSMNet-style pyramid feature CNN: 1/2-res stem, 1/4-res trunk, 4-scale SPP, 1x1 head.
 
     Output: (layer1 [N,32,H/2,W/2], feat [N,feature_dim,H/4,W/4]) when multi_scale, else feat.
@@ -393,7 +416,7 @@ class FeatureExtractor(nn.Module):
 
 
 # --------------------------------------------------------------------------- K-Net (3-D)
-class KalmanGainNet(nn.Module):
+class KalmanGainNet(_PackedWeightsMixin, nn.Module):
     """K-Net: 12 conv3d 3x3x3 (16->64, 10x 64->64, 64->1), BN3d + ReLU, 4 residual pairs.
 
     gain = kv_net(volume[1,16,D,h,w]) -> [1,1,D,h,w]   (basic.py:53-139)

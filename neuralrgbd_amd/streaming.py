@@ -19,12 +19,17 @@ from . import homography as warp_homo
 
 
 class DepthStream:
-    def __init__(self, model, cam_intrinsics, d_candi, t_win_r=2, use_graph=True, device=None):
+    def __init__(self, model, cam_intrinsics, d_candi, t_win_r=2, use_graph=True, device=None, copy_outputs=False):
         self.model = model
         self.cam = cam_intrinsics
         self.d_candi = d_candi
         self.t_win_r = t_win_r
         self.use_graph = use_graph
+        # Once the hipGraph is active, step() hands out the graph's STATIC output buffers: the next step() overwrites them
+        # in place, so a caller that keeps per-frame results (a list for export / evaluation) must either pass
+        # copy_outputs=True (clones: +0.2 GB/s of HBM traffic at config B) or clone what it keeps.  The eager path
+        # returns fresh tensors either way.
+        self.copy_outputs = copy_outputs
         self.device = device if device is not None else next(model.parameters()).device
         self.bv_predict = None          # [1,D,h,w] log-DPV predicted for the next frame, or None (fresh stream)
         self._graph = None
@@ -59,7 +64,8 @@ class DepthStream:
     # ------------------------------------------------------------------ public step
     def step(self, ref_frame, src_frames, src_cam_poses, cam_pose_next=None):
         """ref_frame [1,3,H,W], src_frames [1,V,3,H,W], src_cam_poses [1,V,4,4] (device tensors).
-        Returns (refined DPV [1,D,H,W], DPV [1,D,h,w]); the predicted state for the next frame is kept inside."""
+        Returns (refined DPV [1,D,H,W], DPV [1,D,h,w]); the predicted state for the next frame is kept inside.
+        With the hipGraph active and copy_outputs=False the returned tensors are only valid until the next step()."""
         pose = src_cam_poses[0, self.t_win_r] if cam_pose_next is None else cam_pose_next
         pose_next_inv = torch.linalg.inv(pose)  # outside the graph: the solver may allocate / sync
         if self.bv_predict is None:                      # first window of the stream: D-Net only
@@ -80,7 +86,9 @@ class DepthStream:
             self._graph.replay()
             r, dpv, nxt = st["out"]
             self.bv_predict = nxt        # static output buffer: copied into st["bv"] at the next step
-            return r, dpv
+            if self.copy_outputs:
+                return r.clone(), dpv.clone()
+            return r, dpv                # valid until the next step() (see copy_outputs)
         r, dpv, nxt = self._frame(ref_frame, src_frames, src_cam_poses, pose_next_inv, self.bv_predict)
         self._eager_updates += 1
         self.bv_predict = nxt
