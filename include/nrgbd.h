@@ -289,6 +289,28 @@ int nrgbd_avgpool8(const float* x, float* y, int NC, int H, int W, void* stream)
 int nrgbd_bias_act_nchw(float* x, const float* bias, float slope, int N, int C, long HW, void* stream);
 
 /*
+ * R-Net (DPV up-sampler) on the same matrix-core kernel.  Replaces, per layer of models/Refine.py:51-107:
+ *   m_submodule.conv2d_leakyRelu (nn.Conv2d 3x3 + bias + LeakyReLU 0.01, :18-27)      mode 0
+ *   m_submodule.conv2dTranspose_leakyRelu (nn.ConvTranspose2d k4 s2 p1 + bias + LeakyReLU, :37-45)
+ *                                             as four sub-pixel 2x2-tap launches (pa, pb in {0,1})   mode 1
+ *   conv2_2 + F.log_softmax(dim=1) (:99-105)                                          mode 2
+ *   the torch.cat of :88,93,98: a layer writes its cout_valid channels at channel offset ycoff of a wider
+ *   channels-last pixel (pixel stride ldy floats), i.e. straight into the next layer's concat buffer.
+ * x [N][H][W][Cin] channels-last, Cin % 16 == 0 (zero-padded channels carry zero weights);
+ * w_packed: nrgbd_conv_pack_weights of w [Cout][Cin][taps], taps = 9 (modes 0, 2) or 4 (mode 1: the phase's 2x2 taps in
+ *   row-major order of the input neighbourhood {y-1+pa, y+pa} x {x-1+pb, x+pb}); Cout in {64, 96, 128} (mode 0), 64 (1, 2);
+ * bias [Cout] (padded) or NULL.  mode 0: y[pix*ldy + ycoff + c], c < cout_valid.  mode 1: the same at output pixel
+ *   (2y+pa, 2x+pb) of a [N][2H][2W] tensor.  mode 2: y = planar [N][Cout][H][W] log-probabilities (ldy.. ignored).
+ * nrgbd_rnet_pack: out [P][D+Cf] = (exp(dpv_log [D][P]), feat) — the R-Net's first concat with torch.exp fused
+ *   (models/KVNET.py:128,176 + Refine.py:88); feat is [P][Cf] (feat_planar = 0) or [Cf][P].
+ */
+int nrgbd_conv2d_rnet_f32(const float* x, const float* w_packed, const float* bias, int out_lrelu, float* y,
+                          int ldy, int ycoff, int cout_valid, int mode, int pa, int pb,
+                          int N, int H, int W, int Cin, int Cout, void* stream);
+int nrgbd_rnet_pack(const float* dpv_log, const float* feat, int feat_planar, float* out, int D, int Cf, long P,
+                    void* stream);
+
+/*
  * Feature CNN (and R-Net form): 3x3 convolution, stride 1, padding = dilation, on the fp32 matrix cores with the
  * BatchNorm2d / ReLU / residual work fused around it — the 2-D sibling of nrgbd_conv3d_3x3x3_f32.
  * Replaces, per trunk layer of models/psm_submodule.py:90-167 (feature_extraction; convbn :10-16, BasicBlock :31-50):

@@ -38,15 +38,27 @@ struct Conv2dArgs {
     int x_relu, res_relu, out_lrelu;
     int N, H, W, Cin;
     int xcd;              // re-map workgroups so each XCD owns a contiguous run of tiles (conv_tile.hpp)
+    // generalised output addressing (R-Net, models/Refine.py:51-107): defaults = plain [N][H][W][COUT]
+    int ldy;              // pixel stride of y in floats (>= ycoff + cout_valid): lets a layer write straight INTO a concat buffer
+    int ycoff;            // first channel of y this layer writes
+    int cout_valid;       // columns that exist (< COUT when Cout was padded to the 32-wide fragments)
+    int up;               // 1: this launch is sub-pixel phase (pa, pb) of a stride-2 transposed conv: 2x2 taps, output pixel
+    int pa, pb;           //    (2y+pa, 2x+pb) of a [N][2H][2W] tensor
+    float* planar;        // EPI = 1: log_softmax over the COUT channels, written as [N][COUT][H][W] (the R-Net's last layer)
 };
 
-template <int COUT, int DIL, bool RES>
+// NTAP = 9: 3x3 convolution.  NTAP = 4: one sub-pixel phase of ConvTranspose2d(k=4, s=2, p=1) (m_submodule.py:37-45): output
+// pixel (2y+pa, 2x+pb) sums the 2x2 input neighbourhood rows {y-1+pa, y+pa} x cols {x-1+pb, x+pb} — a 2x2-tap convolution
+// on the same halo tile; the four phases are four launches, so no multiply-by-zero is ever issued.
+// EPI = 1: bias, then log_softmax over the COUT columns of every pixel, stored planar (Refine.py:101-105).
+template <int COUT, int DIL, bool RES, int NTAP = 9, int EPI = 0>
 __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(const Conv2dArgs a) {
     constexpr int HS = kT2 + 2 * DIL, HALO = HS * HS;   // halo tile edge / pixels (324 | 400)
     constexpr int NPF = (HALO * (kCB / 4) + 255) / 256;  // 16-B words per thread per channel block (6 | 7)
     constexpr int NF = COUT / 32;                        // 32-column output fragments
     constexpr int G4 = kCB / 8;                          // k-groups per block (4 k-steps = 8 channels each)
-    constexpr int NSTEP = 9 * G4;
+    constexpr int NSTEP = NTAP * G4;
+    static_assert(NTAP == 9 || (NTAP == 4 && DIL == 1), "2x2 taps are the stride-2 transposed-conv phases");
     static_assert(2 + (RES ? 2 : 1) * NPF <= NSTEP, "prefetch does not fit the step loop");
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [HALO][kSV]; reused for the statistics
 
@@ -64,7 +76,8 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
     int dy, px;
     row_to_yx(i, dy, px);
     const int wy = wv * 4;
-    const int hv0 = (wy + dy) * HS + px;   // m = 0, tap (0,0); m = 1 is two rows further
+    // m = 0, tap (0,0); m = 1 is two rows further.  A transposed-conv phase starts its 2x2 window at halo offset (pa, pb).
+    const int hv0 = (wy + dy) * HS + px + (NTAP == 4 ? a.pa * HS + a.pb : 0);
 
     f32x16 acc[2][NF];
 #pragma unroll
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
             const int cur = s & 1, nxt = cur ^ 1;
             if (s + 1 < NSTEP) {  // A operands of step s+1
                 const int tap = (s + 1) / G4, g = (s + 1) % G4;
-                const int voff = ((tap / 3) * HS + (tap % 3)) * DIL;  // tap offset in halo pixels
+                const int voff = NTAP == 9 ? ((tap / 3) * HS + (tap % 3)) * DIL : (tap >> 1) * HS + (tap & 1);  // tap offset in halo pixels
                 int h0 = hv0;
                 asm volatile("" : "+v"(h0));  // keep the swizzled addresses out of long-lived registers
                 An[nxt][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(h0 + voff, khalf * 2 + g));
@@ -198,6 +211,54 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
     float s1[NF], s2[NF], bs[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) { s1[f] = 0.f; s2[f] = 0.f; bs[f] = a.bias ? a.bias[f * 32 + i] : 0.f; }
+    if constexpr (EPI == 1) {
+        // log_softmax over the COUT columns of each pixel: a pixel (MFMA row) lives in register r of the 32 lanes of its
+        // half-wave, one column per lane and fragment -> max / sum over the fragments in the lane, then a 5-step butterfly
+        // across the 32 lanes.  Stored planar [N][COUT][H][W]: registers 4q..4q+3 of a lane are 4 consecutive x of one row,
+        // i.e. one 16-byte store into the lane's own channel plane.
+        const size_t plane = (size_t)a.H * a.W;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float z[4][NF];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) { z[e][f] = acc[m][f][4 * q + e] + bs[f]; mx = fmaxf(mx, z[e][f]); }
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                    float sm = 0.f;
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) { z[e][f] = z[e][f] - mx; sm += expf(z[e][f]); }
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) sm += __shfl_xor(sm, o, 64);
+                    const float ls = logf(sm);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) z[e][f] = z[e][f] - ls;
+                }
+                const int row = 8 * q + 4 * khalf;               // first of the 4 MFMA rows held in registers 4q..4q+3
+                int ry, rx;
+                row_to_yx(row, ry, rx);
+                const int gy = y0 + wy + 2 * m + ry, gx = x0 + rx;
+                if (gy < a.H) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        float* o = a.planar + ((size_t)n * COUT + f * 32 + i) * plane + (size_t)gy * a.W + gx;
+                        if (gx + 3 < a.W && (a.W & 3) == 0) {
+                            *reinterpret_cast<f32x4*>(o) = f32x4{z[0][f], z[1][f], z[2][f], z[3][f]};
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (gx + e < a.W) o[e] = z[e][f];
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -207,12 +268,13 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
             row_to_yx(row, ry, rx);
             const int gy = y0 + wy + 2 * m + ry, gx = x0 + rx;
             if (gy < a.H && gx < a.W) {
-                const size_t pix = ((size_t)n * a.H + gy) * a.W + gx;
+                const size_t pix = a.up ? ((size_t)n * (2 * a.H) + 2 * gy + a.pa) * (2 * a.W) + 2 * gx + a.pb
+                                        : ((size_t)n * a.H + gy) * a.W + gx;
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
                     float z = acc[m][f][r] + bs[f];
                     if (a.out_lrelu) z = z > 0.f ? z : 0.01f * z;
-                    a.y[pix * COUT + f * 32 + i] = z;
+                    if (f * 32 + i < a.cout_valid) a.y[pix * a.ldy + a.ycoff + f * 32 + i] = z;
                     s1[f] += z;
                     s2[f] = __builtin_fmaf(z, z, s2[f]);
                 }
@@ -360,6 +422,14 @@ static void launch_conv2d(const Conv2dArgs& a, int nwg, hipStream_t st) {
     else       hipLaunchKernelGGL((conv2d_mfma_kernel<COUT, DIL, false>), dim3(nwg), dim3(256), lds, st, a);
 }
 
+// R-Net forms: no residual operand, dilation 1; NTAP = 4 (transposed-conv phase) or EPI = 1 (planar log-softmax)
+template <int COUT, int NTAP, int EPI>
+static void launch_conv2d_ex(const Conv2dArgs& a, int nwg, hipStream_t st) {
+    constexpr int HS = kT2 + 2;
+    const size_t lds = (size_t)HS * HS * kSV * sizeof(float);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<COUT, 1, false, NTAP, EPI>), dim3(nwg), dim3(256), lds, st, a);
+}
+
 }  // namespace nrgbd
 
 extern "C" int nrgbd_conv2d_workgroups(int N, int H, int W) {
@@ -371,7 +441,7 @@ extern "C" int nrgbd_conv2d_workgroups(int N, int H, int W) {
 extern "C" int nrgbd_conv_pack_weights(const float* w, float* wp, int Cin, int Cout, int taps, void* stream) {
     using namespace nrgbd;
     if (!w || !wp) return NRGBD_E_NULL;
-    if (Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 32 || (taps != 9 && taps != 27)) return NRGBD_E_SHAPE;
+    if (Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 32 || (taps != 9 && taps != 27 && taps != 4)) return NRGBD_E_SHAPE;
     const long total = (long)taps * Cin * Cout;
     hipLaunchKernelGGL(conv_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        w, wp, Cin, Cout, taps);
@@ -388,7 +458,7 @@ extern "C" int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_rel
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB) return NRGBD_E_SHAPE;
     if ((long)N * H * W * Cin >= (1L << 32)) return NRGBD_E_SHAPE;  // 32-bit element offsets in the loader
     Conv2dArgs a{x, x_ss, res, res_ss, materialized, w_packed, bias, y, stats, x_relu, res_relu, out_lrelu, N, H, W, Cin,
-                 dev_env_int("NRGBD_XCD")};
+                 dev_env_int("NRGBD_XCD"), Cout, 0, Cout, 0, 0, 0, nullptr};
     const int nwg = ceil_div(W, kT2) * ceil_div(H, kT2) * N;
     hipStream_t st = (hipStream_t)stream;
     if (dilation == 1 && Cout == 32) launch_conv2d<32, 1>(a, nwg, st);
@@ -397,6 +467,76 @@ extern "C" int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_rel
     else if (dilation == 1 && Cout == 128) launch_conv2d<128, 1>(a, nwg, st);
     else if (dilation == 2 && Cout == 128) launch_conv2d<128, 2>(a, nwg, st);
     else return NRGBD_E_SHAPE;
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+extern "C" int nrgbd_conv2d_rnet_f32(const float* x, const float* w_packed, const float* bias, int out_lrelu, float* y,
+                                     int ldy, int ycoff, int cout_valid, int mode, int pa, int pb, int N, int H, int W,
+                                     int Cin, int Cout, void* stream) {
+    using namespace nrgbd;
+    if (!x || !w_packed || !y) return NRGBD_E_NULL;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB) return NRGBD_E_SHAPE;
+    if ((long)N * H * W * Cin >= (1L << 32)) return NRGBD_E_SHAPE;
+    if (mode < 0 || mode > 2 || (pa & ~1) || (pb & ~1)) return NRGBD_E_ARG;
+    if (mode != 2 && (cout_valid <= 0 || cout_valid > Cout || ycoff < 0 || ldy < ycoff + cout_valid)) return NRGBD_E_SHAPE;
+    Conv2dArgs a{x, nullptr, nullptr, nullptr, nullptr, w_packed, bias, y, nullptr, 0, 0, out_lrelu, N, H, W, Cin,
+                 0, ldy, ycoff, cout_valid, mode == 1 ? 1 : 0, pa, pb, mode == 2 ? y : nullptr};
+    const int nwg = ceil_div(W, kT2) * ceil_div(H, kT2) * N;
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) {          // 3x3 convolution (+ bias, LeakyReLU), output anywhere inside a wider pixel
+        if (Cout == 64) launch_conv2d_ex<64, 9, 0>(a, nwg, st);
+        else if (Cout == 96) launch_conv2d_ex<96, 9, 0>(a, nwg, st);
+        else if (Cout == 128) launch_conv2d_ex<128, 9, 0>(a, nwg, st);
+        else return NRGBD_E_SHAPE;
+    } else if (mode == 1) {   // one phase of ConvTranspose2d(k4, s2, p1)
+        if (Cout == 64) launch_conv2d_ex<64, 4, 0>(a, nwg, st);
+        else return NRGBD_E_SHAPE;
+    } else {                  // last layer: bias + log_softmax over the channels, planar output
+        if (Cout == 64) launch_conv2d_ex<64, 9, 1>(a, nwg, st);
+        else return NRGBD_E_SHAPE;
+    }
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+// R-Net input assembly (Refine.py:88): x0[p][0..D-1] = exp(dpv_log[d][p]) (the caller's torch.exp), x0[p][D..D+Cf-1] =
+// quarter-resolution features (channels-last [P][Cf] or planar [Cf][P]); one pass instead of exp + permute + cat.
+namespace nrgbd {
+__global__ __launch_bounds__(256) void rnet_pack_kernel(const float* __restrict__ dpv_log, const float* __restrict__ feat,
+                                                        int feat_planar, float* __restrict__ out, int D, int Cf, long P) {
+    __shared__ float tile[64][65];
+    const long p0 = (long)blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int C = D + Cf;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        // a 64-channel x 64-pixel block through LDS: planar reads coalesced along p, channels-last writes along c
+        for (int c = wv; c < 64 && c0 + c < C; c += 4) {
+            const int ch = c0 + c;
+            const long p = p0 + lane;
+            float v = 0.f;
+            if (p < P) {
+                if (ch < D) v = expf(dpv_log[(size_t)ch * P + p]);
+                else v = feat_planar ? feat[(size_t)(ch - D) * P + p] : feat[(size_t)p * Cf + (ch - D)];
+            }
+            tile[c][lane] = v;
+        }
+        __syncthreads();
+        for (int t = tid; t < 64 * 64; t += 256) {
+            const int px = t >> 6, c = t & 63;
+            if (p0 + px < P && c0 + c < C) out[(size_t)(p0 + px) * C + c0 + c] = tile[c][px];
+        }
+        __syncthreads();
+    }
+}
+}  // namespace nrgbd
+
+extern "C" int nrgbd_rnet_pack(const float* dpv_log, const float* feat, int feat_planar, float* out, int D, int Cf, long P,
+                               void* stream) {
+    if (!dpv_log || !feat || !out) return NRGBD_E_NULL;
+    if (D <= 0 || Cf <= 0 || P <= 0) return NRGBD_E_SHAPE;
+    hipLaunchKernelGGL(nrgbd::rnet_pack_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dpv_log,
+                       feat, feat_planar, out, D, Cf, P);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void warp_volume_kernel(const WarpVolArgs a) {
 // (channels 64..67 = R,G,B,0: one aligned 16-B word) of the NHWC texel tensor, output channels-last
 // [D][h][w][16] for conv3d.hip.  One lane = one (pixel, depth): 4 views x 4 taps x one 16-B load, the
 // 16 output channels leave as four 16-B stores (64 contiguous bytes per lane).
-__global__ __launch_bounds__(256) void warp_volume_cl16_kernel(const WarpVolArgs a) {
+template <bool ALIGN>
+__global__ __launch_bounds__(256) void warp_volume_cl16_kernel(const WarpVolArgs a, float rcx, float rcy) {
     const size_t hw = (size_t)a.h * a.w;
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256) void warp_volume_cl16_kernel(const WarpVolArgs
     for (int v = 0; v < 4; ++v) {
         const SweepTerm st = make_sweep_term(a.KR + 9 * v, a.Kt + 3 * v, rx, ry, rz);
         float ix, iy;
-        sweep_sample_pos(st, d, a.cx, a.cy, wf, hf, a.align != 0, ix, iy);
+        // same bits as sweep_sample_pos (common.hpp: exact constant-divisor and shared-reciprocal divisions)
+        sweep_sample_pos_fast<ALIGN>(st, d, a.cx, a.cy, rcx, rcy, wf, hf, ix, iy);
         const Bilinear b = bilinear_zeros(ix, iy, a.w, a.h);
         const float* s = a.src + v * a.sv;
         const float4 A = *reinterpret_cast<const float4*>(s + b.y0 * a.sy + b.x0 * a.sx);
@@ -107,9 +109,11 @@ extern "C" int nrgbd_warp_volume(const float* src, long sv, long sc, long sy, lo
     const bool word_src = Cs == 3 && sc == 1 && rc == 1 && !((sv | sy | sx | ry | rx) & 3) &&
                           !((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(ref) |
                              reinterpret_cast<uintptr_t>(out)) & 15);
-    if (channels_last && V == 4 && ref && bv_cur && word_src)
-        hipLaunchKernelGGL(warp_volume_cl16_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else
+    const float rcx = (float)(1.0 / (double)cx), rcy = (float)(1.0 / (double)cy);
+    if (channels_last && V == 4 && ref && bv_cur && word_src) {
+        if (align_corners) hipLaunchKernelGGL(warp_volume_cl16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, rcx, rcy);
+        else hipLaunchKernelGGL(warp_volume_cl16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, rcx, rcy);
+    } else
         hipLaunchKernelGGL(warp_volume_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;

@@ -142,6 +142,8 @@ class KVNET(nn.Module):
         return out
 
     def _refine(self, dpv_log, features):
+        if hasattr(self.r_net, "forward_log") and not torch.is_grad_enabled():
+            return self.r_net.forward_log(dpv_log, features)      # exp fused into the first concat; matrix-core convs
         return self.r_net(torch.exp(dpv_log), img_features=features)
 
     def forward(self, ref_frame, src_frames, src_cam_poses, BatchIdx, cam_intrinsics=None,
@@ -186,8 +188,10 @@ class KVNET(nn.Module):
             K, rays = warp_homo._cam_dev(cam, dev)
             cx, cy = cam['intrinsic_M'][0, 2], cam['intrinsic_M'][1, 2]
         KR, Kt = warp_homo.homography_terms(K, src_cam_poses[0, :, :3, :3], src_cam_poses[0, :, :3, 3])
-        rgb_src = texels[:V, :, :, F_dim:]    # strided views into the texel tensor, no copies
-        rgb_ref = texels[V, :, :, F_dim:]
+        # the RGB word of every texel as a compact [V+1,h,w,4] plane: at the texel tensor's 272-B stride every lane of the
+        # warp kernel's gathers touched its own cache line; at 16 B per texel four neighbouring taps share one
+        rgb4 = texels[..., F_dim:].contiguous()
+        rgb_src, rgb_ref, Cp = rgb4[:V], rgb4[V], rgb4.shape[-1]
         fused = (not torch.is_grad_enabled()) and self.kv_net.in_channels == 16 and self.KVNet_feature_dim == 64 \
             and not self.kv_net.if_normalize and self.kv_net.up_sample_ratio is None
         warp_args = (rgb_src, (h * w * Cp, 1, w * Cp, Cp), rgb_ref, (1, w * Cp, Cp), KR, Kt, rays,

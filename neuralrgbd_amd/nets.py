@@ -564,7 +564,7 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
 
 
 # --------------------------------------------------------------------------- R-Net (DPV up-sampler)
-class DPVUpsampleNet(nn.Module):
+class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
     """R-Net: 2-level conv / transposed-conv decoder over the DPV (D as channels) and the
     1/4-, 1/2- and full-resolution image features; log-softmax over D at the end.
 
@@ -625,6 +625,97 @@ class DPVUpsampleNet(nn.Module):
         x = layer(self.conv2_1, layer(self.conv2, torch.cat([x, full], dim=1)))
         x = layer(self.conv2_2, x, slope=1.0)
         return ops.logsoftmax_d(x[0]).unsqueeze(0)
+
+    # ------------------------------------------------------------------ hand-written matrix-core path (inference)
+    def mfma_ok(self, dpv):
+        """The R-Net on csrc/conv2d.hip: the canonical widths (D = 64 candidates + 64 / 32 / 3 image-feature channels),
+        batch 1, inference.  NRGBD_RNET = mfma | vendor | auto (default) selects; other widths use the vendor path."""
+        import os
+        mode = os.environ.get("NRGBD_RNET", "auto")
+        shapes = (self.conv0[0].in_channels == 128 and self.conv1[0].in_channels == 96 and
+                  self.conv2[0].in_channels == 67 and self.conv2_2.out_channels == 64 and
+                  self.trans_conv0[0].out_channels == 64 and self.trans_conv1[0].out_channels == 64)
+        return mode != "vendor" and shapes and dpv.is_cuda and not torch.is_grad_enabled() and dpv.shape[0] == 1
+
+    def _rnet_packed(self):
+        """Packed B-operand streams + padded biases of the nine layers (cached; see invalidate_packed_weights)."""
+        from . import ops
+        cache = self.__dict__.setdefault("_pk_cache", {})
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if cache.get("key") == key:
+            return cache["val"]
+
+        def conv(m, cin_p, cout_p):
+            c = m[0] if isinstance(m, nn.Sequential) else m
+            w, b = c.weight.detach(), c.bias.detach()
+            wp = w.new_zeros(cout_p, cin_p, 3, 3)
+            wp[:w.shape[0], :w.shape[1]] = w
+            bp = b.new_zeros(cout_p)
+            bp[:b.shape[0]] = b
+            return ops.conv_pack_weights(wp.contiguous()), bp.contiguous()
+
+        def deconv(m):
+            c = m[0]
+            w, b = c.weight.detach(), c.bias.detach()          # [Cin, Cout, 4, 4]
+            phases = {}
+            for pa in (0, 1):
+                for pb in (0, 1):
+                    ky = [3, 1] if pa == 0 else [2, 0]        # kernel row that links input row y-1+pa+ty to output row 2y+pa
+                    kx = [3, 1] if pb == 0 else [2, 0]
+                    wph = w[:, :, ky][:, :, :, kx].permute(1, 0, 2, 3).contiguous()   # [Cout, Cin, 2, 2]
+                    phases[(pa, pb)] = ops.conv_pack_weights(wph)
+            return phases, b.contiguous()
+
+        val = {"conv0": conv(self.conv0, 128, 128), "conv0_1": conv(self.conv0_1, 128, 128), "t0": deconv(self.trans_conv0),
+               "conv1": conv(self.conv1, 96, 96), "conv1_1": conv(self.conv1_1, 96, 96), "t1": deconv(self.trans_conv1),
+               "conv2": conv(self.conv2, 80, 96), "conv2_1": conv(self.conv2_1, 80, 64), "conv2_2": conv(self.conv2_2, 64, 64)}
+        cache["key"], cache["val"] = key, val
+        return val
+
+    def _rnet_buffers(self, h, w, dev):
+        """Persistent channels-last concat buffers (zero-initialised ONCE: the 13 padding channels of the two 80-wide
+        full-resolution buffers are never written and must stay zero)."""
+        cache = self.__dict__.setdefault("_buf_cache", {})
+        key = (h, w, str(dev))
+        if key not in cache:
+            cache.clear()
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+            cache[key] = {"c1": z(1, 2 * h, 2 * w, 96), "c2": z(1, 4 * h, 4 * w, 80), "g2": z(1, 4 * h, 4 * w, 80)}
+        return cache[key]
+
+    def forward_log(self, dpv_log, img_features):
+        """Same result as forward(torch.exp(dpv_log), img_features) (models/KVNET.py:128,176 + Refine.py:79-107) with the
+        exp fused into the first concat; on the matrix-core kernels when mfma_ok()."""
+        if not self.mfma_ok(dpv_log):
+            return self.forward(torch.exp(dpv_log), img_features)
+        from . import ops
+        quarter, half, full = img_features
+        h, w = dpv_log.shape[2:]
+        dev = dpv_log.device
+        pk, buf = self._rnet_packed(), self._rnet_buffers(h, w, dev)
+        # level 1/4: cat(exp(dpv), feat) -> conv0 -> conv0_1
+        q_cl = quarter.permute(0, 2, 3, 1)
+        if q_cl.is_contiguous():
+            x = ops.rnet_pack(dpv_log[0].contiguous(), q_cl[0], feat_planar=False)
+        else:
+            x = ops.rnet_pack(dpv_log[0].contiguous(), quarter[0].contiguous(), feat_planar=True)
+        x = ops.conv2d_rnet(x, pk["conv0"][0], 128, bias=pk["conv0"][1])
+        x = ops.conv2d_rnet(x, pk["conv0_1"][0], 128, bias=pk["conv0_1"][1])
+        # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..63 of the concat buffer; features 64..95
+        c1 = buf["c1"]
+        for (pa, pb), wp in pk["t0"][0].items():
+            ops.conv2d_rnet(x, wp, 64, bias=pk["t0"][1], out=c1, ldy=96, ycoff=0, cout_valid=64, mode=1, pa=pa, pb=pb)
+        c1[..., 64:].copy_(half.permute(0, 2, 3, 1))
+        x = ops.conv2d_rnet(c1, pk["conv1"][0], 96, bias=pk["conv1"][1])
+        x = ops.conv2d_rnet(x, pk["conv1_1"][0], 96, bias=pk["conv1_1"][1])
+        # full resolution: 64 + 3 channels in 80-wide pixels (padding channels zero, with zero weights)
+        c2, g2 = buf["c2"], buf["g2"]
+        for (pa, pb), wp in pk["t1"][0].items():
+            ops.conv2d_rnet(x, wp, 64, bias=pk["t1"][1], out=c2, ldy=80, ycoff=0, cout_valid=64, mode=1, pa=pa, pb=pb)
+        c2[..., 64:67].copy_(full.permute(0, 2, 3, 1))
+        ops.conv2d_rnet(c2, pk["conv2"][0], 96, bias=pk["conv2"][1], out=g2, ldy=80, ycoff=0, cout_valid=67)
+        x = ops.conv2d_rnet(g2, pk["conv2_1"][0], 64, bias=pk["conv2_1"][1])
+        return ops.conv2d_rnet(x, pk["conv2_2"][0], 64, bias=pk["conv2_2"][1], lrelu=False, mode=2)
 
     def forward(self, dpv_raw, img_features):
         if dpv_raw.is_cuda and not torch.is_grad_enabled() and dpv_raw.shape[0] == 1 \

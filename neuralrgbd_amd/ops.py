@@ -380,6 +380,44 @@ def conv2d(x, w_packed, cout, dilation=1, x_ss=None, x_relu=False, res=None, res
     return y, stats, mat
 
 
+def conv2d_rnet(x, w_packed, cout, bias=None, lrelu=True, out=None, ldy=None, ycoff=0, cout_valid=None, mode=0, pa=0, pb=0):
+    """R-Net layer on the matrix cores (nrgbd_conv2d_rnet_f32).  x [N,H,W,Cin] channels-last.
+    mode 0: 3x3 conv -> out[..., ycoff:ycoff+cout_valid] of a [N,H,W,ldy] buffer (allocated [N,H,W,cout_valid] if None);
+    mode 1: sub-pixel phase (pa, pb) of ConvTranspose2d(k4,s2,p1) -> the same inside a [N,2H,2W,ldy] buffer (required);
+    mode 2: conv + bias + log_softmax over the channels -> planar [N,cout,H,W]."""
+    x = _need(x, "x")
+    N, H, W, Cin = x.shape
+    cv = cout if cout_valid is None else cout_valid
+    if mode == 2:
+        out = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device)
+        ldy = cout
+    elif out is None:
+        if mode == 1:
+            raise ValueError("conv2d_rnet: a transposed-conv phase writes into a caller-provided [N,2H,2W,ldy] buffer")
+        out = torch.empty((N, H, W, cv), dtype=torch.float32, device=x.device)
+        ldy = cv
+    elif ldy is None:
+        ldy = out.shape[-1]
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv2d_rnet_f32(_p(x), _p(w_packed), _p(bias), int(bool(lrelu)), _p(out), int(ldy), int(ycoff),
+                                                int(cv), int(mode), int(pa), int(pb), N, H, W, Cin, int(cout), _stream(x))
+    _lib.check(rc, "nrgbd_conv2d_rnet_f32")
+    return out
+
+
+def rnet_pack(dpv_log, feat, feat_planar):
+    """dpv_log [D,h,w] (log-prob), feat [h,w,Cf] (or [Cf,h,w] if feat_planar) -> [1,h,w,D+Cf] = cat(exp(dpv), feat)."""
+    dpv_log = _need(dpv_log, "dpv_log")
+    feat = _need(feat, "feat")
+    D, h, w = dpv_log.shape
+    Cf = feat.shape[0] if feat_planar else feat.shape[-1]
+    out = torch.empty((1, h, w, D + Cf), dtype=torch.float32, device=dpv_log.device)
+    with torch.cuda.device(dpv_log.device):
+        rc = _lib.load().nrgbd_rnet_pack(_p(dpv_log), _p(feat), int(bool(feat_planar)), _p(out), D, Cf, h * w, _stream(dpv_log))
+    _lib.check(rc, "nrgbd_rnet_pack")
+    return out
+
+
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
     """Per-workgroup partials [nwg, 2C] -> scale_shift [C,2]; updates the running statistics in place (train mode)."""
     stats = _need(stats, "stats")

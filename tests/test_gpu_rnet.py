@@ -1,0 +1,108 @@
+"""R-Net (models/Refine.py:24-107) on the hand-written matrix-core kernels: every layer form against the torch operator it
+replaces (fp32), then the whole up-sampler against the nn.Module graph, both channel layouts of the image features."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from neuralrgbd_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,cin_pad,cout_pad", [(32, 48, 128, 128, 128, 128), (40, 56, 96, 96, 96, 96),
+                                                            (33, 50, 67, 67, 80, 96), (48, 64, 67, 64, 80, 64)])
+def test_conv3x3_bias_lrelu_into_wider_pixels(H, W, Cin, Cout, cin_pad, cout_pad):
+    """mode 0: conv2d_leakyRelu with zero-padded channels, written at a channel offset of a wider buffer."""
+    from neuralrgbd_amd import ops
+    x = _rand(1, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, 3, 3, seed=2, scale=0.05)
+    b = _rand(Cout, seed=3, scale=0.1)
+    want = F.leaky_relu(F.conv2d(x, w, b, 1, 1), 0.01)
+    xp = torch.zeros(1, H, W, cin_pad, device=DEV)
+    xp[..., :Cin] = x.permute(0, 2, 3, 1)
+    wp = torch.zeros(cout_pad, cin_pad, 3, 3, device=DEV)
+    wp[:Cout, :Cin] = w
+    bp = torch.zeros(cout_pad, device=DEV)
+    bp[:Cout] = b
+    ldy, off = Cout + 21, 8
+    out = torch.full((1, H, W, ldy), 7.0, device=DEV)
+    ops.conv2d_rnet(xp, ops.conv_pack_weights(wp), cout_pad, bias=bp, out=out, ldy=ldy, ycoff=off, cout_valid=Cout)
+    got = out[..., off:off + Cout].permute(0, 3, 1, 2)
+    err = (got - want).abs().max().item()
+    print("[parity] R-Net conv %d->%d %dx%d: max|d|=%.2e (|y|max %.1f)" % (Cin, Cout, H, W, err, want.abs().max().item()))
+    assert err < 2e-5 * max(1.0, want.abs().max().item())
+    assert bool((out[..., :off] == 7.0).all()) and bool((out[..., off + Cout:] == 7.0).all())   # nothing else touched
+
+
+@pytest.mark.parametrize("H,W,Cin", [(24, 40, 128), (33, 29, 96)])
+def test_transposed_conv_as_four_subpixel_phases(H, W, Cin):
+    """mode 1: ConvTranspose2d(k4, s2, p1) + bias + LeakyReLU = four 2x2-tap launches."""
+    from neuralrgbd_amd import ops
+    x = _rand(1, Cin, H, W, seed=4)
+    w = _rand(Cin, 64, 4, 4, seed=5, scale=0.05)
+    b = _rand(64, seed=6, scale=0.1)
+    want = F.leaky_relu(F.conv_transpose2d(x, w, b, 2, 1), 0.01)
+    xc = x.permute(0, 2, 3, 1).contiguous()
+    out = torch.zeros(1, 2 * H, 2 * W, 80, device=DEV)
+    for pa in (0, 1):
+        for pb in (0, 1):
+            ky = [3, 1] if pa == 0 else [2, 0]
+            kx = [3, 1] if pb == 0 else [2, 0]
+            wph = w[:, :, ky][:, :, :, kx].permute(1, 0, 2, 3).contiguous()
+            ops.conv2d_rnet(xc, ops.conv_pack_weights(wph), 64, bias=b, out=out, ldy=80, ycoff=0, cout_valid=64, mode=1, pa=pa, pb=pb)
+    got = out[..., :64].permute(0, 3, 1, 2)
+    err = (got - want).abs().max().item()
+    print("[parity] R-Net transposed conv %d->64 %dx%d: max|d|=%.2e" % (Cin, H, W, err))
+    assert err < 2e-5 * max(1.0, want.abs().max().item())
+    assert bool((out[..., 64:] == 0).all())
+
+
+@pytest.mark.parametrize("H,W", [(32, 48), (37, 45)])
+def test_last_conv_with_planar_log_softmax(H, W):
+    """mode 2: conv2_2 + bias + F.log_softmax(dim=1), stored [1,D,H,W]."""
+    from neuralrgbd_amd import ops
+    x = _rand(1, 64, H, W, seed=7)
+    w = _rand(64, 64, 3, 3, seed=8, scale=0.08)
+    b = _rand(64, seed=9, scale=0.1)
+    want = F.log_softmax(F.conv2d(x, w, b, 1, 1), dim=1)
+    got = ops.conv2d_rnet(x.permute(0, 2, 3, 1).contiguous(), ops.conv_pack_weights(w), 64, bias=b, lrelu=False, mode=2)
+    assert got.shape == want.shape and got.is_contiguous()
+    err = (got - want).abs().max().item()
+    print("[parity] R-Net conv2_2 + log-softmax %dx%d: max|d|=%.2e" % (H, W, err))
+    assert err < 3e-5 and int((got.argmax(1) != want.argmax(1)).sum()) == 0
+
+
+@pytest.mark.parametrize("channels_last_feats", [False, True])
+def test_whole_rnet_matrix_core_path_vs_modules(channels_last_feats, monkeypatch):
+    from neuralrgbd_amd import nets
+    h, w, D = 48, 64, 64
+    net = nets.DPVUpsampleNet(64, 32, 3, D=D)
+    net.load_state_dict(synth.seeded_state_dict(net, 3))
+    net = net.to(DEV)
+    dpv_log = torch.log_softmax(_rand(1, D, h, w, seed=10, scale=3.0), dim=1)
+    feats = [_rand(1, 64, h, w, seed=11), _rand(1, 32, 2 * h, 2 * w, seed=12), _rand(1, 3, 4 * h, 4 * w, seed=13)]
+    if channels_last_feats:   # what the matrix-core feature trunk hands over: NCHW-shaped views of channels-last tensors
+        feats = [f.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) for f in feats]
+    with torch.no_grad():
+        monkeypatch.setenv("NRGBD_RNET", "vendor")
+        want = net.forward_log(dpv_log, feats)
+        with torch.enable_grad():
+            mod = net.forward(torch.exp(dpv_log), [f.contiguous() for f in feats])       # plain nn.Module graph
+        monkeypatch.setenv("NRGBD_RNET", "mfma")
+        assert net.mfma_ok(dpv_log)
+        got = net.forward_log(dpv_log, feats)
+        got2 = net.forward_log(dpv_log, feats)
+    assert torch.equal(got, got2)
+    e1 = (got - mod).abs()
+    e0 = (want - mod).abs()
+    print("[parity] whole R-Net: matrix-core vs modules max %.2e mean %.2e | vendor fused tail vs modules max %.2e mean %.2e" %
+          (e1.max().item(), e1.mean().item(), e0.max().item(), e0.mean().item()))
+    assert e1.mean().item() < 1e-5 and e1.max().item() < 2e-4
+    assert int((got.argmax(1) != mod.argmax(1)).sum()) <= 2
