@@ -162,10 +162,15 @@ class KVNET(nn.Module):
         if has_pred and dpv_valid:
             assert BV_predict.shape[0] == 1
 
+        # update branch at inference: the two R-Net calls of the frame (on BV_cur and on DPV; Refine.py is a per-sample
+        # network without BatchNorm) run as ONE batch of 2 after the K-Net — twice the workgroups per launch for the
+        # quarter-resolution layers, which alone do not fill the chip
+        batch_refine = (self.if_refined and has_pred and bool(dpv_valid) and not torch.is_grad_enabled()
+                        and hasattr(self.r_net, "forward_log") and self.r_net.mfma_ok(BV_predict))
         if self.if_refined:
             BV_cur, features = self.d_net(ref_frame, src_frames, src_cam_poses, BV_predict=None)
             features.append(ref_frame)
-            dmap_cur_refined = self._refine(BV_cur, features)
+            dmap_cur_refined = None if batch_refine else self._refine(BV_cur, features)
         else:
             BV_cur = self.d_net(ref_frame, src_frames, src_cam_poses, BV_predict=None)
             dmap_cur_refined = -1
@@ -210,5 +215,9 @@ class KVNET(nn.Module):
                 gain = torch.squeeze(self.kv_net(volume.unsqueeze(0)), dim=1)   # torch modules
             DPV = torch.log_softmax(gain + BV_predict, dim=1)
 
-        dmap_refined = self._refine(DPV, features) if self.if_refined else -1
+        if batch_refine:
+            both = self.r_net.forward_log(torch.cat((BV_cur, DPV), dim=0), features)     # [2,D,H,W]
+            dmap_cur_refined, dmap_refined = both[0:1], both[1:2]
+        else:
+            dmap_refined = self._refine(DPV, features) if self.if_refined else -1
         return dmap_cur_refined, dmap_refined, BV_cur, DPV

@@ -635,7 +635,7 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         shapes = (self.conv0[0].in_channels == 128 and self.conv1[0].in_channels == 96 and
                   self.conv2[0].in_channels == 67 and self.conv2_2.out_channels == 64 and
                   self.trans_conv0[0].out_channels == 64 and self.trans_conv1[0].out_channels == 64)
-        return mode != "vendor" and shapes and dpv.is_cuda and not torch.is_grad_enabled() and dpv.shape[0] == 1
+        return mode != "vendor" and shapes and dpv.is_cuda and not torch.is_grad_enabled() and dpv.shape[0] in (1, 2)
 
     def _rnet_packed(self):
         """Packed B-operand streams + padded biases of the nine layers (cached; see invalidate_packed_weights)."""
@@ -672,15 +672,17 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         cache["key"], cache["val"] = key, val
         return val
 
-    def _rnet_buffers(self, h, w, dev):
+    def _rnet_buffers(self, n, h, w, dev):
         """Persistent channels-last concat buffers (zero-initialised ONCE: the 13 padding channels of the two 80-wide
-        full-resolution buffers are never written and must stay zero)."""
+        full-resolution buffers are never written and must stay zero).  One set per batch size (1: first frame, 2: update)."""
         cache = self.__dict__.setdefault("_buf_cache", {})
-        key = (h, w, str(dev))
+        key = (n, h, w, str(dev))
         if key not in cache:
-            cache.clear()
+            for k in [k for k in cache if k[1:] != key[1:]]:
+                del cache[k]
             z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-            cache[key] = {"c1": z(1, 2 * h, 2 * w, 96), "c2": z(1, 4 * h, 4 * w, 80), "g2": z(1, 4 * h, 4 * w, 80)}
+            cache[key] = {"x0": z(n, h, w, 128), "c1": z(n, 2 * h, 2 * w, 96), "c2": z(n, 4 * h, 4 * w, 80),
+                          "g2": z(n, 4 * h, 4 * w, 80)}
         return cache[key]
 
     def forward_log(self, dpv_log, img_features):
@@ -689,16 +691,18 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         if not self.mfma_ok(dpv_log):
             return self.forward(torch.exp(dpv_log), img_features)
         from . import ops
-        quarter, half, full = img_features
-        h, w = dpv_log.shape[2:]
+        quarter, half, full = img_features        # one image's features, shared by every sample of the batch
+        n, _, h, w = dpv_log.shape
         dev = dpv_log.device
-        pk, buf = self._rnet_packed(), self._rnet_buffers(h, w, dev)
+        pk, buf = self._rnet_packed(), self._rnet_buffers(n, h, w, dev)
         # level 1/4: cat(exp(dpv), feat) -> conv0 -> conv0_1
         q_cl = quarter.permute(0, 2, 3, 1)
-        if q_cl.is_contiguous():
-            x = ops.rnet_pack(dpv_log[0].contiguous(), q_cl[0], feat_planar=False)
-        else:
-            x = ops.rnet_pack(dpv_log[0].contiguous(), quarter[0].contiguous(), feat_planar=True)
+        x = buf["x0"]
+        for b in range(n):
+            if q_cl.is_contiguous():
+                ops.rnet_pack(dpv_log[b].contiguous(), q_cl[0], feat_planar=False, out=x[b:b + 1])
+            else:
+                ops.rnet_pack(dpv_log[b].contiguous(), quarter[0].contiguous(), feat_planar=True, out=x[b:b + 1])
         x = ops.conv2d_rnet(x, pk["conv0"][0], 128, bias=pk["conv0"][1])
         x = ops.conv2d_rnet(x, pk["conv0_1"][0], 128, bias=pk["conv0_1"][1])
         # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..63 of the concat buffer; features 64..95

@@ -405,13 +405,16 @@ def conv2d_rnet(x, w_packed, cout, bias=None, lrelu=True, out=None, ldy=None, yc
     return out
 
 
-def rnet_pack(dpv_log, feat, feat_planar):
+def rnet_pack(dpv_log, feat, feat_planar, out=None):
     """dpv_log [D,h,w] (log-prob), feat [h,w,Cf] (or [Cf,h,w] if feat_planar) -> [1,h,w,D+Cf] = cat(exp(dpv), feat)."""
     dpv_log = _need(dpv_log, "dpv_log")
     feat = _need(feat, "feat")
     D, h, w = dpv_log.shape
     Cf = feat.shape[0] if feat_planar else feat.shape[-1]
-    out = torch.empty((1, h, w, D + Cf), dtype=torch.float32, device=dpv_log.device)
+    if out is None:
+        out = torch.empty((1, h, w, D + Cf), dtype=torch.float32, device=dpv_log.device)
+    elif tuple(out.shape) != (1, h, w, D + Cf) or not out.is_contiguous():
+        raise ValueError("rnet_pack: out must be a contiguous [1,h,w,D+Cf] tensor")
     with torch.cuda.device(dpv_log.device):
         rc = _lib.load().nrgbd_rnet_pack(_p(dpv_log), _p(feat), int(bool(feat_planar)), _p(out), D, Cf, h * w, _stream(dpv_log))
     _lib.check(rc, "nrgbd_rnet_pack")

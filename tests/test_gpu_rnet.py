@@ -106,3 +106,20 @@ def test_whole_rnet_matrix_core_path_vs_modules(channels_last_feats, monkeypatch
           (e1.max().item(), e1.mean().item(), e0.max().item(), e0.mean().item()))
     assert e1.mean().item() < 1e-5 and e1.max().item() < 2e-4
     assert int((got.argmax(1) != mod.argmax(1)).sum()) <= 2
+
+
+def test_batch_of_two_equals_two_calls(monkeypatch):
+    """KVNET.forward refines BV_cur and DPV as one batch of 2 in the update branch: identical to two single calls."""
+    from neuralrgbd_amd import nets
+    monkeypatch.setenv("NRGBD_RNET", "mfma")
+    h, w, D = 32, 48, 64
+    net = nets.DPVUpsampleNet(64, 32, 3, D=D)
+    net.load_state_dict(synth.seeded_state_dict(net, 4))
+    net = net.to(DEV)
+    a = torch.log_softmax(_rand(1, D, h, w, seed=20, scale=3.0), dim=1)
+    b = torch.log_softmax(_rand(1, D, h, w, seed=21, scale=2.0), dim=1)
+    feats = [_rand(1, 64, h, w, seed=22), _rand(1, 32, 2 * h, 2 * w, seed=23), _rand(1, 3, 4 * h, 4 * w, seed=24)]
+    with torch.no_grad():
+        ra, rb = net.forward_log(a, feats).clone(), net.forward_log(b, feats).clone()
+        both = net.forward_log(torch.cat((a, b), 0), feats)
+    assert torch.equal(both[0:1], ra) and torch.equal(both[1:2], rb)
