@@ -18,9 +18,14 @@ The JSON line carries
   roofline      HBM roofline of the dominant sampling kernel (fused warp + cost volume + log-softmax):
                 algorithmic bytes 4[(V+1)*67*hw + D*hw] per launch / its mean launch duration, measured
                 with HIP events on the launch stream inside the timed steps (peak 8.0 TB/s);
+                `traffic` = HBM-side bytes per launch from a committed rocprofv3 --pmc measurement of this bench's
+                own windows (tools/pmc_traffic.sh -> profiles/r2_costvol_traffic.json);
   cpu_baseline  the CPU oracle (oracle/kvnet_oracle.py: the reference algorithm restated on torch-CPU
-                + the C sampling oracle) timed on this node's host cores on ONE update frame of the
-                same workload (rank 0, N=1 only).
+                + the C sampling oracle) timed on this node's host cores on update frames of the same
+                workload: 1 warm-up + median of 2 (rank 0, N=1 only);
+  parity        the GPU frame vs that oracle frame on the same window and filter state: max / mean |d| and
+                arg-max depth-index mismatches of BV_cur, DPV, BV_predict and the refined DPV.
+`--mode train` prints a separate, labelled line for the training iteration at BASELINE config 4's shape.
 """
 import argparse
 import json

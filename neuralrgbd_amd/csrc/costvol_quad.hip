@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
         return keep + rgbpart;
     };
     using T_ = std::true_type; using F_ = std::false_type;
-    using N2 = std::integral_constant<int, 2>; using N4 = std::integral_constant<int, 4>;
+    using N1 = std::integral_constant<int, 1>; using N2 = std::integral_constant<int, 2>; using N4 = std::integral_constant<int, 4>;
 
     // Loop order: views OUTER.  All workgroups of an XCD (one band of tiles) sweep the same source view at about the same
     // time, so the band's footprint in ONE view (~2 MB) is what has to live in the 4 MB L2 — with the views inside the
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
 #undef NRGBD_ROW_SHR_UNION
             int n = 0, xlo = 0, xhi = 1, ylo = 0, yhi = 1;
 #pragma unroll
-            for (int tryn = kQRun; tryn >= 2; tryn >>= 1) {
+            for (int tryn = kQRun; tryn >= 1; tryn >>= 1) {
                 const int l = tryn - 1;       // the lane holding the union of the next tryn candidates
                 const int uxlo = __builtin_amdgcn_readlane(bx.x, l), uxhi = __builtin_amdgcn_readlane(bx.y, l);
                 const int uylo = __builtin_amdgcn_readlane(bx.z, l), uyhi = __builtin_amdgcn_readlane(bx.w, l);
@@ -352,7 +352,9 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
                     n = tryn; xlo = uxlo; xhi = uxhi; ylo = uylo; yhi = uyhi;
                 }
             }
-            const bool staged = n >= 2 && !NRGBD_DBG(a, 1);
+            // a single candidate whose footprint fits could be staged as well (developer bit 32): measured 300 us vs 287 us
+            // at config B — a patch fill + two barriers for 64 (pixel, candidate) pairs costs more than their 16 global loads
+            const bool staged = n >= (NRGBD_DBG(a, 32) ? 1 : 2) && !NRGBD_DBG(a, 1);
             if (!staged) n = min(4, nmax);                     // one group straight from global memory
             const int j0 = rev ? hi - n : lo;                  // the run: candidates j0 .. j0 + n - 1
             const int ngroups = (n + 3) >> 2;
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
                     const float prev = (v > 0) ? *o : 0.f;     // this quad's own store of the previous view
                     float acc;
                     if (!staged) acc = group(F_{}, N4{}, sv, st, k0, nc, 0, 0, 0, 0, 0);
+                    else if (nc == 1) acc = group(T_{}, N1{}, sv, st, k0, 1, xlo, xhi, ylo, yhi, cols);
                     else if (nc == 2) acc = group(T_{}, N2{}, sv, st, k0, 2, xlo, xhi, ylo, yhi, cols);
                     else acc = group(T_{}, N4{}, sv, st, k0, 4, xlo, xhi, ylo, yhi, cols);
                     if (inside && j < nc) *o = prev + div_by_const(acc, a.sigma, a.rsigma);   // homography.py:325 (/ sigma), views in order
