@@ -298,7 +298,8 @@ int nrgbd_bias_act_nchw(float* x, const float* bias, float slope, int N, int C, 
  *   channels-last pixel (pixel stride ldy floats), i.e. straight into the next layer's concat buffer.
  * x [N][H][W][Cin] channels-last, Cin % 16 == 0 (zero-padded channels carry zero weights);
  * w_packed: nrgbd_conv_pack_weights of w [Cout][Cin][taps], taps = 9 (modes 0, 2) or 4 (mode 1: the phase's 2x2 taps in
- *   row-major order of the input neighbourhood {y-1+pa, y+pa} x {x-1+pb, x+pb}); Cout in {64, 96, 128} (mode 0), 64 (1, 2);
+ *   row-major order of the input neighbourhood {y-1+pa, y+pa} x {x-1+pb, x+pb}); Cout in {64, 96, 128} (mode 0), 64 (mode 1),
+ *   {64, 128} (mode 2); wider layers are launched as several output-column slices (ycoff);
  * bias [Cout] (padded) or NULL.  mode 0: y[pix*ldy + ycoff + c], c < cout_valid.  mode 1: the same at output pixel
  *   (2y+pa, 2x+pb) of a [N][2H][2W] tensor.  mode 2: y = planar [N][Cout][H][W] log-probabilities (ldy.. ignored).
  * nrgbd_rnet_pack: out [P][D+Cf] = (exp(dpv_log [D][P]), feat) — the R-Net's first concat with torch.exp fused

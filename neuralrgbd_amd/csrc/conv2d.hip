@@ -494,6 +494,7 @@ extern "C" int nrgbd_conv2d_rnet_f32(const float* x, const float* w_packed, cons
         else return NRGBD_E_SHAPE;
     } else {                  // last layer: bias + log_softmax over the channels, planar output
         if (Cout == 64) launch_conv2d_ex<64, 9, 1>(a, nwg, st);
+        else if (Cout == 128) launch_conv2d_ex<128, 9, 1>(a, nwg, st);
         else return NRGBD_E_SHAPE;
     }
     NRGBD_CHECK_LAUNCH();

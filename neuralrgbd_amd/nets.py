@@ -627,62 +627,92 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         return ops.logsoftmax_d(x[0]).unsqueeze(0)
 
     # ------------------------------------------------------------------ hand-written matrix-core path (inference)
+    _SLICES = {64: (64,), 96: (96,), 128: (128,), 160: (96, 64), 192: (96, 96)}   # output columns per launch (kernel widths)
+
+    def _widths(self):
+        """(D, C0, C1, C2) of this net, or None when the matrix-core kernel has no instantiation for them: D in {64, 128}
+        depth candidates + 64 / 32 / 3 image-feature channels (every script of the reference: feature_dim 64)."""
+        D = self.conv2_2.out_channels
+        C0 = self.conv0[0].in_channels - D
+        C1 = self.conv1[0].in_channels - D
+        C2 = self.conv2[0].in_channels - D
+        ok = D in (64, 128) and (C0, C1, C2) == (64, 32, 3) and self.trans_conv0[0].out_channels == D \
+            and self.trans_conv1[0].out_channels == D and self.conv2_1[0].out_channels == D
+        return (D, C0, C1, C2) if ok else None
+
     def mfma_ok(self, dpv):
-        """The R-Net on csrc/conv2d.hip: the canonical widths (D = 64 candidates + 64 / 32 / 3 image-feature channels),
-        batch 1, inference.  NRGBD_RNET = mfma | vendor | auto (default) selects; other widths use the vendor path."""
+        """The R-Net on csrc/conv2d.hip (inference, batch 1 or 2).  NRGBD_RNET = mfma | vendor | auto (default) selects;
+        widths without an instantiation use the vendor path."""
         import os
         mode = os.environ.get("NRGBD_RNET", "auto")
-        shapes = (self.conv0[0].in_channels == 128 and self.conv1[0].in_channels == 96 and
-                  self.conv2[0].in_channels == 67 and self.conv2_2.out_channels == 64 and
-                  self.trans_conv0[0].out_channels == 64 and self.trans_conv1[0].out_channels == 64)
-        return mode != "vendor" and shapes and dpv.is_cuda and not torch.is_grad_enabled() and dpv.shape[0] in (1, 2)
+        return mode != "vendor" and self._widths() is not None and dpv.is_cuda and not torch.is_grad_enabled() \
+            and dpv.shape[0] in (1, 2)
 
     def _rnet_packed(self):
-        """Packed B-operand streams + padded biases of the nine layers (cached; see invalidate_packed_weights)."""
+        """Per layer a list of output-column slices (packed B-operand stream, padded bias, kernel width, first column,
+        valid columns); transposed convs additionally per sub-pixel phase.  Cached (see invalidate_packed_weights)."""
         from . import ops
         cache = self.__dict__.setdefault("_pk_cache", {})
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if cache.get("key") == key:
             return cache["val"]
+        pad16 = lambda c: (c + 15) // 16 * 16
 
-        def conv(m, cin_p, cout_p):
+        def slices(cout):
+            cp = pad16(cout)
+            cp = cp if cp in self._SLICES else min(k for k in self._SLICES if k >= cp)
+            out, c0 = [], 0
+            for wdt in self._SLICES[cp]:
+                out.append((c0, wdt, max(0, min(wdt, cout - c0))))
+                c0 += wdt
+            return [t for t in out if t[2] > 0]
+
+        def conv(m):
             c = m[0] if isinstance(m, nn.Sequential) else m
             w, b = c.weight.detach(), c.bias.detach()
-            wp = w.new_zeros(cout_p, cin_p, 3, 3)
-            wp[:w.shape[0], :w.shape[1]] = w
-            bp = b.new_zeros(cout_p)
-            bp[:b.shape[0]] = b
-            return ops.conv_pack_weights(wp.contiguous()), bp.contiguous()
+            cin_p = pad16(w.shape[1])
+            res = []
+            for c0, wdt, valid in slices(w.shape[0]):
+                wp = w.new_zeros(wdt, cin_p, 3, 3)
+                wp[:valid, :w.shape[1]] = w[c0:c0 + valid]
+                bp = b.new_zeros(wdt)
+                bp[:valid] = b[c0:c0 + valid]
+                res.append((ops.conv_pack_weights(wp.contiguous()), bp.contiguous(), wdt, c0, valid))
+            return res
 
         def deconv(m):
             c = m[0]
             w, b = c.weight.detach(), c.bias.detach()          # [Cin, Cout, 4, 4]
-            phases = {}
+            res = {}
             for pa in (0, 1):
                 for pb in (0, 1):
                     ky = [3, 1] if pa == 0 else [2, 0]        # kernel row that links input row y-1+pa+ty to output row 2y+pa
                     kx = [3, 1] if pb == 0 else [2, 0]
-                    wph = w[:, :, ky][:, :, :, kx].permute(1, 0, 2, 3).contiguous()   # [Cout, Cin, 2, 2]
-                    phases[(pa, pb)] = ops.conv_pack_weights(wph)
-            return phases, b.contiguous()
+                    wph = w[:, :, ky][:, :, :, kx].permute(1, 0, 2, 3)                # [Cout, Cin, 2, 2]
+                    res[(pa, pb)] = [(ops.conv_pack_weights(wph[c0:c0 + 64].contiguous()), b[c0:c0 + 64].contiguous(), 64, c0, 64)
+                                     for c0 in range(0, w.shape[1], 64)]
+            return res
 
-        val = {"conv0": conv(self.conv0, 128, 128), "conv0_1": conv(self.conv0_1, 128, 128), "t0": deconv(self.trans_conv0),
-               "conv1": conv(self.conv1, 96, 96), "conv1_1": conv(self.conv1_1, 96, 96), "t1": deconv(self.trans_conv1),
-               "conv2": conv(self.conv2, 80, 96), "conv2_1": conv(self.conv2_1, 80, 64), "conv2_2": conv(self.conv2_2, 64, 64)}
+        val = {"conv0": conv(self.conv0), "conv0_1": conv(self.conv0_1), "t0": deconv(self.trans_conv0),
+               "conv1": conv(self.conv1), "conv1_1": conv(self.conv1_1), "t1": deconv(self.trans_conv1),
+               "conv2": conv(self.conv2), "conv2_1": conv(self.conv2_1), "conv2_2": conv(self.conv2_2)}
         cache["key"], cache["val"] = key, val
         return val
 
     def _rnet_buffers(self, n, h, w, dev):
-        """Persistent channels-last concat buffers (zero-initialised ONCE: the 13 padding channels of the two 80-wide
-        full-resolution buffers are never written and must stay zero).  One set per batch size (1: first frame, 2: update)."""
+        """Persistent channels-last buffers (zero-initialised ONCE: the padding channels of the full-resolution pixels —
+        67 -> 80, 131 -> 144 — are never written and must stay zero).  One set per batch size (1: first frame, 2: update)."""
         cache = self.__dict__.setdefault("_buf_cache", {})
         key = (n, h, w, str(dev))
         if key not in cache:
             for k in [k for k in cache if k[1:] != key[1:]]:
                 del cache[k]
+            D, C0, C1, C2 = self._widths()
             z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-            cache[key] = {"x0": z(n, h, w, 128), "c1": z(n, 2 * h, 2 * w, 96), "c2": z(n, 4 * h, 4 * w, 80),
-                          "g2": z(n, 4 * h, 4 * w, 80)}
+            w2 = (D + C2 + 15) // 16 * 16
+            cache[key] = {"x0": z(n, h, w, D + C0), "a0": z(n, h, w, D + C0), "b0": z(n, h, w, D + C0),
+                          "c1": z(n, 2 * h, 2 * w, D + C1), "a1": z(n, 2 * h, 2 * w, D + C1), "b1": z(n, 2 * h, 2 * w, D + C1),
+                          "c2": z(n, 4 * h, 4 * w, w2), "g2": z(n, 4 * h, 4 * w, w2), "h2": z(n, 4 * h, 4 * w, D)}
         return cache[key]
 
     def forward_log(self, dpv_log, img_features):
@@ -692,9 +722,17 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
             return self.forward(torch.exp(dpv_log), img_features)
         from . import ops
         quarter, half, full = img_features        # one image's features, shared by every sample of the batch
-        n, _, h, w = dpv_log.shape
+        n, D, h, w = dpv_log.shape
         dev = dpv_log.device
         pk, buf = self._rnet_packed(), self._rnet_buffers(n, h, w, dev)
+
+        def conv(x, layer, out, mode=0, pa=0, pb=0):
+            """All output-column slices of one layer into `out` (pixel stride = its last dimension)."""
+            for wp, bias, wdt, c0, valid in layer:
+                ops.conv2d_rnet(x, wp, wdt, bias=bias, out=out, ldy=out.shape[-1], ycoff=c0, cout_valid=valid, mode=mode,
+                                pa=pa, pb=pb)
+            return out
+
         # level 1/4: cat(exp(dpv), feat) -> conv0 -> conv0_1
         q_cl = quarter.permute(0, 2, 3, 1)
         x = buf["x0"]
@@ -703,23 +741,21 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 ops.rnet_pack(dpv_log[b].contiguous(), q_cl[0], feat_planar=False, out=x[b:b + 1])
             else:
                 ops.rnet_pack(dpv_log[b].contiguous(), quarter[0].contiguous(), feat_planar=True, out=x[b:b + 1])
-        x = ops.conv2d_rnet(x, pk["conv0"][0], 128, bias=pk["conv0"][1])
-        x = ops.conv2d_rnet(x, pk["conv0_1"][0], 128, bias=pk["conv0_1"][1])
-        # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..63 of the concat buffer; features 64..95
+        x = conv(conv(x, pk["conv0"], buf["a0"]), pk["conv0_1"], buf["b0"])
+        # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..D-1 of the concat buffer; features behind
         c1 = buf["c1"]
-        for (pa, pb), wp in pk["t0"][0].items():
-            ops.conv2d_rnet(x, wp, 64, bias=pk["t0"][1], out=c1, ldy=96, ycoff=0, cout_valid=64, mode=1, pa=pa, pb=pb)
-        c1[..., 64:].copy_(half.permute(0, 2, 3, 1))
-        x = ops.conv2d_rnet(c1, pk["conv1"][0], 96, bias=pk["conv1"][1])
-        x = ops.conv2d_rnet(x, pk["conv1_1"][0], 96, bias=pk["conv1_1"][1])
-        # full resolution: 64 + 3 channels in 80-wide pixels (padding channels zero, with zero weights)
-        c2, g2 = buf["c2"], buf["g2"]
-        for (pa, pb), wp in pk["t1"][0].items():
-            ops.conv2d_rnet(x, wp, 64, bias=pk["t1"][1], out=c2, ldy=80, ycoff=0, cout_valid=64, mode=1, pa=pa, pb=pb)
-        c2[..., 64:67].copy_(full.permute(0, 2, 3, 1))
-        ops.conv2d_rnet(c2, pk["conv2"][0], 96, bias=pk["conv2"][1], out=g2, ldy=80, ycoff=0, cout_valid=67)
-        x = ops.conv2d_rnet(g2, pk["conv2_1"][0], 64, bias=pk["conv2_1"][1])
-        return ops.conv2d_rnet(x, pk["conv2_2"][0], 64, bias=pk["conv2_2"][1], lrelu=False, mode=2)
+        for (pa, pb), layer in pk["t0"].items():
+            conv(x, layer, c1, mode=1, pa=pa, pb=pb)
+        c1[..., D:].copy_(half.permute(0, 2, 3, 1))
+        x = conv(conv(c1, pk["conv1"], buf["a1"]), pk["conv1_1"], buf["b1"])
+        # full resolution: D + 3 channels in 16-aligned pixels (padding channels zero, with zero weights)
+        c2 = buf["c2"]
+        for (pa, pb), layer in pk["t1"].items():
+            conv(x, layer, c2, mode=1, pa=pa, pb=pb)
+        c2[..., D:D + 3].copy_(full.permute(0, 2, 3, 1))
+        x = conv(conv(c2, pk["conv2"], buf["g2"]), pk["conv2_1"], buf["h2"])
+        wp, bias, wdt, _, _ = pk["conv2_2"][0]
+        return ops.conv2d_rnet(x, wp, wdt, bias=bias, lrelu=False, mode=2)
 
     def forward(self, dpv_raw, img_features):
         if dpv_raw.is_cuda and not torch.is_grad_enabled() and dpv_raw.shape[0] == 1 \

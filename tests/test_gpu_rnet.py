@@ -79,10 +79,11 @@ def test_last_conv_with_planar_log_softmax(H, W):
     assert err < 3e-5 and int((got.argmax(1) != want.argmax(1)).sum()) == 0
 
 
-@pytest.mark.parametrize("channels_last_feats", [False, True])
-def test_whole_rnet_matrix_core_path_vs_modules(channels_last_feats, monkeypatch):
+@pytest.mark.parametrize("channels_last_feats,D", [(False, 64), (True, 64), (True, 128)])
+def test_whole_rnet_matrix_core_path_vs_modules(channels_last_feats, D, monkeypatch):
+    """D = 64 (configs S, B, K) and D = 128 (config H: 192 / 160 / 131-channel layers as output-column slices)."""
     from neuralrgbd_amd import nets
-    h, w, D = 48, 64, 64
+    h, w = 48, 64
     net = nets.DPVUpsampleNet(64, 32, 3, D=D)
     net.load_state_dict(synth.seeded_state_dict(net, 3))
     net = net.to(DEV)
