@@ -221,7 +221,10 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         mean of means is the mean).  Under autograd each window is a crop + reshape + mean: one reduction kernel
         forward and an expand backward, instead of avg_pool2d's one-thread-per-output loop over 64x64 elements
         (0.45 ms per window forward at the ScanNet grid, and as much again backward)."""
-        if _fused_ok(deep) and deep.shape[2] % 64 == 0 and deep.shape[3] % 64 == 0:
+        # multiples of 8 suffice: avg_pool2d's floor drops the same ragged border at every level (floor(W/k) windows of k
+        # pixels = floor((W/8)/(k/8)) windows of k/8 cells) — the ScanNet grid 64x96 used to miss this path and paid
+        # 1.8 ms per frame in avg_pool2d's one-thread-per-output loop
+        if _fused_ok(deep) and deep.shape[2] % 8 == 0 and deep.shape[3] % 8 == 0:
             from . import ops
             p8 = ops.avgpool8(deep)
             return {8: p8, 16: F.avg_pool2d(p8, 2), 32: F.avg_pool2d(p8, 4), 64: F.avg_pool2d(p8, 8)}
@@ -356,7 +359,7 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         deep = ops.nhwc_act(a.z, a.ss, a.relu, a.r, a.r_ss, a.r_relu)
         N, h, w, _ = deep.shape
         deep_nchw = deep.permute(0, 3, 1, 2)                               # channels-last view for the torch pooling ops
-        if h % 64 == 0 and w % 64 == 0:
+        if h % 8 == 0 and w % 8 == 0:                                      # see _spp_pools: the floor crops agree at every level
             p8 = F.avg_pool2d(deep_nchw, 8)
             pools = {8: p8, 16: F.avg_pool2d(p8, 2), 32: F.avg_pool2d(p8, 4), 64: F.avg_pool2d(p8, 8)}
         else:
@@ -641,12 +644,17 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         return (D, C0, C1, C2) if ok else None
 
     def mfma_ok(self, dpv):
-        """The R-Net on csrc/conv2d.hip (inference, batch 1 or 2).  NRGBD_RNET = mfma | vendor | auto (default) selects;
-        widths without an instantiation use the vendor path."""
+        """The R-Net on csrc/conv2d.hip (inference, batch 1 or 2).  NRGBD_RNET = mfma | vendor | auto (default).
+        auto: the matrix-core path when the quarter-resolution grid has >= 64 tiles of 16x16 pixels (configs B and H:
+        79.9 vs 80.8 ms and 63.4 vs 63.8 ms per frame, same box).  Below that its two quarter-resolution layers cannot
+        fill 256 CUs with 16x16-pixel workgroups and MIOpen's Winograd kernels win (config S 14.2 vs 14.4 ms, K equal):
+        those grids, and widths without an instantiation, use the vendor path."""
         import os
         mode = os.environ.get("NRGBD_RNET", "auto")
-        return mode != "vendor" and self._widths() is not None and dpv.is_cuda and not torch.is_grad_enabled() \
-            and dpv.shape[0] in (1, 2)
+        if mode == "vendor" or self._widths() is None or not dpv.is_cuda or torch.is_grad_enabled() or dpv.shape[0] not in (1, 2):
+            return False
+        tiles = ((dpv.shape[2] + 15) // 16) * ((dpv.shape[3] + 15) // 16)
+        return mode == "mfma" or tiles >= 64
 
     def _rnet_packed(self):
         """Per layer a list of output-column slices (packed B-operand stream, padded bias, kernel width, first column,
