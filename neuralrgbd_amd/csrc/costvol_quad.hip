@@ -139,7 +139,20 @@ __global__ __launch_bounds__(256, 3) void costvol_quad(const CostvolArgs a) {
     // workgroup -> (tile, candidate chunk); XCD k (= blockIdx % 8) owns a contiguous eighth of the tile list so that the
     // source rows a band of tiles samples stay in ONE 4 MB L2
     int id = blockIdx.x;
-    if ((gridDim.x & 7) == 0) id = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if ((gridDim.x & 7) == 0) {
+        const int per = gridDim.x >> 3;          // workgroups of one XCD = its band of the tile list
+        int u = blockIdx.x >> 3;
+        // Inside the band the tiles are handed out in a scrambled order (developer bit 64 turns it off): the workgroups that
+        // share a CU (consecutive or 32 apart in an XCD's dispatch order) then come from tiles ~5 columns / a row + 11
+        // columns apart instead of neighbours.  A tile's cost (how many near-plane runs go to global memory) varies
+        // smoothly over the image, so neighbours on one CU could make slow CUs and fast CUs.  Measured: 277 vs 280 us at
+        // config B (within run-to-run noise) — per-CU load imbalance is not what limits the kernel.
+        if ((per & 31) == 0 && !NRGBD_DBG(a, 64)) {
+            const int r = u >> 5, c = u & 31;
+            u = (r << 5) | ((c * 5 + r * 11) & 31);
+        }
+        id = (blockIdx.x & 7) * per + u;
+    }
     const int tile = id / a.nchunk, chunk = id - tile * a.nchunk;
     // Developer switch (NRGBD_ABLATE bit 16): every other workgroup walks its candidates far -> near, to de-phase the
     // staging-bound (near planes) and math-bound (far planes) parts of co-resident workgroups.  Measured: 288 us with,
