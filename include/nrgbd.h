@@ -289,6 +289,19 @@ int nrgbd_avgpool8(const float* x, float* y, int NC, int H, int W, void* stream)
 int nrgbd_bias_act_nchw(float* x, const float* bias, float slope, int N, int C, long HW, void* stream);
 
 /*
+ * nrgbd_conv3d_wino_f32 — the K-Net's 64 -> 64 layer (same contract as nrgbd_conv3d_3x3x3_f32 with Cin = Cout = 64) with the
+ * two in-plane dimensions in the Winograd domain F(2x2, 3x3): 2.25x fewer fp32 multiplies (MFMAs) per layer, exact-algorithm
+ * fp32 (rounding order differs, as in any Winograd convolution).  Replaces the same reference lines (models/basic.py:71-94).
+ *   w_wino: 12 stages (4 input-channel blocks x 3 depth taps) x 16 transform points x [4 waves][64 lanes][4] floats =
+ *           U[xi][kd][ci][co] = (G g G^T) packed by the host mirror (neuralrgbd_amd/ops.py::conv3d_wino_pack), 196,608 floats
+ *   stats [nrgbd_conv3d_wino_workgroups(D,H,W)][128]  (nrgbd_bn3d_finalize reduces them like the direct kernel's)
+ */
+int nrgbd_conv3d_wino_workgroups(int D, int H, int W);
+int nrgbd_conv3d_wino_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
+                          int res_relu, float* materialized, const float* w_wino, float* y, float* stats,
+                          int D, int H, int W, void* stream);
+
+/*
  * R-Net (DPV up-sampler) on the same matrix-core kernel.  Replaces, per layer of models/Refine.py:51-107:
  *   m_submodule.conv2d_leakyRelu (nn.Conv2d 3x3 + bias + LeakyReLU 0.01, :18-27)      mode 0
  *   m_submodule.conv2dTranspose_leakyRelu (nn.ConvTranspose2d k4 s2 p1 + bias + LeakyReLU, :37-45)

@@ -464,6 +464,18 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
             cache[id(conv)] = hit
         return hit[1]
 
+    def _packed_wino(self, conv):
+        """Winograd-domain weights U = G g G^T of a 64 -> 64 layer, re-packed only when its weight changes."""
+        from . import ops
+        cache = self.__dict__.setdefault("_wp_cache", {})
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device), "wino")
+        hit = cache.get(("wino", id(conv)))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_wino_pack(w.detach().contiguous()))
+            cache[("wino", id(conv))] = hit
+        return hit[1]
+
     def _bn_scale_shift(self, bn, stats, count):
         """(scale, shift) of a BatchNorm3d: batch statistics in train mode (the reference never leaves it,
         SURVEY §0.2) incl. the running-statistics side effect; running statistics in eval mode."""
@@ -499,10 +511,17 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         count = D * H * W
         need_stats = lambda bn: bn.training or not bn.track_running_stats
 
+        import os
+        wino = os.environ.get("NRGBD_KNET", "auto") == "wino"     # the ten 64 -> 64 layers in the Winograd domain (conv3d_wino.hip)
+
         def run(i, x, x_ss, x_relu, res=None, materialize=False):
             conv, bn = L[i]
-            y, st, mat = ops.conv3d(x, self._packed(conv), x_ss=x_ss, x_relu=x_relu, res=res,
-                                    materialize=materialize, want_stats=need_stats(bn))
+            if wino and conv.in_channels == 64:
+                y, st, mat = ops.conv3d_wino(x, self._packed_wino(conv), x_ss=x_ss, x_relu=x_relu, res=res,
+                                             materialize=materialize, want_stats=need_stats(bn))
+            else:
+                y, st, mat = ops.conv3d(x, self._packed(conv), x_ss=x_ss, x_relu=x_relu, res=res,
+                                        materialize=materialize, want_stats=need_stats(bn))
             return y, self._bn_scale_shift(bn, st, count), mat
 
         z, ss, _ = run(0, vol, None, False)                       # dres0.0

@@ -302,6 +302,43 @@ def conv3d(x, w_packed, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu
     return y, stats, mat
 
 
+def conv3d_wino_pack(w):
+    """w [64, 64, 3, 3, 3] -> Winograd-domain B-operand stream of nrgbd_conv3d_wino_f32: U = G g G^T over (ky, kx) in
+    float64, rounded once to fp32, laid out [stage = cb*3 + kd][xi = 4*xi_y + xi_x][wave][lane = kq*16 + j][e] with
+    ci = cb*16 + 4*kq + e and co = 16*wave + j."""
+    w = _need(w, "w")
+    if tuple(w.shape) != (64, 64, 3, 3, 3):
+        raise ValueError("conv3d_wino_pack expects [64, 64, 3, 3, 3], got %s" % (tuple(w.shape),))
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+    U = torch.einsum("ay,ockyx,bx->ockab", G, w.detach().double(), G).reshape(64, 64, 3, 16)      # [co, ci, kd, xi]
+    U = U.reshape(4, 16, 4, 4, 4, 3, 16)                     # co -> (wave, j); ci -> (cb, kq, e)
+    U = U.permute(2, 5, 6, 0, 3, 1, 4).contiguous()          # [cb, kd, xi, wave, kq, j, e]
+    return U.to(torch.float32).reshape(-1)
+
+
+def conv3d_wino_workgroups(D, H, W):
+    return int(_lib.load().nrgbd_conv3d_wino_workgroups(D, H, W))
+
+
+def conv3d_wino(x, w_wino, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False, materialize=False, want_stats=True):
+    """Channels-last 3x3x3 convolution 64 -> 64 with the in-plane dimensions in the Winograd domain (same arguments and
+    results as conv3d): x [D,H,W,64] -> (y [D,H,W,64], stats | None, materialized | None)."""
+    x = _need(x, "x")
+    D, H, W, Cin = x.shape
+    if Cin != 64:
+        raise ValueError("conv3d_wino: 64 input channels, got %d" % Cin)
+    y = torch.empty((D, H, W, 64), dtype=torch.float32, device=x.device)
+    stats = torch.empty((conv3d_wino_workgroups(D, H, W), 128), dtype=torch.float32, device=x.device) if want_stats else None
+    mat = torch.empty_like(x) if materialize else None
+    if res is not None:
+        res = _need(res, "res", x.shape)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv3d_wino_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(mat),
+                                                _p(w_wino), _p(y), _p(stats), D, H, W, _stream(x))
+    _lib.check(rc, "nrgbd_conv3d_wino_f32")
+    return y, stats, mat
+
+
 def conv3d_wgrad(x, gy):
     """Weight gradient of the channels-last 3x3x3 convolution: x [D,H,W,Cin], gy [D,H,W,64] -> dW [64,Cin,3,3,3]."""
     x = _need(x, "x")
