@@ -512,7 +512,9 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         need_stats = lambda bn: bn.training or not bn.track_running_stats
 
         import os
-        wino = os.environ.get("NRGBD_KNET", "auto") == "wino"     # the ten 64 -> 64 layers in the Winograd domain (conv3d_wino.hip)
+        # the ten 64 -> 64 layers in the Winograd domain (conv3d_wino.hip: 3.3 vs 5.4 ms per layer at config B, and closer to
+        # the float64 result than the direct kernel); NRGBD_KNET=direct selects conv3d.hip for A/B
+        wino = os.environ.get("NRGBD_KNET", "auto") != "direct"
 
         def run(i, x, x_ss, x_relu, res=None, materialize=False):
             conv, bn = L[i]
