@@ -302,6 +302,25 @@ int nrgbd_conv3d_wino_f32(const float* x, const float* x_ss, int x_relu, const f
                           int D, int H, int W, void* stream);
 
 /*
+ * nrgbd_conv_wino_f32 — generation 2 of the Winograd-domain convolution (csrc/wino_pc.hip): a persistent 8-wave workgroup per
+ * CU, 4 consumer waves that only issue MFMAs and 4 producer waves that load / normalise / transform the operand two stages
+ * ahead.  One entry for
+ *   kd = 3: the K-Net's 3x3x3 layers (models/basic.py:71-94), x [N = depth][H][W][Cin], dilation 1;
+ *   kd = 1: the 3x3 stride-1 layers of the feature CNN (models/psm_submodule.py:10-16,31-50,100-134), x [N images][H][W][Cin],
+ *           padding = dilation in {1, 2}.
+ * Cin % 16 == 0, Cout % 64 == 0; same fused prologue (x_ss / x_relu / res / res_ss / res_relu / materialized) and statistics
+ * epilogue as nrgbd_conv3d_3x3x3_f32 / nrgbd_conv2d_3x3_f32.
+ *   w_wino: [Cout/64][stage = cb*kd + depth tap][16 transform points][4 waves][64 lanes][4] floats, U = G g G^T over (ky, kx)
+ *           (host mirror: neuralrgbd_amd/ops.py::conv_wino_pack)
+ *   stats  [nrgbd_conv_wino_tiles(N,H,W,dilation)][2*Cout] partial (sum, sum of squares) rows for nrgbd_bn_finalize /
+ *           nrgbd_bn3d_finalize, or NULL
+ */
+int nrgbd_conv_wino_tiles(int N, int H, int W, int dilation);
+int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
+                        int res_relu, float* materialized, const float* w_wino, float* y, float* stats,
+                        int N, int H, int W, int Cin, int Cout, int kd, int dilation, void* stream);
+
+/*
  * R-Net (DPV up-sampler) on the same matrix-core kernel.  Replaces, per layer of models/Refine.py:51-107:
  *   m_submodule.conv2d_leakyRelu (nn.Conv2d 3x3 + bias + LeakyReLU 0.01, :18-27)      mode 0
  *   m_submodule.conv2dTranspose_leakyRelu (nn.ConvTranspose2d k4 s2 p1 + bias + LeakyReLU, :37-45)

@@ -42,6 +42,8 @@ SIGNATURES = {
     "nrgbd_conv3d_3x3x3_cout1_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "nrgbd_conv3d_wino_workgroups": (_I, [_I, _I, _I]),
     "nrgbd_conv3d_wino_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "nrgbd_conv_wino_tiles": (_I, [_I, _I, _I, _I]),
+    "nrgbd_conv_wino_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv3d_wgrad_workgroups": (_I, []),
     "nrgbd_conv3d_wgrad_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "nrgbd_bn3d_finalize": (_I, [_P, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P]),

@@ -339,6 +339,47 @@ def conv3d_wino(x, w_wino, x_ss=None, x_relu=False, res=None, res_ss=None, res_r
     return y, stats, mat
 
 
+def conv_wino_pack(w):
+    """w [Cout, Cin, 3, 3, 3] (kd = 3) or [Cout, Cin, 3, 3] (kd = 1) -> Winograd-domain B-operand stream of nrgbd_conv_wino_f32:
+    U = G g G^T over (ky, kx) in float64, rounded once to fp32, laid out [cg][stage = cb*kd + depth tap][xi = 4*xi_y + xi_x]
+    [wave][lane = kq*16 + j][e] with ci = cb*16 + 4*kq + e and co = cg*64 + 16*wave + j."""
+    w = _need(w, "w")
+    if w.dim() == 4:
+        w = w[:, :, None]
+    if w.dim() != 5 or tuple(w.shape[3:]) != (3, 3) or w.shape[2] not in (1, 3) or w.shape[0] % 64 or w.shape[1] % 16:
+        raise ValueError("conv_wino_pack expects [Cout%%64, Cin%%16, (3,) 3, 3], got %s" % (tuple(w.shape),))
+    Cout, Cin, KD = w.shape[:3]
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+    U = torch.einsum("ay,ockyx,bx->ockab", G, w.detach().double(), G).reshape(Cout, Cin, KD, 16)   # [co, ci, kd, xi]
+    U = U.reshape(Cout // 64, 4, 16, Cin // 16, 4, 4, KD, 16)   # co -> (cg, wave, j); ci -> (cb, kq, e)
+    U = U.permute(0, 3, 6, 7, 1, 4, 2, 5).contiguous()          # [cg, cb, kd, xi, wave, kq, j, e]
+    return U.to(torch.float32).reshape(-1)
+
+
+def conv_wino_tiles(N, H, W, dilation=1):
+    return int(_lib.load().nrgbd_conv_wino_tiles(N, H, W, dilation))
+
+
+def conv_wino(x, w_wino, Cout, kd, dilation=1, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False,
+              materialize=False, want_stats=True):
+    """Channels-last 3x3(x3) stride-1 convolution in the Winograd domain on the producer/consumer kernel (wino_pc.hip):
+    x [N,H,W,Cin] -> (y [N,H,W,Cout], stats [tiles, 2*Cout] | None, materialized | None); kd = 3 convolves over N as depth."""
+    x = _need(x, "x")
+    N, H, W, Cin = x.shape
+    y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
+    stats = torch.empty((conv_wino_tiles(N, H, W, dilation), 2 * Cout), dtype=torch.float32, device=x.device) if want_stats else None
+    mat = torch.empty_like(x) if materialize else None
+    if res is not None:
+        res = _need(res, "res", x.shape)
+    if w_wino.numel() != (Cout // 64) * (Cin // 16) * kd * 16 * 1024:
+        raise ValueError("conv_wino: packed weights do not match Cin=%d Cout=%d kd=%d" % (Cin, Cout, kd))
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv_wino_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(mat),
+                                              _p(w_wino), _p(y), _p(stats), N, H, W, Cin, Cout, kd, dilation, _stream(x))
+    _lib.check(rc, "nrgbd_conv_wino_f32")
+    return y, stats, mat
+
+
 def conv3d_wgrad(x, gy):
     """Weight gradient of the channels-last 3x3x3 convolution: x [D,H,W,Cin], gy [D,H,W,64] -> dW [64,Cin,3,3,3]."""
     x = _need(x, "x")

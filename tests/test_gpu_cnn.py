@@ -142,3 +142,49 @@ def test_rnet_fused_tail_vs_torch_modules(h, w):
     b = torch.randn(5, device=DEV)
     ref = F.leaky_relu(x + b.view(1, -1, 1, 1), 0.01)
     assert torch.allclose(ops.bias_act_(x.clone(), b, 0.01), ref, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------- Winograd-domain 2-D layers (wino_pc.hip, kd = 1)
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", [
+    (1, 16, 16, 64, 64, 1), (3, 21, 37, 64, 64, 1), (2, 24, 40, 64, 128, 1), (2, 30, 34, 128, 128, 1),
+    (2, 30, 34, 128, 128, 2), (1, 5, 7, 128, 128, 2), (1, 16, 32, 320, 128, 1), (5, 48, 64, 32, 64, 1),
+    (5, 96, 128, 64, 64, 1), (2, 33, 47, 128, 128, 2)])
+def test_conv_wino_pc_2d_plain_vs_torch(N, H, W, Cin, Cout, dil):
+    """Producer/consumer Winograd kernel, kd = 1: the feature CNN's 3x3 stride-1 layers (dilation 1 and 2, 64-column output
+    groups, any Cin % 16) vs F.conv2d in float64, statistics rows included."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + H + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(DEV)
+    want = F.conv2d(x.double(), w.double(), padding=dil, dilation=dil)
+    y, stats, _ = ops.conv_wino(_cl(x), ops.conv_wino_pack(w), Cout, 1, dil)
+    err = (y.permute(0, 3, 1, 2).double() - want).abs().max().item()
+    scale = want.abs().max().item()
+    print("[parity] conv_wino_pc 2d N%d %dx%d %d->%d dil%d max|d vs fp64|=%.3e (|y|max %.2f)" % (N, H, W, Cin, Cout, dil, err, scale))
+    assert err < 2e-5 * max(1.0, scale)
+    assert stats.shape == (ops.conv_wino_tiles(N, H, W, dil), 2 * Cout)
+    s = stats.double().sum(0)
+    assert torch.allclose(s[:Cout], want.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[Cout:], (want ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("Cin,Cout,dil", [(64, 64, 1), (128, 128, 2)])
+def test_conv_wino_pc_2d_fused_prologue_materialize(Cin, Cout, dil):
+    from neuralrgbd_amd import ops
+    N, H, W = 2, 19, 35
+    g = torch.Generator().manual_seed(Cin + dil)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    r = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    ss = torch.randn(Cin, 2, generator=g).to(DEV)
+    rs = torch.randn(Cin, 2, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(DEV)
+    inp = torch.relu(x * ss[:, 0].view(1, -1, 1, 1) + ss[:, 1].view(1, -1, 1, 1)) + (r * rs[:, 0].view(1, -1, 1, 1) + rs[:, 1].view(1, -1, 1, 1))
+    want = F.conv2d(inp, w, padding=dil, dilation=dil)
+    y, stats, mat = ops.conv_wino(_cl(x), ops.conv_wino_pack(w), Cout, 1, dil, x_ss=ss, x_relu=True, res=_cl(r), res_ss=rs,
+                                  materialize=True)
+    assert (mat.permute(0, 3, 1, 2) - inp).abs().max().item() < 1e-5
+    err = (y.permute(0, 3, 1, 2) - want).abs().max().item()
+    print("[parity] conv_wino_pc 2d fused %d->%d dil%d max|d|=%.3e" % (Cin, Cout, dil, err))
+    assert err < 1e-4 * max(1.0, want.abs().max().item())
+    s = stats.double().sum(0)
+    assert torch.allclose(s[:Cout], want.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-2)

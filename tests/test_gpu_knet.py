@@ -187,3 +187,50 @@ def test_conv3d_wino_fused_prologue_and_materialize():
     assert (y2.permute(3, 0, 1, 2) - F.conv3d(act2[None], w, padding=1)[0]).abs().max().item() < 2e-4
     y3, _, _ = ops.conv3d_wino(_cl(x), wp, x_ss=ss, res=_cl(r))
     assert torch.equal(y2, y3)                                  # deterministic
+
+
+# ----------------------------------------------------------------------------- generation 2: producer / consumer waves (wino_pc.hip)
+@pytest.mark.parametrize("D,H,W", [(4, 16, 32), (2, 8, 16), (5, 13, 21), (3, 10, 40), (8, 24, 48), (1, 8, 16), (40, 40, 72)])
+def test_conv_wino_pc_3d_plain_vs_torch(D, H, W):
+    """Persistent producer/consumer Winograd kernel, kd = 3 (the K-Net's 64 -> 64 layers) vs F.conv3d in float64; the last
+    grid has more tiles (900) than CUs, so workgroups walk several tiles and the weight ring wraps across them."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(D * 1000 + H)
+    x = torch.randn(64, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    want = F.conv3d(x[None].double(), w.double(), padding=1)[0]
+    y, stats, _ = ops.conv_wino(_cl(x), ops.conv_wino_pack(w), 64, 3)
+    err = (y.permute(3, 0, 1, 2).double() - want).abs().max().item()
+    scale = want.abs().max().item()
+    print("[parity] conv_wino_pc 3d %dx%dx%d max|d vs fp64|=%.3e (|y|max %.2f)" % (D, H, W, err, scale))
+    assert err < 2e-5 * max(1.0, scale)
+    assert stats.shape == (ops.conv_wino_tiles(D, H, W), 128)
+    s = stats.double().sum(0)
+    assert torch.allclose(s[:64], want.sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[64:], (want ** 2).sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+    y1, _, _ = ops.conv3d_wino(_cl(x), ops.conv3d_wino_pack(w))
+    print("[parity] conv_wino_pc vs generation 1: max|d|=%.3e" % (y - y1).abs().max().item())
+    assert (y - y1).abs().max().item() < 1e-5 * max(1.0, scale)
+
+
+def test_conv_wino_pc_3d_fused_prologue_and_materialize():
+    from neuralrgbd_amd import ops
+    D, H, W, C = 6, 18, 36, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(C, D, H, W, generator=g).to(DEV)
+    r = torch.randn(C, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    ss = torch.randn(C, 2, generator=g).to(DEV)
+    rs = torch.randn(C, 2, generator=g).to(DEV)
+    act = torch.relu(x * ss[:, 0, None, None, None] + ss[:, 1, None, None, None]) \
+        + torch.relu(r * rs[:, 0, None, None, None] + rs[:, 1, None, None, None])
+    want = F.conv3d(act[None], w, padding=1)[0]
+    wp = ops.conv_wino_pack(w)
+    y, _, mat = ops.conv_wino(_cl(x), wp, 64, 3, x_ss=ss, x_relu=True, res=_cl(r), res_ss=rs, res_relu=True, materialize=True)
+    assert (y.permute(3, 0, 1, 2) - want).abs().max().item() < 2e-4
+    assert (mat.permute(3, 0, 1, 2) - act).abs().max().item() < 1e-5
+    act2 = (x * ss[:, 0, None, None, None] + ss[:, 1, None, None, None]) + r
+    y2, _, _ = ops.conv_wino(_cl(x), wp, 64, 3, x_ss=ss, res=_cl(r))
+    assert (y2.permute(3, 0, 1, 2) - F.conv3d(act2[None], w, padding=1)[0]).abs().max().item() < 2e-4
+    y3, _, _ = ops.conv_wino(_cl(x), wp, 64, 3, x_ss=ss, res=_cl(r))
+    assert torch.equal(y2, y3)                                  # deterministic

@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="B")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--cnn", action="store_true", help="also time the feature CNN's 2-D layer shapes")
     args = ap.parse_args()
     from neuralrgbd_amd import ops
     D, H, W = GRIDS[args.config]
@@ -36,13 +37,32 @@ def main():
     flops = 2.0 * D * H * W * 64 * 64 * 27
     for name, fn in (("direct plain", lambda: ops.conv3d(x, wd, x_ss=ss, x_relu=True)),
                      ("wino   plain", lambda: ops.conv3d_wino(x, ww, x_ss=ss, x_relu=True)),
+                     ("wino-pc plain", lambda: ops.conv_wino(x, ww, 64, 3, x_ss=ss, x_relu=True)),
                      ("direct res+mat", lambda: ops.conv3d(x, wd, x_ss=ss, res=r, materialize=True)),
-                     ("wino   res+mat", lambda: ops.conv3d_wino(x, ww, x_ss=ss, res=r, materialize=True))):
+                     ("wino   res+mat", lambda: ops.conv3d_wino(x, ww, x_ss=ss, res=r, materialize=True)),
+                     ("wino-pc res+mat", lambda: ops.conv_wino(x, ww, 64, 3, x_ss=ss, res=r, materialize=True))):
         ms = timeit(fn, args.iters)
         print("%-16s %8.3f ms   %6.1f TFLOP/s nominal (27-tap flops)" % (name, ms, flops / ms / 1e9))
     y1 = ops.conv3d(x, wd, x_ss=ss, x_relu=True)[0]
     y2 = ops.conv3d_wino(x, ww, x_ss=ss, x_relu=True)[0]
     print("max|wino - direct| = %.3e (|y|max %.2f)" % ((y1 - y2).abs().max().item(), y1.abs().max().item()))
+    y3 = ops.conv_wino(x, ww, 64, 3, x_ss=ss, x_relu=True)[0]
+    print("max|wino-pc - direct| = %.3e" % (y1 - y3).abs().max().item())
+    if args.cnn:
+        import torch.nn.functional as F
+        # the feature CNN's layer shapes at config B (5 images): direct conv2d.hip vs the Winograd kernel (kd = 1)
+        for (N, Hh, Ww, Cin, Cout, dil) in ((5, 192, 256, 64, 64, 1), (5, 192, 256, 128, 128, 1), (5, 192, 256, 128, 128, 2),
+                                            (5, 192, 256, 320, 128, 1), (5, 64, 96, 64, 64, 1), (5, 64, 96, 128, 128, 2)):
+            x2 = torch.randn(N, Hh, Ww, Cin, generator=g).cuda()
+            w2 = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).cuda()
+            s2 = torch.rand(Cin, 2, generator=g).cuda()
+            wd2, ww2 = ops.conv_pack_weights(w2), ops.conv_wino_pack(w2)
+            fl = 2.0 * N * Hh * Ww * Cin * Cout * 9
+            t1 = timeit(lambda: ops.conv2d(x2, wd2, Cout, dil, x_ss=s2, x_relu=True), args.iters)
+            t2 = timeit(lambda: ops.conv_wino(x2, ww2, Cout, 1, dil, x_ss=s2, x_relu=True), args.iters)
+            d = (ops.conv2d(x2, wd2, Cout, dil, x_ss=s2, x_relu=True)[0] - ops.conv_wino(x2, ww2, Cout, 1, dil, x_ss=s2, x_relu=True)[0]).abs().max().item()
+            print("conv2d N%d %dx%d %3d->%3d dil%d: direct %7.3f ms (%5.1f TF)  wino-pc %7.3f ms (%5.1f TF nominal)  max|d| %.2e"
+                  % (N, Hh, Ww, Cin, Cout, dil, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9, d))
 
 
 if __name__ == "__main__":
