@@ -51,6 +51,8 @@ struct WinoPcArgs {
     int x_relu, res_relu;
     int N, H, W, Cin, Cout;
     int ntiles;           // spatial tiles x Cout/64
+    int abl;              // developer ablation bits, honoured by -DNRGBD_DEV builds only: 1 = producers only, 2 = consumers only,
+                          // 4 = no transform, 8 = no publish, 16 / 32 = s_setprio 2 for the consumers / producers
 };
 
 struct PcTile { int n, y0, x0, py, px, cg, row; };
@@ -81,6 +83,27 @@ __device__ __forceinline__ int pc_slot(int xi, int tile, int slot) {
     return ((xi * kPcTiles + tile) << 4) + (((slot + 2 * ((tile >> 3) & 1)) & 3) << 2);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed fp32 helpers (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two lanes of a register pair per instruction).  The
+// producers' VALU instructions only get the issue slots the co-resident consumer's MFMA stream leaves (measured: about one
+// per MFMA), so every instruction saved there is stage time saved.  a*s + c with a splat s; s = -1 is the exact c - a.
+__device__ __forceinline__ f32x4 pk_fma_s(f32x4 a, float s, f32x4 c) {
+    const f32x2 m = {s, s};
+    const f32x2 lo = __builtin_elementwise_fma(a.lo, m, c.lo), hi = __builtin_elementwise_fma(a.hi, m, c.hi);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+// max(x, 0) as ONE v_max_f32: fmaxf() on a packed-FMA result costs two (the compiler quiets a possible signalling NaN first)
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
+    const f32x2 lo = a.lo + b.lo, hi = a.hi + b.hi;
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
 template <int KD, int DIL, bool RES>
 __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -88,8 +111,14 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     float* rawb = lds + kPcNBuf * kPcV;        // [4 producer waves][4 rows][20 pixels][16]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = wave & 3;                   // index within the role
     const int NS = (a.Cin / kCB) * KD;         // stages per tile
+#ifdef NRGBD_DEV
+    const int abl = a.abl;
+#else
+    constexpr int abl = 0;
+#endif
 
     // ---- this workgroup's share of the tile list: XCD x = blockIdx % 8 owns the x-th contiguous eighth, its workgroups
     //      (slots) walk it interleaved, so the workgroups of one XCD are always on neighbouring tiles
@@ -107,7 +136,9 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     const int count = (end - first + step - 1) / step;
     const unsigned plane = (unsigned)((size_t)a.H * a.W * a.Cin);
 
-    if (wv < 4) {
+    // Producers are waves 0-3: VALU issue on a SIMD is arbitrated by age, and the producers' (few) VALU instructions have to
+    // get through beside the consumer's continuous MFMA stream (measured: 3.58 -> 3.38 ms per layer from this alone)
+    if (wave >= 4) {
         // =========================================== consumer: 16 output channels x 16 xi x 32 tiles ====================
         const int kq = lane >> 4, jj = lane & 15;
         f32x4 acc[16][2];
@@ -127,6 +158,9 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         An[0][0] = *reinterpret_cast<const f32x4*>(Vb + a0);
         An[0][1] = *reinterpret_cast<const f32x4*>(Vb + a1);
         int buf = 0;
+#ifdef NRGBD_DEV
+        long t_mfma = 0, t_bar = 0, t_epi = 0;
+#endif
         for (int it = 0; it < count; ++it) {
             const int tnext = first + (it + 1 < count ? it + 1 : it) * step;
             const PcTile tn = pc_decode<KD, DIL>(tnext, a);
@@ -137,6 +171,10 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                 const float* Vn = Vb + nbuf * kPcV;
                 const f32x4* wcur = wt + (size_t)s * (16 * 256);
                 const f32x4* wnx = s + 1 < NS ? wcur + 16 * 256 : wt_next;
+#ifdef NRGBD_DEV
+                const long c0 = wall_clock64();
+#endif
+                if (!(abl & 1))
 #pragma unroll
                 for (int xi = 0; xi < 16; ++xi) {
                     const int cur = xi & 1, nxt = cur ^ 1;
@@ -157,9 +195,19 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+#ifdef NRGBD_DEV
+                const long c1 = wall_clock64();
+#endif
                 __syncthreads();
+#ifdef NRGBD_DEV
+                const long c2 = wall_clock64();
+                t_mfma += c1 - c0; t_bar += c2 - c1;
+#endif
                 buf = nbuf;
             }
+#ifdef NRGBD_DEV
+            const long c3 = wall_clock64();
+#endif
             // ---- inverse transform Y = A^T M A in registers + output + per-channel partial statistics ----
             // lane (kq, jj): output channel co = 16 wv + jj; register r of row block m = tile 16 m + 4 kq + r
             const int co = tl.cg * 64 + wv * 16 + jj;
@@ -202,139 +250,233 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
             for (int xi = 0; xi < 16; ++xi) { acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             tl = tn;
             wt = wt_next;
+#ifdef NRGBD_DEV
+            t_epi += wall_clock64() - c3;
+#endif
         }
+#ifdef NRGBD_DEV
+        if ((abl & 64) && a.stats && wv == 0 && lane == 0) {   // timing record over the first statistics rows (results invalid)
+            float* o = a.stats + (size_t)blockIdx.x * 8;
+            o[0] = (float)t_mfma; o[1] = (float)t_bar; o[2] = (float)t_epi; o[3] = (float)count;
+        }
+#endif
     } else {
         // =========================================== producer: tile row pw (8 Winograd tiles) ===========================
-        const int pw = wv - 4;
+        const int pw = wv;
         float* raw = rawb + pw * kPcRawWave;
         const int w4 = lane & 3;
         // load / publish items: item = lane + 64u -> strip pixel pi = item >> 2 in (row, de-interleaved column) order
-        int it_rr[kPcNPF], it_col[kPcNPF], wr_off[kPcNPF];
+        // item u of this lane -> strip row, image-order column and strip offset (recomputed where needed: a few integer
+        // operations instead of 15 live registers)
+        auto item_rr = [&](int u) { return ((lane + 64 * u) >> 2) / 18; };
+        auto item_cp = [&](int u) { const int pi = (lane + 64 * u) >> 2; return pi - (pi / 18) * 18; };
+        auto item_col = [&](int u) { const int cp = item_cp(u); return cp < 9 ? 2 * cp : 2 * cp - 17; };   // even columns first, then odd
+        // strip offset an item is published at; the 32 lanes without a fifth item (288 = 4.5 x 64) write a zero into the
+        // strip's 8 pad pixels (columns 18, 19 of the 20-pixel row pitch) so that the publish loop has no per-lane branch
+        int wr_off[kPcNPF];
 #pragma unroll
         for (int u = 0; u < kPcNPF; ++u) {
-            const int pi = (lane + 64 * u) >> 2;
-            const int rr = pi / 18, cp = pi - rr * 18;
-            it_rr[u] = rr;
-            it_col[u] = cp < 9 ? 2 * cp : 2 * cp - 17;      // strip columns stored even ones first, then odd ones
-            wr_off[u] = (rr * kPcRawW + cp) * kCB + w4 * 4;
+            const int item = lane + 64 * u, e = (item - kPcItems) >> 2;
+            wr_off[u] = item < kPcItems ? (item_rr(u) * kPcRawW + item_cp(u)) * kCB + w4 * 4
+                                        : ((e >> 1) * kPcRawW + 18 + (e & 1)) * kCB + w4 * 4;
         }
         // transform item of this lane: (tile of the row, 16-byte word, half of the xi rows); 16 consecutive lanes = 4 tiles x 4
         // words: conflict-free strip reads (the four tiles' columns are consecutive strip pixels) and V writes
         const int tword = lane & 3, txl = ((lane >> 5) << 2) | ((lane >> 2) & 3), thalf = (lane >> 4) & 1;
         const int ttile = pw * 8 + txl;
-        const int rd0 = (thalf * kPcRawW + txl) * kCB + tword * 4;   // strip (row thalf, column 2 txl): cc = 0; cc=1: +9 px; 2: +1; 3: +10
+        // Row transform without per-lane selects: the lane reads its three strip rows in a lane-dependent ORDER (R0, R1, R2) and
+        // computes ya = R0 - R1, yb = R1 + sg * R2:
+        //   half 0 (xi_y 0, 1): R = strip rows (0, 2, 1), sg = +1 ->  d0 - d2,  d2 + d1
+        //   half 1 (xi_y 2, 3): R = strip rows (2, 1, 3), sg = -1 ->  d2 - d1,  d1 - d3
+        // (strip columns of tile txl: cc = 0 at column pixel txl, cc = 1: +9 pixels, cc = 2: +1, cc = 3: +10)
+        const int rdc = txl * kCB + tword * 4;
+        const int rdR0 = (thalf ? 2 : 0) * kPcRawW * kCB + rdc, rdR1 = (thalf ? 1 : 2) * kPcRawW * kCB + rdc,
+                  rdR2 = (thalf ? 3 : 1) * kPcRawW * kCB + rdc;
+        const float sg = thalf ? -1.f : 1.f;
+        float m1 = -1.f;                    // opaque to the optimiser: fma(a, -1, c) would otherwise be folded into four scalar
+        asm volatile("" : "+v"(m1));        // v_sub_f32; as a register operand it stays one v_pk_fma_f32 per pair (same rounding)
 
-        unsigned off[kPcNPF], ok = 0, own = 0;
-        PcTile tl = pc_decode<KD, DIL>(first, a);
-        auto setup = [&](const PcTile& t) {
-            ok = 0; own = 0;
+        // Per-tile bookkeeping of this lane's items: in-plane element offset (a harmless in-tensor offset when outside),
+        // inside-the-image bits, owner bits (materialise target).  Two books: the raw words run TWO stages ahead of their
+        // use, so the last two stages of a tile already load the next tile's words.
+        unsigned cur_off[kPcNPF], cur_own = 0, nxt_off[kPcNPF], nxt_own = 0;   // BYTE offsets
+        float cur_keep[kPcNPF], nxt_keep[kPcNPF];                               // 1 inside the image, 0 outside (zero padding)
+        auto setup = [&](const PcTile& t, unsigned (&b_off)[kPcNPF], float (&b_keep)[kPcNPF], unsigned& b_own) __attribute__((always_inline)) {
+            b_own = 0;
 #pragma unroll
             for (int u = 0; u < kPcNPF; ++u) {
-                const int hy = 2 * pw + it_rr[u], hx = it_col[u];
+                const int rr = item_rr(u), hy = 2 * pw + rr, hx = item_col(u);
                 const int gy = t.y0 + t.py + DIL * (hy - 1), gx = t.x0 + t.px + DIL * (hx - 1);
                 const bool in = (lane + 64 * u) < kPcItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 const unsigned n2 = KD == 3 ? 0u : (unsigned)t.n;
-                off[u] = in ? (unsigned)((((size_t)n2 * a.H + gy) * a.W + gx) * a.Cin + w4 * 4) : (unsigned)(w4 * 4);
-                if (in) ok |= 1u << u;
-                if (in && (it_rr[u] == 1 || it_rr[u] == 2) && hx >= 1 && hx <= kPcTW) own |= 1u << u;
+                b_off[u] = 4u * (in ? (unsigned)((((size_t)n2 * a.H + gy) * a.W + gx) * a.Cin + w4 * 4) : (unsigned)(w4 * 4));
+                b_keep[u] = in ? 1.f : 0.f;
+                if (in && (rr == 1 || rr == 2) && hx >= 1 && hx <= kPcTW) b_own |= 1u << u;
             }
         };
-        f32x4 pre[kPcNPF], prer[RES ? kPcNPF : 1];
-        auto issue = [&](const PcTile& t, int s) {   // raw words of stage s of tile t -> registers
+        // One register set per stage parity: raw words (+ residual words) and the (scale, shift) of the stage's 4 channels.
+        // A set is refilled for stage s+2 right after stage s has published it, so a load has two stage periods to land:
+        // with a single set the chain load -> publish -> next load made the producers' period = memory latency + publish
+        // (measured 2.8 us against the consumers' 2.0 us of MFMAs), i.e. the matrix pipe waited for the producers.
+        struct Regs { f32x4 pre[kPcNPF]; f32x4 prer[RES ? kPcNPF : 1]; f32x4 ss[2]; f32x4 rs[2]; };
+        PcTile tl = pc_decode<KD, DIL>(first, a), tn = tl;
+        // raw words of stage s -> registers; nx: the stage belongs to the NEXT tile (book nxt_*, tile tn).  The book is
+        // selected per value, not per pointer: a pointer select would force both books into scratch memory.
+        auto issue = [&](bool nx, int s, Regs& r) __attribute__((always_inline)) {
             const int cb = s / KD, kd = s - cb * KD;
-            const int z = KD == 3 ? min(max(t.n + kd - 1, 0), a.N - 1) : 0;   // clamped: an outside slice is zeroed when published
-            const unsigned base = (unsigned)z * plane + (unsigned)(cb * kCB);
+            r.ss[0] = r.ss[1] = r.rs[0] = r.rs[1] = f32x4{1.f, 0.f, 1.f, 0.f};
+            if (a.x_ss) {
+                r.ss[0] = *reinterpret_cast<const f32x4*>(a.x_ss + 2 * (cb * kCB + w4 * 4));
+                r.ss[1] = *reinterpret_cast<const f32x4*>(a.x_ss + 2 * (cb * kCB + w4 * 4) + 4);
+            }
+            if (RES && a.res_ss) {
+                r.rs[0] = *reinterpret_cast<const f32x4*>(a.res_ss + 2 * (cb * kCB + w4 * 4));
+                r.rs[1] = *reinterpret_cast<const f32x4*>(a.res_ss + 2 * (cb * kCB + w4 * 4) + 4);
+            }
+            const int tz = nx ? tn.n : tl.n;
+            const int z = KD == 3 ? min(max(tz + kd - 1, 0), a.N - 1) : 0;   // clamped: an outside slice is zeroed when published
+            // uniform 64-bit base + per-lane 32-bit byte offset: the global_load saddr form, no per-lane 64-bit address math
+            const size_t base = ((size_t)z * plane + (size_t)(cb * kCB)) * sizeof(float);
+            const char* xb = reinterpret_cast<const char*>(a.x) + base;
+            const char* rb = reinterpret_cast<const char*>(a.res) + base;
 #pragma unroll
             for (int u = 0; u < kPcNPF; ++u) {
-                pre[u] = *reinterpret_cast<const f32x4*>(a.x + base + off[u]);
-                if constexpr (RES) prer[u] = *reinterpret_cast<const f32x4*>(a.res + base + off[u]);
+                const unsigned o = nx ? nxt_off[u] : cur_off[u];
+                r.pre[u] = *reinterpret_cast<const f32x4*>(xb + o);
+                if constexpr (RES) r.prer[u] = *reinterpret_cast<const f32x4*>(rb + o);
             }
         };
-        setup(tl);
-        issue(tl, 0);
+        setup(tl, cur_off, cur_keep, cur_own);
+        Regs set0, set1;
+        issue(false, 0, set0);
+        issue(false, 1, set1);               // NS is even and >= 2 (checked by the launcher)
         int qbuf = 0;
-        for (int it = 0; it < count; ++it) {
-            for (int s = 0; s < NS; ++s) {
-                const int cb = s / KD, kd = s - cb * KD;
-                const int z = KD == 3 ? tl.n + kd - 1 : tl.n;
-                const bool zin = KD != 3 || (z >= 0 && z < a.N);
-                {   // (1) normalise / activate the prefetched words and publish them to this wave's strip
-                    const int c = cb * kCB + w4 * 4;
-                    float ss[8] = {1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f}, rs[8] = {1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f};
-                    if (a.x_ss) {
+#ifdef NRGBD_DEV
+        long t_pub = 0, t_tr = 0, t_pbar = 0, t_q0 = 0, t_q1 = 0, t_q2 = 0;
+#endif
+        bool has_next = false;
+        // one stage: publish set r (stage s of the current tile), refill it for stage s+2, transform, barrier
+        auto stage = [&](int s, Regs& r) __attribute__((always_inline)) {
+#ifdef NRGBD_DEV
+            const long p0 = wall_clock64();
+            long p1 = p0;
+#endif
+            const int cb = s / KD, kd = s - cb * KD;
+            const int z = KD == 3 ? tl.n + kd - 1 : tl.n;
+            const bool zin = KD != 3 || (z >= 0 && z < a.N);
+            if (!(abl & 2)) {
+#ifdef NRGBD_DEV
+                if (abl & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                const long q0 = wall_clock64();
+#endif
+                if (!(abl & 8)) {   // (1) normalise / activate the prefetched words and publish them to this wave's strip
+                    // Straight-line, packed, no per-lane branches or selects: as a chain of exec-masked blocks this phase took
+                    // 0.74 us alone and 2.0 us beside the consumers' MFMA stream — longer than the MFMAs it has to stay ahead of.
+                    if (!zin) {   // a depth tap outside the volume: the whole slice is zero padding
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) ss[e] = a.x_ss[2 * c + e];
-                    }
-                    if (RES && a.res_ss) {
+                        for (int u = 0; u < kPcNPF; ++u) *reinterpret_cast<f32x4*>(raw + wr_off[u]) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    } else {
+                        // (scale, shift) pairs re-paired for the packed FMAs: channels (0,1) and (2,3); identity = (1, 0)
+                        const f32x2 sc01 = {r.ss[0].x, r.ss[0].z}, sh01 = {r.ss[0].y, r.ss[0].w}, sc23 = {r.ss[1].x, r.ss[1].z}, sh23 = {r.ss[1].y, r.ss[1].w};
+                        const f32x2 rc01 = {r.rs[0].x, r.rs[0].z}, rh01 = {r.rs[0].y, r.rs[0].w}, rc23 = {r.rs[1].x, r.rs[1].z}, rh23 = {r.rs[1].y, r.rs[1].w};
+                        const bool wmat = a.mat && (KD != 3 || kd == 1) && tl.cg == 0;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) rs[e] = a.res_ss[2 * c + e];
-                    }
-                    const bool wmat = a.mat && (KD != 3 || kd == 1) && tl.cg == 0;
-#pragma unroll
-                    for (int u = 0; u < kPcNPF; ++u) {
-                        if (lane + 64 * u >= kPcItems) continue;
-                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                        if (zin && ((ok >> u) & 1u)) {   // zero padding applies to the ACTIVATED tensor
-                            v = pre[u];
-                            if (a.x_ss) {
-                                v.x = __builtin_fmaf(v.x, ss[0], ss[1]); v.y = __builtin_fmaf(v.y, ss[2], ss[3]);
-                                v.z = __builtin_fmaf(v.z, ss[4], ss[5]); v.w = __builtin_fmaf(v.w, ss[6], ss[7]);
-                            }
-                            if (a.x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        for (int u = 0; u < kPcNPF; ++u) {
+                            const f32x4 x = r.pre[u];
+                            f32x2 lo = __builtin_elementwise_fma(x.lo, sc01, sh01), hi = __builtin_elementwise_fma(x.hi, sc23, sh23);
+                            if (a.x_relu) { lo.x = relu1(lo.x); lo.y = relu1(lo.y); hi.x = relu1(hi.x); hi.y = relu1(hi.y); }
                             if constexpr (RES) {
-                                f32x4 r = prer[u];
-                                if (a.res_ss) {
-                                    r.x = __builtin_fmaf(r.x, rs[0], rs[1]); r.y = __builtin_fmaf(r.y, rs[2], rs[3]);
-                                    r.z = __builtin_fmaf(r.z, rs[4], rs[5]); r.w = __builtin_fmaf(r.w, rs[6], rs[7]);
-                                }
-                                if (a.res_relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-                                v = v + r;
+                                const f32x4 q = r.prer[u];
+                                f32x2 ql = __builtin_elementwise_fma(q.lo, rc01, rh01), qh = __builtin_elementwise_fma(q.hi, rc23, rh23);
+                                if (a.res_relu) { ql.x = relu1(ql.x); ql.y = relu1(ql.y); qh.x = relu1(qh.x); qh.y = relu1(qh.y); }
+                                lo = lo + ql; hi = hi + qh;
                             }
+                            // zero padding applies to the ACTIVATED tensor: out-of-image lanes (their loads read a harmless
+                            // in-tensor word) are multiplied by 0
+                            const f32x2 kk = {cur_keep[u], cur_keep[u]};
+                            lo = lo * kk; hi = hi * kk;
+                            const f32x4 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
                             // the activated input is written once: by the wave that owns the pixel, at the centre tap
-                            if (wmat && ((own >> u) & 1u))
-                                *reinterpret_cast<f32x4*>(a.mat + (unsigned)z * (KD == 3 ? plane : 0u) + (unsigned)(cb * kCB) + off[u]) = v;
+                            if (wmat) {
+                                if ((cur_own >> u) & 1u)
+                                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.mat) + ((size_t)(KD == 3 ? z : 0) * plane + (size_t)(cb * kCB)) * sizeof(float) + cur_off[u]) = v;
+                            }
+                            if (abl & 128) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }
+                            *reinterpret_cast<f32x4*>(raw + wr_off[u]) = v;
                         }
-                        *reinterpret_cast<f32x4*>(raw + wr_off[u]) = v;
                     }
                 }
-                // (2) the next stage's words fly while this one is transformed (and while the consumers work through two more)
-                if (s + 1 < NS) issue(tl, s + 1);
-                else if (it + 1 < count) { tl = pc_decode<KD, DIL>(first + (it + 1) * step, a); setup(tl); issue(tl, 0); }
+#ifdef NRGBD_DEV
+                const long q1 = wall_clock64();
+#endif
+                // (2) refill the set: stage s+2 of this tile, or stage s+2-NS of the next one
+                {
+                    const bool nx = s + 2 >= NS;
+                    if (!nx || has_next) issue(nx, nx ? s + 2 - NS : s + 2, r);
+                }
+#ifdef NRGBD_DEV
+                const long q2 = wall_clock64();
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the strip is wave-private: in-order LDS, no barrier
-                {   // (3) input transform B^T d B of this lane's (tile, word): rows first (2 of the 4 xi_y), then columns
-                    f32x4 r0[4], r1[4], r2[4];
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const int co = ((cc & 1) * 9 + (cc >> 1)) * kCB;
-                        r0[cc] = *reinterpret_cast<const f32x4*>(raw + rd0 + co);
-                        r1[cc] = *reinterpret_cast<const f32x4*>(raw + rd0 + kPcRawW * kCB + co);
-                        r2[cc] = *reinterpret_cast<const f32x4*>(raw + rd0 + 2 * kPcRawW * kCB + co);
-                    }
-                    // half 0: strip rows 0,1,2 = patch rows d0,d1,d2 -> xi_y 0 = d0 - d2, xi_y 1 = d1 + d2
-                    // half 1: strip rows 1,2,3 = patch rows d1,d2,d3 -> xi_y 2 = d2 - d1, xi_y 3 = d1 - d3
+#ifdef NRGBD_DEV
+                p1 = wall_clock64();
+                t_q0 += q0 - p0; t_q1 += q1 - q0; t_q2 += q2 - q1;
+#endif
+                if (!(abl & 4)) {   // (3) input transform B^T d B of this lane's (tile, word): rows (2 of the 4 xi_y), then columns
                     f32x4 ya[4], yb[4];
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
-                        ya[cc] = thalf ? (r1[cc] - r0[cc]) : (r0[cc] - r2[cc]);
-                        yb[cc] = thalf ? (r0[cc] - r2[cc]) : (r1[cc] + r2[cc]);
+                        const int co = ((cc & 1) * 9 + (cc >> 1)) * kCB;
+                        const f32x4 R0 = *reinterpret_cast<const f32x4*>(raw + rdR0 + co);
+                        const f32x4 R1 = *reinterpret_cast<const f32x4*>(raw + rdR1 + co);
+                        const f32x4 R2 = *reinterpret_cast<const f32x4*>(raw + rdR2 + co);
+                        ya[cc] = pk_fma_s(R1, m1, R0);   // R0 - R1
+                        yb[cc] = pk_fma_s(R2, sg, R1);     // R1 +- R2
                     }
                     float* Vq = Vb + qbuf * kPcV;
                     const int xa = (2 * thalf) * 4, xb = (2 * thalf + 1) * 4;
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 0, ttile, tword)) = ya[0] - ya[2];
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 1, ttile, tword)) = ya[1] + ya[2];
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 2, ttile, tword)) = ya[2] - ya[1];
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 3, ttile, tword)) = ya[1] - ya[3];
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 0, ttile, tword)) = yb[0] - yb[2];
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 1, ttile, tword)) = yb[1] + yb[2];
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 2, ttile, tword)) = yb[2] - yb[1];
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 3, ttile, tword)) = yb[1] - yb[3];
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 0, ttile, tword)) = pk_fma_s(ya[2], m1, ya[0]);   // y0 - y2
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 1, ttile, tword)) = pk_add(ya[1], ya[2]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 2, ttile, tword)) = pk_fma_s(ya[1], m1, ya[2]);   // y2 - y1
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 3, ttile, tword)) = pk_fma_s(ya[3], m1, ya[1]);   // y1 - y3
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 0, ttile, tword)) = pk_fma_s(yb[2], m1, yb[0]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 1, ttile, tword)) = pk_add(yb[1], yb[2]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 2, ttile, tword)) = pk_fma_s(yb[1], m1, yb[2]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 3, ttile, tword)) = pk_fma_s(yb[3], m1, yb[1]);
                 }
-                __syncthreads();
-                qbuf = qbuf == kPcNBuf - 1 ? 0 : qbuf + 1;
             }
+#ifdef NRGBD_DEV
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long p2 = wall_clock64();
+#endif
+            __syncthreads();
+#ifdef NRGBD_DEV
+            t_pub += p1 - p0; t_tr += p2 - p1; t_pbar += wall_clock64() - p2;
+#endif
+            qbuf = qbuf == kPcNBuf - 1 ? 0 : qbuf + 1;
+        };
+        for (int it = 0; it < count; ++it) {
+            has_next = it + 1 < count;
+            for (int s = 0; s < NS; s += 2) {
+                if (s + 2 == NS && has_next) { tn = pc_decode<KD, DIL>(first + (it + 1) * step, a); setup(tn, nxt_off, nxt_keep, nxt_own); }
+                stage(s, set0);
+                stage(s + 1, set1);
+            }
+            tl = tn;
+#pragma unroll
+            for (int u = 0; u < kPcNPF; ++u) { cur_off[u] = nxt_off[u]; cur_keep[u] = nxt_keep[u]; }
+            cur_own = nxt_own;
         }
         __syncthreads();                       // the consumers' last two stages
         __syncthreads();
+#ifdef NRGBD_DEV
+        if ((abl & 64) && a.stats && wv == 0 && lane == 0) {
+            float* o = a.stats + (size_t)blockIdx.x * 8 + 4;
+            o[0] = (float)t_pub; o[1] = (float)t_tr; o[2] = (float)t_pbar; o[3] = 0.f;
+            float* o2 = a.stats + 4096 + (size_t)blockIdx.x * 4;
+            o2[0] = (float)t_q0; o2[1] = (float)t_q1; o2[2] = (float)t_q2; o2[3] = 0.f;
+        }
+#endif
     }
 }
 
@@ -353,11 +495,13 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     if (!x || !w_wino || !y) return NRGBD_E_NULL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
     if ((kd != 1 && kd != 3) || (dilation != 1 && dilation != 2) || (kd == 3 && dilation != 1)) return NRGBD_E_ARG;
-    if ((long)N * H * W * Cin >= (1L << 32)) return NRGBD_E_SHAPE;   // 32-bit element offsets in the loader
+    if (((Cin / kCB) * kd) & 1) return NRGBD_E_SHAPE;   // stages are produced in pairs (two register sets)
+    if ((long)N * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;   // 32-bit BYTE offsets in the loader
     const int rows = nrgbd_conv_wino_tiles(N, H, W, dilation);
     const long nt = (long)rows * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
-    WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt};
+    WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt,
+                 dev_env_int("NRGBD_WINO_ABL")};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);

@@ -25,7 +25,12 @@ def main():
     ap.add_argument("--config", default="B")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--cnn", action="store_true", help="also time the feature CNN's 2-D layer shapes")
+    ap.add_argument("--dev", action="store_true", help="load libnrgbd_hip_dev.so (python -m neuralrgbd_amd.build --dev): "
+                    "NRGBD_WINO_ABL=1|2 (producers only / consumers only) is honoured there")
     args = ap.parse_args()
+    if args.dev:
+        from neuralrgbd_amd import _lib
+        _lib.LIB_PATH = _lib.LIB_PATH.replace("libnrgbd_hip.so", "libnrgbd_hip_dev.so")
     from neuralrgbd_amd import ops
     D, H, W = GRIDS[args.config]
     g = torch.Generator().manual_seed(0)
@@ -43,6 +48,17 @@ def main():
                      ("wino-pc res+mat", lambda: ops.conv_wino(x, ww, 64, 3, x_ss=ss, res=r, materialize=True))):
         ms = timeit(fn, args.iters)
         print("%-16s %8.3f ms   %6.1f TFLOP/s nominal (27-tap flops)" % (name, ms, flops / ms / 1e9))
+    if args.dev and (int(os.environ.get("NRGBD_WINO_ABL", "0")) & 64):
+        # in-kernel clocks (dev build): per workgroup [mfma, consumer barrier, epilogue, tiles | publish, transform, producer barrier]
+        st = ops.conv_wino(x, ww, 64, 3, x_ss=ss, x_relu=True)[1]
+        torch.cuda.synchronize()
+        rec = st.reshape(-1)[:256 * 8].reshape(256, 8).double().cpu()
+        per = rec[:, 3:4] * 12
+        names = ("mfma", "c-barrier", "epilogue/tile*12", "tiles", "publish", "transform", "p-barrier")
+        vals = rec.clone(); vals[:, [0, 1, 2, 4, 5, 6]] /= per
+        r2 = st.reshape(-1)[4096:4096 + 256 * 4].reshape(256, 4).double().cpu() / per
+        print("publish split: wait-vmcnt %.0f  valu+ds_write %.0f  issue-loads %.0f" % tuple(r2.median(0).values.tolist()[:3]))
+        print("in-kernel wall_clock64 (10 ns ticks) per stage, median over workgroups: " + "  ".join("%s %.0f" % (n, v) for n, v in zip(names, vals.median(0).values.tolist())))
     y1 = ops.conv3d(x, wd, x_ss=ss, x_relu=True)[0]
     y2 = ops.conv3d_wino(x, ww, x_ss=ss, x_relu=True)[0]
     print("max|wino - direct| = %.3e (|y|max %.2f)" % ((y1 - y2).abs().max().item(), y1.abs().max().item()))
