@@ -16,6 +16,7 @@ BatchNorm2d are built with track_running_stats=False, the two residual-shortcut 
 eleven BatchNorm3d keep (and update) running statistics.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -80,6 +81,19 @@ def _packed_weights(owner, conv):
     if hit is None or hit[0] != key:
         hit = (key, ops.conv_pack_weights(w.detach().contiguous()))
         cache[id(conv)] = hit
+    return hit[1]
+
+
+def _packed_wino(owner, conv):
+    """Winograd-domain weight stream U = G g G^T of a 3x3(x3) conv for csrc/wino_pc.hip, re-packed only when its weight changes."""
+    from . import ops
+    cache = owner.__dict__.setdefault("_wp_cache", {})
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device), "wino")
+    hit = cache.get(("wino", id(conv)))
+    if hit is None or hit[0] != key:
+        hit = (key, ops.conv_wino_pack(w.detach().contiguous()))
+        cache[("wino", id(conv))] = hit
     return hit[1]
 
 
@@ -280,7 +294,17 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         d = conv.dilation[0]
         mfma = (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (d, d)
                 and conv.in_channels % 16 == 0 and (conv.out_channels, d) in self._MFMA_SHAPES)
-        if mfma:
+        # Winograd-domain kernel (csrc/wino_pc.hip) for every layer it covers (Cin % 32 == 0, Cout % 64 == 0: all but the
+        # 32-channel half-resolution layers): 0.116 vs 0.193 ms (64 -> 64), 0.37 vs 0.69 ms (128 -> 128), 0.80 vs 1.62 ms
+        # (320 -> 128) at config B, and 2.4-3x at the 64x96 grid where 16x16 tiles under-fill the chip.  NRGBD_CNN_CONV=direct
+        # keeps conv2d.hip for A/B.
+        wino = (mfma and d in (1, 2) and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
+                and os.environ.get("NRGBD_CNN_CONV", "wino") != "direct")
+        if wino:
+            z, st, mat = ops.conv_wino(a.z, _packed_wino(self, conv), conv.out_channels, 1, d, x_ss=a.ss, x_relu=a.relu,
+                                       res=a.r, res_ss=a.r_ss, res_relu=a.r_relu, materialize=materialize,
+                                       want_stats=_needs_stats(bn))
+        elif mfma:
             z, st, mat = ops.conv2d(a.z, _packed_weights(self, conv), conv.out_channels, d, x_ss=a.ss, x_relu=a.relu,
                                     res=a.r, res_ss=a.r_ss, res_relu=a.r_relu, materialize=materialize,
                                     want_stats=_needs_stats(bn))
@@ -314,17 +338,13 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         return _Act(y2.z, y2.ss, False, r=sk.z, r_ss=sk.ss)
 
     def fused_ok(self, x):
-        """Inference on the GPU, and a 1/4-resolution grid large enough to fill the chip with the conv kernel's
-        16 x 16-pixel workgroup tiles (>= 1.5 per CU; measured: 1024x768 and 640x480 images gain, 384x256 and
-        768x256 lose against the vendor convolutions + csrc/bn2d.hip).  NRGBD_CNN=vendor|mfma overrides."""
-        import os
+        """Inference on the GPU -> the matrix-core trunk (forward_channels_last).  With the 8x16-pixel tiles of the persistent
+        Winograd kernel it wins at every SURVEY grid (round 2: trunk 2.6 vs 3.7 ms at 256x384 images, 11.7 vs 19.5 ms at
+        1024x768; with round 1's 16x16-tile direct kernel the small grids under-filled the chip and stayed on the vendor
+        convolutions).  NRGBD_CNN=vendor|mfma overrides."""
         if not (x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32):
             return False
-        mode = os.environ.get("NRGBD_CNN", "auto")
-        if mode != "auto":
-            return mode == "mfma"
-        tiles = x.shape[0] * (-(-x.shape[2] // 64)) * (-(-x.shape[3] // 64))
-        return tiles >= 384
+        return os.environ.get("NRGBD_CNN", "auto") != "vendor"
 
     def forward_channels_last(self, x):
         """Inference on the hand-written kernels: x [N,3,H,W] -> (layer1 [N,H/2,W/2,32], feat [N,H/4,W/4,F]), both
@@ -512,15 +532,19 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         need_stats = lambda bn: bn.training or not bn.track_running_stats
 
         import os
-        # the ten 64 -> 64 layers in the Winograd domain (conv3d_wino.hip: 3.3 vs 5.4 ms per layer at config B, and closer to
-        # the float64 result than the direct kernel); NRGBD_KNET=direct selects conv3d.hip for A/B
-        wino = os.environ.get("NRGBD_KNET", "auto") != "direct"
+        # the ten 64 -> 64 layers in the Winograd domain (wino_pc.hip 3.0 / conv3d_wino.hip 3.3 / conv3d.hip 5.4 ms per layer at
+        # config B, and closer to the float64 result than the direct kernel); NRGBD_KNET=wino1|direct select the others for A/B
+        mode = os.environ.get("NRGBD_KNET", "auto")   # auto = wino_pc.hip (generation 2) | wino1 = conv3d_wino.hip | direct
+        wino = mode != "direct"
 
         def run(i, x, x_ss, x_relu, res=None, materialize=False):
             conv, bn = L[i]
-            if wino and conv.in_channels == 64:
+            if wino and conv.in_channels == 64 and mode == "wino1":
                 y, st, mat = ops.conv3d_wino(x, self._packed_wino(conv), x_ss=x_ss, x_relu=x_relu, res=res,
                                              materialize=materialize, want_stats=need_stats(bn))
+            elif wino and conv.in_channels == 64:
+                y, st, mat = ops.conv_wino(x, _packed_wino(self, conv), 64, 3, x_ss=x_ss, x_relu=x_relu, res=res,
+                                           materialize=materialize, want_stats=need_stats(bn))
             else:
                 y, st, mat = ops.conv3d(x, self._packed(conv), x_ss=x_ss, x_relu=x_relu, res=res,
                                         materialize=materialize, want_stats=need_stats(bn))
