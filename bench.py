@@ -315,8 +315,8 @@ def main():
     timer = KernelTimer()
     ops.costvol = timer.wrap(ops.costvol)
     # the K-Net's plain 64->64 layer (BatchNorm+ReLU prologue, no residual operand): 6 of its 12 layers
-    knet_timer = KernelTimer(keep=lambda a, k: a[0].shape[-1] == 64 and k.get("res") is None and k.get("x_ss") is not None)
-    ops.conv3d = knet_timer.wrap(ops.conv3d)
+    knet_timer = KernelTimer(keep=lambda a, k: a[0].shape[-1] == 64 and a[3] == 3 and k.get("res") is None and k.get("x_ss") is not None)
+    ops.conv_wino = knet_timer.wrap(ops.conv_wino)
 
     # the streaming driver: same per-frame work as test_utils/test_KVNet.py::test (R_net=True), state resident,
     # the update-branch frame captured into one hipGraph after an eager warm-up frame.  Extra streams per GPU are
@@ -369,11 +369,17 @@ def main():
         }
         if knet_timer.last is not None:   # secondary roofline: the matrix-core kernel that takes most of the frame
             c_ms = knet_timer.measure(5)
-            flops = 2.0 * D * h * w * 64 * 64 * 27
+            # F(2x2,3x3) in the plane x 3 depth taps: 16 multiplies per 4 outputs and (ci, co, kd) instead of 36 -> the MFMAs
+            # the kernel actually issues; the 27-tap figure is what a direct convolution would need for the same layer
+            nominal = 2.0 * D * h * w * 64 * 64 * 27
+            tiles = D * (-(-h // 2)) * (-(-w // 2))
+            flops = 2.0 * tiles * 16 * 64 * 64 * 3
             tf = flops / (c_ms * 1e-3) / 1e12
-            line["roofline_mfma"] = {"bound": "mfma", "kernel": "conv3d_mfma_kernel<64> (one K-Net 3x3x3 64->64 layer; the 10 such "
-                                     "layers are ~2/3 of the frame)", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS,
-                                     "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS, "flops": flops, "kernel_ms": c_ms,
+            line["roofline_mfma"] = {"bound": "mfma", "kernel": "conv_wino_pc_kernel<3,1,false> (one K-Net 3x3x3 64->64 layer in the "
+                                     "Winograd domain; the 10 such layers are ~55 % of the frame)", "achieved": tf,
+                                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                                     "flops": flops, "direct_conv_flops": nominal,
+                                     "direct_conv_equivalent_tflops": nominal / (c_ms * 1e-3) / 1e12, "kernel_ms": c_ms,
                                      "launches_timed": 5, "timing": "HIP events around back-to-back re-launches of the frame's own layer call"}
         if world == 1 and not args.no_cpu_baseline:
             # the same frame on both sides: window ring[0] filtered with the stream's current state

@@ -25,6 +25,8 @@
 //   tiles, depth fastest, so the three slices a 3-D tile needs are shared in that XCD's L2), so a tile's epilogue and the
 //   next tile's first loads overlap with the producers' run-ahead instead of being exposed at every workgroup boundary.
 // LDS: 3 x 32 KB V + 4 x 5 KB raw strips = 116 KB (one workgroup per CU; 2 waves per SIMD, up to 256 VGPRs each).
+#include <type_traits>
+
 #include "conv_tile.hpp"
 
 namespace nrgbd {
@@ -141,11 +143,10 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     if (wave >= 4) {
         // =========================================== consumer: 16 output channels x 16 xi x 32 tiles ====================
         const int kq = lane >> 4, jj = lane & 15;
-        f32x4 acc[16][2];
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) { acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        f32x4 acc[16][2];                      // written by the first stage of every tile (C operand = 0): never cleared
         const int a0 = pc_slot(0, jj, kq), a1 = pc_slot(0, 16 + jj, kq);   // + xi * 512 floats + buffer
         const f32x4* wbase = reinterpret_cast<const f32x4*>(a.wp) + wv * 64 + lane;
+        const unsigned lane_yoff = (unsigned)jj + (unsigned)((DIL * 2 * (kq >> 1)) * a.W + 8 * (kq & 1) * DIL) * (unsigned)a.Cout;
         const size_t wgroup = (size_t)NS * 16 * 256;                        // f32x4 per 64-column output group
 
         PcTile tl = pc_decode<KD, DIL>(first, a);
@@ -174,26 +175,36 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
 #ifdef NRGBD_DEV
                 const long c0 = wall_clock64();
 #endif
-                if (!(abl & 1))
+                // one stage = 16 transform points x (2 A reads + 1 weight line + 8 MFMAs).  FIRST (stage 0 of a tile): the first
+                // k-step takes a zero C operand instead of the accumulator, which saves clearing 128 registers per tile.
+                auto body = [&](auto first_tag) __attribute__((always_inline)) {
+                    constexpr bool FIRST = decltype(first_tag)::value;
+                    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int xi = 0; xi < 16; ++xi) {
-                    const int cur = xi & 1, nxt = cur ^ 1;
-                    if (xi + 1 < 16) {
-                        An[nxt][0] = *reinterpret_cast<const f32x4*>(Vc + a0 + (xi + 1) * (kPcTiles * kCB));
-                        An[nxt][1] = *reinterpret_cast<const f32x4*>(Vc + a1 + (xi + 1) * (kPcTiles * kCB));
-                    } else {   // first operand of the next stage: its buffer was completed two barriers ago
-                        An[nxt][0] = *reinterpret_cast<const f32x4*>(Vn + a0);
-                        An[nxt][1] = *reinterpret_cast<const f32x4*>(Vn + a1);
-                    }
-                    Bn[(xi + kPcBD) % kPcNB] = xi + kPcBD < 16 ? wcur[(xi + kPcBD) * 256] : wnx[(xi + kPcBD - 16) * 256];
+                    for (int xi = 0; xi < 16; ++xi) {
+                        const int cur = xi & 1, nxt = cur ^ 1;
+                        if (xi + 1 < 16) {
+                            An[nxt][0] = *reinterpret_cast<const f32x4*>(Vc + a0 + (xi + 1) * (kPcTiles * kCB));
+                            An[nxt][1] = *reinterpret_cast<const f32x4*>(Vc + a1 + (xi + 1) * (kPcTiles * kCB));
+                        } else {   // first operand of the next stage: its buffer was completed two barriers ago
+                            An[nxt][0] = *reinterpret_cast<const f32x4*>(Vn + a0);
+                            An[nxt][1] = *reinterpret_cast<const f32x4*>(Vn + a1);
+                        }
+                        Bn[(xi + kPcBD) % kPcNB] = xi + kPcBD < 16 ? wcur[(xi + kPcBD) * 256] : wnx[(xi + kPcBD - 16) * 256];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[cur][0][e], Bn[xi % kPcNB][e], acc[xi][0], 0, 0, 0);
-                        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[cur][1][e], Bn[xi % kPcNB][e], acc[xi][1], 0, 0, 0);
-                        // pin the order: the two row blocks alternate (no back-to-back dependent MFMAs) and the operand
-                        // streams keep their distances
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int e = 0; e < 4; ++e) {
+                            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[cur][0][e], Bn[xi % kPcNB][e],
+                                                                              FIRST && e == 0 ? zero4 : acc[xi][0], 0, 0, 0);
+                            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[cur][1][e], Bn[xi % kPcNB][e],
+                                                                              FIRST && e == 0 ? zero4 : acc[xi][1], 0, 0, 0);
+                            // pin the order: the two row blocks alternate (no back-to-back dependent MFMAs) and the operand
+                            // streams keep their distances
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
+                };
+                if (!(abl & 1)) {
+                    if (s == 0) body(std::true_type{}); else body(std::false_type{});
                 }
 #ifdef NRGBD_DEV
                 const long c1 = wall_clock64();
@@ -209,15 +220,17 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
             const long c3 = wall_clock64();
 #endif
             // ---- inverse transform Y = A^T M A in registers + output + per-channel partial statistics ----
-            // lane (kq, jj): output channel co = 16 wv + jj; register r of row block m = tile 16 m + 4 kq + r
+            // lane (kq, jj): output channel co = 16 wv + jj; register r of row block m = tile 16 m + 4 kq + r, i.e. tile row
+            // 2m + (kq >> 1), tile column 4 (kq & 1) + r: the lane part of an output's address is loop-invariant (lane_yoff),
+            // the (m, r, a) part is uniform -> scalar base + 32-bit lane offset stores, no per-store address arithmetic
             const int co = tl.cg * 64 + wv * 16 + jj;
+            float* ybase = a.y + (((size_t)tl.n * a.H + tl.y0 + tl.py) * a.W + tl.x0 + tl.px) * a.Cout + tl.cg * 64 + wv * 16;
+            const bool inside = tl.y0 + tl.py + DIL * (kPcTH - 1) < a.H && tl.x0 + tl.px + DIL * (kPcTW - 1) < a.W;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int tile = 16 * m + 4 * kq + r;
-                    const int ty = tile >> 3, tx = tile & 7;
                     float tr[2][4];   // t[a][xi_x] = sum_xi_y A^T[a][xi_y] M[xi_y][xi_x]
 #pragma unroll
                     for (int xx = 0; xx < 4; ++xx) {
@@ -229,11 +242,18 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                     for (int aa = 0; aa < 2; ++aa) {
                         const float o0 = (tr[aa][0] + tr[aa][1]) + tr[aa][2];
                         const float o1 = (tr[aa][1] - tr[aa][2]) - tr[aa][3];
-                        const int gy = tl.y0 + tl.py + DIL * (2 * ty + aa), gx = tl.x0 + tl.px + DIL * (2 * tx);
-                        if (gy < a.H) {
-                            float* o = a.y + (((size_t)tl.n * a.H + gy) * a.W + gx) * a.Cout + co;
-                            if (gx < a.W) { o[0] = o0; s1 += o0; s2 = __builtin_fmaf(o0, o0, s2); }
-                            if (gx + DIL < a.W) { o[(size_t)DIL * a.Cout] = o1; s1 += o1; s2 = __builtin_fmaf(o1, o1, s2); }
+                        float* o = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * r * DIL)) * a.Cout;   // uniform
+                        if (inside) {
+                            o[lane_yoff] = o0; o[lane_yoff + DIL * a.Cout] = o1;
+                            s1 += o0; s2 = __builtin_fmaf(o0, o0, s2);
+                            s1 += o1; s2 = __builtin_fmaf(o1, o1, s2);
+                        } else {
+                            const int tile = 16 * m + 4 * kq + r;
+                            const int gy = tl.y0 + tl.py + DIL * (2 * (tile >> 3) + aa), gx = tl.x0 + tl.px + DIL * (2 * (tile & 7));
+                            if (gy < a.H) {
+                                if (gx < a.W) { o[lane_yoff] = o0; s1 += o0; s2 = __builtin_fmaf(o0, o0, s2); }
+                                if (gx + DIL < a.W) { o[lane_yoff + DIL * a.Cout] = o1; s1 += o1; s2 = __builtin_fmaf(o1, o1, s2); }
+                            }
                         }
                     }
                 }
@@ -246,8 +266,6 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                     a.stats[(size_t)tl.row * (2 * a.Cout) + a.Cout + co] = s2;
                 }
             }
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) { acc[xi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[xi][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             tl = tn;
             wt = wt_next;
 #ifdef NRGBD_DEV
