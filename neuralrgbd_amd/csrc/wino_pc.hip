@@ -398,28 +398,55 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                         const f32x2 sc01 = {r.ss[0].x, r.ss[0].z}, sh01 = {r.ss[0].y, r.ss[0].w}, sc23 = {r.ss[1].x, r.ss[1].z}, sh23 = {r.ss[1].y, r.ss[1].w};
                         const f32x2 rc01 = {r.rs[0].x, r.rs[0].z}, rh01 = {r.rs[0].y, r.rs[0].w}, rc23 = {r.rs[1].x, r.rs[1].z}, rh23 = {r.rs[1].y, r.rs[1].w};
                         const bool wmat = a.mat && (KD != 3 || kd == 1) && tl.cg == 0;
+                        // Breadth-first over the 5 items — all FMAs, then all ReLUs, then all masks, then the stores — and
+                        // pinned in that order: beside the consumer's MFMA stream a VALU instruction that has to wait for
+                        // its predecessor's result loses the issue port to the next MFMA (32 cycles), an independent one
+                        // issues back to back.
+                        f32x2 lo[kPcNPF], hi[kPcNPF];
 #pragma unroll
                         for (int u = 0; u < kPcNPF; ++u) {
-                            const f32x4 x = r.pre[u];
-                            f32x2 lo = __builtin_elementwise_fma(x.lo, sc01, sh01), hi = __builtin_elementwise_fma(x.hi, sc23, sh23);
-                            if (a.x_relu) { lo.x = relu1(lo.x); lo.y = relu1(lo.y); hi.x = relu1(hi.x); hi.y = relu1(hi.y); }
-                            if constexpr (RES) {
-                                const f32x4 q = r.prer[u];
-                                f32x2 ql = __builtin_elementwise_fma(q.lo, rc01, rh01), qh = __builtin_elementwise_fma(q.hi, rc23, rh23);
-                                if (a.res_relu) { ql.x = relu1(ql.x); ql.y = relu1(ql.y); qh.x = relu1(qh.x); qh.y = relu1(qh.y); }
-                                lo = lo + ql; hi = hi + qh;
+                            lo[u] = __builtin_elementwise_fma(r.pre[u].lo, sc01, sh01);
+                            hi[u] = __builtin_elementwise_fma(r.pre[u].hi, sc23, sh23);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (a.x_relu) {
+#pragma unroll
+                            for (int u = 0; u < kPcNPF; ++u) { lo[u].x = relu1(lo[u].x); lo[u].y = relu1(lo[u].y); hi[u].x = relu1(hi[u].x); hi[u].y = relu1(hi[u].y); }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (RES) {
+                            f32x2 ql[kPcNPF], qh[kPcNPF];
+#pragma unroll
+                            for (int u = 0; u < kPcNPF; ++u) {
+                                ql[u] = __builtin_elementwise_fma(r.prer[u].lo, rc01, rh01);
+                                qh[u] = __builtin_elementwise_fma(r.prer[u].hi, rc23, rh23);
                             }
-                            // zero padding applies to the ACTIVATED tensor: out-of-image lanes (their loads read a harmless
-                            // in-tensor word) are multiplied by 0
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (a.res_relu) {
+#pragma unroll
+                                for (int u = 0; u < kPcNPF; ++u) { ql[u].x = relu1(ql[u].x); ql[u].y = relu1(ql[u].y); qh[u].x = relu1(qh[u].x); qh[u].y = relu1(qh[u].y); }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < kPcNPF; ++u) { lo[u] = lo[u] + ql[u]; hi[u] = hi[u] + qh[u]; }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        // zero padding applies to the ACTIVATED tensor: out-of-image lanes (their loads read a harmless in-tensor
+                        // word) are multiplied by 0
+#pragma unroll
+                        for (int u = 0; u < kPcNPF; ++u) {
                             const f32x2 kk = {cur_keep[u], cur_keep[u]};
-                            lo = lo * kk; hi = hi * kk;
-                            const f32x4 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+                            lo[u] = lo[u] * kk; hi[u] = hi[u] * kk;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < kPcNPF; ++u) {
+                            const f32x4 v = __builtin_shufflevector(lo[u], hi[u], 0, 1, 2, 3);
                             // the activated input is written once: by the wave that owns the pixel, at the centre tap
                             if (wmat) {
                                 if ((cur_own >> u) & 1u)
                                     *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.mat) + ((size_t)(KD == 3 ? z : 0) * plane + (size_t)(cb * kCB)) * sizeof(float) + cur_off[u]) = v;
                             }
-                            if (abl & 128) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }
                             *reinterpret_cast<f32x4*>(raw + wr_off[u]) = v;
                         }
                     }
