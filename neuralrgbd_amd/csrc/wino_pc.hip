@@ -402,52 +402,63 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                         // pinned in that order: beside the consumer's MFMA stream a VALU instruction that has to wait for
                         // its predecessor's result loses the issue port to the next MFMA (32 cycles), an independent one
                         // issues back to back.
-                        f32x2 lo[kPcNPF], hi[kPcNPF];
+                        // (with a residual operand: in two groups of items, which keeps the phase inside the register budget)
+                        auto group = [&](auto u0_tag, auto u1_tag) __attribute__((always_inline)) {
+                            constexpr int U0 = decltype(u0_tag)::value, U1 = decltype(u1_tag)::value, NU = U1 - U0;
+                            f32x2 lo[NU], hi[NU];
 #pragma unroll
-                        for (int u = 0; u < kPcNPF; ++u) {
-                            lo[u] = __builtin_elementwise_fma(r.pre[u].lo, sc01, sh01);
-                            hi[u] = __builtin_elementwise_fma(r.pre[u].hi, sc23, sh23);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (a.x_relu) {
+                            for (int i = 0; i < NU; ++i) {
+                                lo[i] = __builtin_elementwise_fma(r.pre[U0 + i].lo, sc01, sh01);
+                                hi[i] = __builtin_elementwise_fma(r.pre[U0 + i].hi, sc23, sh23);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (a.x_relu) {
 #pragma unroll
-                            for (int u = 0; u < kPcNPF; ++u) { lo[u].x = relu1(lo[u].x); lo[u].y = relu1(lo[u].y); hi[u].x = relu1(hi[u].x); hi[u].y = relu1(hi[u].y); }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                                for (int i = 0; i < NU; ++i) { lo[i].x = relu1(lo[i].x); lo[i].y = relu1(lo[i].y); hi[i].x = relu1(hi[i].x); hi[i].y = relu1(hi[i].y); }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (RES) {
+                                f32x2 ql[NU], qh[NU];
+#pragma unroll
+                                for (int i = 0; i < NU; ++i) {
+                                    ql[i] = __builtin_elementwise_fma(r.prer[U0 + i].lo, rc01, rh01);
+                                    qh[i] = __builtin_elementwise_fma(r.prer[U0 + i].hi, rc23, rh23);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (a.res_relu) {
+#pragma unroll
+                                    for (int i = 0; i < NU; ++i) { ql[i].x = relu1(ql[i].x); ql[i].y = relu1(ql[i].y); qh[i].x = relu1(qh[i].x); qh[i].y = relu1(qh[i].y); }
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int i = 0; i < NU; ++i) { lo[i] = lo[i] + ql[i]; hi[i] = hi[i] + qh[i]; }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            // zero padding applies to the ACTIVATED tensor: out-of-image lanes (their loads read a harmless
+                            // in-tensor word) are multiplied by 0
+#pragma unroll
+                            for (int i = 0; i < NU; ++i) {
+                                const f32x2 kk = {cur_keep[U0 + i], cur_keep[U0 + i]};
+                                lo[i] = lo[i] * kk; hi[i] = hi[i] * kk;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < NU; ++i) {
+                                const int u = U0 + i;
+                                const f32x4 v = __builtin_shufflevector(lo[i], hi[i], 0, 1, 2, 3);
+                                // the activated input is written once: by the wave that owns the pixel, at the centre tap
+                                if (wmat) {
+                                    if ((cur_own >> u) & 1u)
+                                        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.mat) + ((size_t)(KD == 3 ? z : 0) * plane + (size_t)(cb * kCB)) * sizeof(float) + cur_off[u]) = v;
+                                }
+                                *reinterpret_cast<f32x4*>(raw + wr_off[u]) = v;
+                            }
+                        };
                         if constexpr (RES) {
-                            f32x2 ql[kPcNPF], qh[kPcNPF];
-#pragma unroll
-                            for (int u = 0; u < kPcNPF; ++u) {
-                                ql[u] = __builtin_elementwise_fma(r.prer[u].lo, rc01, rh01);
-                                qh[u] = __builtin_elementwise_fma(r.prer[u].hi, rc23, rh23);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (a.res_relu) {
-#pragma unroll
-                                for (int u = 0; u < kPcNPF; ++u) { ql[u].x = relu1(ql[u].x); ql[u].y = relu1(ql[u].y); qh[u].x = relu1(qh[u].x); qh[u].y = relu1(qh[u].y); }
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int u = 0; u < kPcNPF; ++u) { lo[u] = lo[u] + ql[u]; hi[u] = hi[u] + qh[u]; }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        // zero padding applies to the ACTIVATED tensor: out-of-image lanes (their loads read a harmless in-tensor
-                        // word) are multiplied by 0
-#pragma unroll
-                        for (int u = 0; u < kPcNPF; ++u) {
-                            const f32x2 kk = {cur_keep[u], cur_keep[u]};
-                            lo[u] = lo[u] * kk; hi[u] = hi[u] * kk;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < kPcNPF; ++u) {
-                            const f32x4 v = __builtin_shufflevector(lo[u], hi[u], 0, 1, 2, 3);
-                            // the activated input is written once: by the wave that owns the pixel, at the centre tap
-                            if (wmat) {
-                                if ((cur_own >> u) & 1u)
-                                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.mat) + ((size_t)(KD == 3 ? z : 0) * plane + (size_t)(cb * kCB)) * sizeof(float) + cur_off[u]) = v;
-                            }
-                            *reinterpret_cast<f32x4*>(raw + wr_off[u]) = v;
+                            group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+                            group(std::integral_constant<int, 3>{}, std::integral_constant<int, kPcNPF>{});
+                        } else {
+                            group(std::integral_constant<int, 0>{}, std::integral_constant<int, kPcNPF>{});
                         }
                     }
                 }
