@@ -312,10 +312,14 @@ int nrgbd_conv3d_wino_f32(const float* x, const float* x_ss, int x_relu, const f
  * epilogue as nrgbd_conv3d_3x3x3_f32 / nrgbd_conv2d_3x3_f32.
  *   w_wino: [Cout/64][stage = cb*kd + depth tap][16 transform points][4 waves][64 lanes][4] floats, U = G g G^T over (ky, kx)
  *           (host mirror: neuralrgbd_amd/ops.py::conv_wino_pack)
- *   stats  [nrgbd_conv_wino_tiles(N,H,W,dilation)][2*Cout] partial (sum, sum of squares) rows for nrgbd_bn_finalize /
- *           nrgbd_bn3d_finalize, or NULL
+ *   stats  [2*Cout][nrgbd_conv_wino_tiles(N,H,W,dilation)] (COLUMN-major: a channel's per-tile partial sums, then its partial
+ *           sums of squares, each one contiguous run) for nrgbd_bn_finalize_cm, or NULL
+ * nrgbd_bn_finalize_cm — the BatchNorm finaliser (same contract as nrgbd_bn_finalize: models/basic.py:13-51 BatchNorm2d/3d with
+ *   batch statistics, running-statistics side effect) for column-major partials [2C][rows]
  */
 int nrgbd_conv_wino_tiles(int N, int H, int W, int dilation);
+int nrgbd_bn_finalize_cm(const float* stats, int rows, int C, long count, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream);
 int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
                         int res_relu, float* materialized, const float* w_wino, float* y, float* stats,
                         int N, int H, int W, int Cin, int Cout, int kd, int dilation, void* stream);

@@ -49,10 +49,11 @@ struct WinoPcArgs {
     float* mat;           // materialised input act(x) + act(res), or null
     const float* wp;      // Winograd-domain weights [Cout/64][stage = cb*KD + kd][16 xi][4 waves][64 lanes][4]
     float* y;             // [N][H][W][Cout] raw convolution output
-    float* stats;         // [spatial tiles][2*Cout]: per-channel sum and sum of squares of y, or null
+    float* stats;         // [2*Cout][spatial tiles] (column-major): per-channel sum and sum of squares of y per tile, or null
     int x_relu, res_relu;
     int N, H, W, Cin, Cout;
     int ntiles;           // spatial tiles x Cout/64
+    int rows;             // spatial tiles (statistics rows)
     int abl;              // developer ablation bits, honoured by -DNRGBD_DEV builds only: 1 = producers only, 2 = consumers only,
                           // 4 = no transform, 8 = no publish, 16 / 32 = s_setprio 2 for the consumers / producers
 };
@@ -262,8 +263,9 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                 s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
                 s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
                 if (kq == 0) {
-                    a.stats[(size_t)tl.row * (2 * a.Cout) + co] = s1;
-                    a.stats[(size_t)tl.row * (2 * a.Cout) + a.Cout + co] = s2;
+                    // column-major partials [2 Cout][rows]: nrgbd_bn_finalize_cm reads a channel's partials as one run
+                    a.stats[(size_t)co * a.rows + tl.row] = s1;
+                    a.stats[(size_t)(a.Cout + co) * a.rows + tl.row] = s2;
                 }
             }
             tl = tn;
@@ -536,7 +538,55 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     }
 }
 
+// Column-major partials [2C][rows] -> BatchNorm (scale, shift) [C][2] + running statistics: workgroup c reads channel c's two
+// runs of `rows` floats coalesced (the row-major finaliser walks a 4-byte column of a [rows][2C] matrix: 64 us per K-Net layer
+// at 24,576 rows; this one 6 us), fixed-order fp64 tree.
+__global__ __launch_bounds__(256) void bn_finalize_cm_kernel(const float* __restrict__ stats, int rows, int C, double count,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, float momentum, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float* __restrict__ ss) {
+    __shared__ double sh[2][256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float* p1 = stats + (size_t)c * rows;
+    const float* p2 = stats + (size_t)(C + c) * rows;
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = tid; g < rows; g += 256) { s1 += (double)p1[g]; s2 += (double)p2[g]; }
+    sh[0][tid] = s1; sh[1][tid] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double mean = sh[0][0] / count;
+        double var = sh[1][0] / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        ss[2 * c] = sc;
+        ss[2 * c + 1] = beta[c] - (float)mean * sc;
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
 }  // namespace nrgbd
+
+extern "C" int nrgbd_bn_finalize_cm(const float* stats, int rows, int C, long count, const float* gamma, const float* beta,
+                                    float eps, float momentum, float* running_mean, float* running_var, float* scale_shift,
+                                    void* stream) {
+    using namespace nrgbd;
+    if (!stats || !gamma || !beta || !scale_shift) return NRGBD_E_NULL;
+    if (rows <= 0 || count <= 0 || C <= 0) return NRGBD_E_SHAPE;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return NRGBD_E_NULL;
+    hipLaunchKernelGGL(bn_finalize_cm_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, rows, C, (double)count, gamma,
+                       beta, eps, momentum, running_mean, running_var, scale_shift);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
 
 extern "C" int nrgbd_conv_wino_tiles(int N, int H, int W, int dilation) {
     using namespace nrgbd;
@@ -556,7 +606,7 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     const int rows = nrgbd_conv_wino_tiles(N, H, W, dilation);
     const long nt = (long)rows * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
-    WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt,
+    WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt, rows,
                  dev_env_int("NRGBD_WINO_ABL")};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);

@@ -120,17 +120,19 @@ class _PackedWeightsMixin(object):
         return out
 
 
-def _bn_scale_shift(bn, stats, count):
+def _bn_scale_shift(bn, stats, count, cm=False):
     """(scale, shift) [C,2] of a BatchNorm: batch statistics from the conv epilogue's partials in train mode (the
-    reference never leaves it) incl. the running-statistics side effect; running statistics in eval mode."""
+    reference never leaves it) incl. the running-statistics side effect; running statistics in eval mode.
+    cm: the partials are column-major [2C, rows] (the Winograd kernel's), not [workgroups, 2C]."""
     from . import ops
     if bn.training or not bn.track_running_stats:
         upd = bn.training and bn.track_running_stats
         if upd:
             bn.num_batches_tracked += 1
         momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-        return ops.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, momentum,
-                               bn.running_mean if upd else None, bn.running_var if upd else None)
+        fin = ops.bn_finalize_cm if cm else ops.bn_finalize
+        return fin(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, momentum,
+                   bn.running_mean if upd else None, bn.running_var if upd else None)
     sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
     return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 
@@ -315,7 +317,7 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
             z = z.permute(0, 2, 3, 1).contiguous()
             st = ops.nhwc_stats(z) if _needs_stats(bn) else None
         count = z.shape[0] * z.shape[1] * z.shape[2]
-        return _Act(z, _bn_scale_shift(bn, st, count), relu), mat
+        return _Act(z, _bn_scale_shift(bn, st, count, cm=wino), relu), mat
 
     def _pointwise_bn_cl(self, seq, m, stride=1):
         """1x1 Sequential(conv, bn) on a materialised channels-last tensor: a plain GEMM (vendor BLAS) + statistics."""
@@ -496,9 +498,10 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
             cache[("wino", id(conv))] = hit
         return hit[1]
 
-    def _bn_scale_shift(self, bn, stats, count):
+    def _bn_scale_shift(self, bn, stats, count, cm=False):
         """(scale, shift) of a BatchNorm3d: batch statistics in train mode (the reference never leaves it,
-        SURVEY §0.2) incl. the running-statistics side effect; running statistics in eval mode."""
+        SURVEY §0.2) incl. the running-statistics side effect; running statistics in eval mode.
+        cm: column-major partials [128, tiles] of the Winograd kernel instead of [workgroups, 128]."""
         from . import ops
         use_batch = bn.training or not bn.track_running_stats
         if use_batch:
@@ -506,8 +509,9 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
             if upd:
                 bn.num_batches_tracked += 1
             momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            return ops.bn3d_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, momentum,
-                                     bn.running_mean if upd else None, bn.running_var if upd else None)
+            fin = ops.bn_finalize_cm if cm else ops.bn3d_finalize
+            return fin(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, momentum,
+                       bn.running_mean if upd else None, bn.running_var if upd else None)
         sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 
@@ -539,16 +543,18 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
 
         def run(i, x, x_ss, x_relu, res=None, materialize=False):
             conv, bn = L[i]
+            cm = False
             if wino and conv.in_channels == 64 and mode == "wino1":
                 y, st, mat = ops.conv3d_wino(x, self._packed_wino(conv), x_ss=x_ss, x_relu=x_relu, res=res,
                                              materialize=materialize, want_stats=need_stats(bn))
             elif wino and conv.in_channels == 64:
                 y, st, mat = ops.conv_wino(x, _packed_wino(self, conv), 64, 3, x_ss=x_ss, x_relu=x_relu, res=res,
                                            materialize=materialize, want_stats=need_stats(bn))
+                cm = True
             else:
                 y, st, mat = ops.conv3d(x, self._packed(conv), x_ss=x_ss, x_relu=x_relu, res=res,
                                         materialize=materialize, want_stats=need_stats(bn))
-            return y, self._bn_scale_shift(bn, st, count), mat
+            return y, self._bn_scale_shift(bn, st, count, cm=cm), mat
 
         z, ss, _ = run(0, vol, None, False)                       # dres0.0
         z, ss, _ = run(1, z, ss, True)                            # dres0.2   in = relu(bn(z))

@@ -363,11 +363,12 @@ def conv_wino_tiles(N, H, W, dilation=1):
 def conv_wino(x, w_wino, Cout, kd, dilation=1, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False,
               materialize=False, want_stats=True):
     """Channels-last 3x3(x3) stride-1 convolution in the Winograd domain on the producer/consumer kernel (wino_pc.hip):
-    x [N,H,W,Cin] -> (y [N,H,W,Cout], stats [tiles, 2*Cout] | None, materialized | None); kd = 3 convolves over N as depth."""
+    x [N,H,W,Cin] -> (y [N,H,W,Cout], stats [2*Cout, tiles] (column-major partials for bn_finalize_cm) | None,
+    materialized | None); kd = 3 convolves over N as depth."""
     x = _need(x, "x")
     N, H, W, Cin = x.shape
     y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
-    stats = torch.empty((conv_wino_tiles(N, H, W, dilation), 2 * Cout), dtype=torch.float32, device=x.device) if want_stats else None
+    stats = torch.empty((2 * Cout, conv_wino_tiles(N, H, W, dilation)), dtype=torch.float32, device=x.device) if want_stats else None
     mat = torch.empty_like(x) if materialize else None
     if res is not None:
         res = _need(res, "res", x.shape)
@@ -508,6 +509,18 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, run
         rc = _lib.load().nrgbd_bn_finalize(_p(stats), stats.shape[0], C, int(count), _p(gamma), _p(beta), float(eps),
                                            float(momentum), _p(running_mean), _p(running_var), _p(ss), _stream(stats))
     _lib.check(rc, "nrgbd_bn_finalize")
+    return ss
+
+
+def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    """Column-major per-tile partials [2C, rows] (conv_wino) -> scale_shift [C,2]; updates the running statistics in place."""
+    stats = _need(stats, "stats")
+    C = stats.shape[0] // 2
+    ss = torch.empty((C, 2), dtype=torch.float32, device=stats.device)
+    with torch.cuda.device(stats.device):
+        rc = _lib.load().nrgbd_bn_finalize_cm(_p(stats), stats.shape[1], C, int(count), _p(gamma), _p(beta), float(eps),
+                                              float(momentum), _p(running_mean), _p(running_var), _p(ss), _stream(stats))
+    _lib.check(rc, "nrgbd_bn_finalize_cm")
     return ss
 
 

@@ -162,8 +162,8 @@ def test_conv_wino_pc_2d_plain_vs_torch(N, H, W, Cin, Cout, dil):
     scale = want.abs().max().item()
     print("[parity] conv_wino_pc 2d N%d %dx%d %d->%d dil%d max|d vs fp64|=%.3e (|y|max %.2f)" % (N, H, W, Cin, Cout, dil, err, scale))
     assert err < 2e-5 * max(1.0, scale)
-    assert stats.shape == (ops.conv_wino_tiles(N, H, W, dil), 2 * Cout)
-    s = stats.double().sum(0)
+    assert stats.shape == (2 * Cout, ops.conv_wino_tiles(N, H, W, dil))
+    s = stats.double().sum(1)
     assert torch.allclose(s[:Cout], want.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
     assert torch.allclose(s[Cout:], (want ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
 
@@ -186,5 +186,20 @@ def test_conv_wino_pc_2d_fused_prologue_materialize(Cin, Cout, dil):
     err = (y.permute(0, 3, 1, 2) - want).abs().max().item()
     print("[parity] conv_wino_pc 2d fused %d->%d dil%d max|d|=%.3e" % (Cin, Cout, dil, err))
     assert err < 1e-4 * max(1.0, want.abs().max().item())
-    s = stats.double().sum(0)
+    s = stats.double().sum(1)
     assert torch.allclose(s[:Cout], want.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+def test_bn_finalize_cm_matches_row_major_finaliser():
+    """Column-major partials (the Winograd kernel's) through nrgbd_bn_finalize_cm == the same partials through nrgbd_bn_finalize."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rows, C = 777, 128
+    st = torch.randn(rows, 2 * C, generator=g).to(DEV)
+    st[:, C:] = st[:, C:].abs() * 50 + 5.0
+    gamma, beta = torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV)
+    rm1, rv1 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    a = ops.bn_finalize(st, 12345, gamma, beta, 1e-5, 0.1, rm1, rv1)
+    b = ops.bn_finalize_cm(st.t().contiguous(), 12345, gamma, beta, 1e-5, 0.1, rm2, rv2)
+    assert torch.equal(a, b) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)

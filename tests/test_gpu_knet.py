@@ -204,8 +204,8 @@ def test_conv_wino_pc_3d_plain_vs_torch(D, H, W):
     scale = want.abs().max().item()
     print("[parity] conv_wino_pc 3d %dx%dx%d max|d vs fp64|=%.3e (|y|max %.2f)" % (D, H, W, err, scale))
     assert err < 2e-5 * max(1.0, scale)
-    assert stats.shape == (ops.conv_wino_tiles(D, H, W), 128)
-    s = stats.double().sum(0)
+    assert stats.shape == (128, ops.conv_wino_tiles(D, H, W))
+    s = stats.double().sum(1)
     assert torch.allclose(s[:64], want.sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
     assert torch.allclose(s[64:], (want ** 2).sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
     y1, _, _ = ops.conv3d_wino(_cl(x), ops.conv3d_wino_pack(w))
