@@ -367,6 +367,20 @@ int nrgbd_rnet_pack(const float* dpv_log, const float* feat, int feat_planar, fl
  * nrgbd_nhwc_act: y[p*ldy + c] = act(x*s+t) [+ act(res*s'+t')] — the loader's prologue as a stand-alone pass, for
  *   consumers that are not the conv kernel (pooling, the SPP concat of psm_submodule.py:160-163, the 1x1 head).
  */
+/*
+ * nrgbd_conv2d_taps_f32 — the trunk's remaining convolution forms on the same kernel (round 2: no vendor convolution is left in
+ * the feature CNN), with the prologue (x_ss, x_relu) and the statistics epilogue of nrgbd_conv2d_3x3_f32:
+ *   taps = 1: 1x1 convolution (psm_submodule.py:40-43,63-66 shortcut of layer2 / layer3, :103-117 SPP branch convs, :122 head);
+ *             w_packed = nrgbd_conv_pack_weights(w [Cout][Cin][1], taps = 1); Cout in {32, 64, 128}
+ *   taps = 4: the 2x2 window {y-1, y} x {x-1, x} — a stride-2, pad-1 3x3 convolution (psm_submodule.py:90 firstconv, :120
+ *             layer2's first conv) on the space-to-depth image of its input (nrgbd_space_to_depth2), weights re-indexed by the
+ *             host mirror (neuralrgbd_amd/ops.py::conv_s2_pack); Cout in {32, 64}
+ * nrgbd_space_to_depth2: y [N][H/2][W/2][Cp] with y[.][(py*2+px)*C + c] = x[2y+py][2x+px][c], channels >= 4C zero;
+ *   x is [N][C][H][W] (nchw = 1: the input image) or [N][H][W][C]; H, W even, Cp >= 4C.
+ */
+int nrgbd_conv2d_taps_f32(const float* x, const float* x_ss, int x_relu, const float* w_packed, float* y, float* stats,
+                          int N, int H, int W, int Cin, int Cout, int taps, void* stream);
+int nrgbd_space_to_depth2(const float* x, int nchw, float* y, int N, int C, int H, int W, int Cp, void* stream);
 int nrgbd_conv2d_workgroups(int N, int H, int W);
 int nrgbd_conv_pack_weights(const float* w, float* w_packed, int Cin, int Cout, int taps, void* stream);
 int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_relu,

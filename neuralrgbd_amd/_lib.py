@@ -53,6 +53,8 @@ SIGNATURES = {
     "nrgbd_avgpool8": (_I, [_P, _P, _I, _I, _I, _P]),
     "nrgbd_bias_act_nchw": (_I, [_P, _P, _F, _I, _I, _L, _P]),
     "nrgbd_conv2d_workgroups": (_I, [_I, _I, _I]),
+    "nrgbd_conv2d_taps_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_space_to_depth2": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _P]),
     "nrgbd_conv2d_3x3_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv2d_rnet_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
     constexpr int NF = COUT / 32;                        // 32-column output fragments
     constexpr int G4 = kCB / 8;                          // k-groups per block (4 k-steps = 8 channels each)
     constexpr int NSTEP = NTAP * G4;
-    static_assert(NTAP == 9 || (NTAP == 4 && DIL == 1), "2x2 taps are the stride-2 transposed-conv phases");
-    static_assert(2 + (RES ? 2 : 1) * NPF <= NSTEP, "prefetch does not fit the step loop");
+    static_assert(NTAP == 9 || ((NTAP == 4 || NTAP == 1) && DIL == 1), "2x2 taps: transposed-conv phases / stride-2 convs on a "
+                                                                         "space-to-depth input; 1 tap: 1x1 convolutions");
+    // the next block's words are fetched one per step where the step loop is long enough, otherwise all in step 0 (1)
+    constexpr bool PF_SPREAD = 2 + (RES ? 2 : 1) * NPF <= NSTEP;
+    static_assert(PF_SPREAD || NSTEP >= 2, "prefetch does not fit the step loop");
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [HALO][kSV]; reused for the statistics
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -77,7 +80,8 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
     row_to_yx(i, dy, px);
     const int wy = wv * 4;
     // m = 0, tap (0,0); m = 1 is two rows further.  A transposed-conv phase starts its 2x2 window at halo offset (pa, pb).
-    const int hv0 = (wy + dy) * HS + px + (NTAP == 4 ? a.pa * HS + a.pb : 0);
+    // a 1x1 convolution reads the centre of the (unused) one-pixel halo
+    const int hv0 = (wy + dy) * HS + px + (NTAP == 4 ? a.pa * HS + a.pb : NTAP == 1 ? HS + 1 : 0);
 
     f32x16 acc[2][NF];
 #pragma unroll
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
         const f32x4* wb = reinterpret_cast<const f32x4*>(a.wp) + (size_t)cblk * (G4 * NF * 64) + lane;
         // B runs BD steps ahead of its use: vmcnt retires in order, so a B load also waits for the (HBM-latency)
         // prefetch words issued before it; A (LDS) runs one step ahead
-        constexpr int BD = COUT <= 64 ? 3 : 1, NB = BD + 1;
+        constexpr int BD = NTAP == 1 ? 1 : (COUT <= 64 ? 3 : 1), NB = BD + 1;
         f32x4 Bn[NB][NF], An[2][2];
 #pragma unroll
         for (int b = 0; b < BD; ++b) {
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
             const int cur = s & 1, nxt = cur ^ 1;
             if (s + 1 < NSTEP) {  // A operands of step s+1
                 const int tap = (s + 1) / G4, g = (s + 1) % G4;
-                const int voff = NTAP == 9 ? ((tap / 3) * HS + (tap % 3)) * DIL : (tap >> 1) * HS + (tap & 1);  // tap offset in halo pixels
+                const int voff = NTAP == 9 ? ((tap / 3) * HS + (tap % 3)) * DIL : NTAP == 4 ? (tap >> 1) * HS + (tap & 1) : 0;  // tap offset in halo pixels
                 int h0 = hv0;
                 asm volatile("" : "+v"(h0));  // keep the swizzled addresses out of long-lived registers
                 An[nxt][0] = *reinterpret_cast<const f32x4*>(lds + lds_slot(h0 + voff, khalf * 2 + g));
@@ -187,14 +191,27 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
                 for (int f = 0; f < NF; ++f) Bn[(s + BD) % NB][f] = wn[f * 64];
             }
             // one word of the NEXT channel block per step: x in steps 2 .. 2+NPF-1, the residual operand after it
-            if constexpr (!RES) {   // registers to spare: a scalar branch skips the loads in the last block
-                if (s >= 2 && s < 2 + NPF && live) pre[s - 2] = *reinterpret_cast<const f32x4*>(a.x + pf_off[s - 2] + nb);
-            } else {
-                if (s >= 2 && s < 2 + NPF) pre[s - 2] = *reinterpret_cast<const f32x4*>(a.x + ((pf_off[s - 2] + nb) & live));
-            }
-            if constexpr (RES) {
-                if (s >= 2 + NPF && s < 2 + 2 * NPF)
-                    prer[s - 2 - NPF] = *reinterpret_cast<const f32x4*>(a.res + ((pf_off[s - 2 - NPF] + nb) & live));
+            if constexpr (PF_SPREAD) {
+                if constexpr (!RES) {   // registers to spare: a scalar branch skips the loads in the last block
+                    if (s >= 2 && s < 2 + NPF && live) pre[s - 2] = *reinterpret_cast<const f32x4*>(a.x + pf_off[s - 2] + nb);
+                } else {
+                    if (s >= 2 && s < 2 + NPF) pre[s - 2] = *reinterpret_cast<const f32x4*>(a.x + ((pf_off[s - 2] + nb) & live));
+                }
+                if constexpr (RES) {
+                    if (s >= 2 + NPF && s < 2 + 2 * NPF)
+                        prer[s - 2 - NPF] = *reinterpret_cast<const f32x4*>(a.res + ((pf_off[s - 2 - NPF] + nb) & live));
+                }
+            } else {   // short step loops (1x1): everything at once
+                if (s == 0) {
+#pragma unroll
+                    for (int u = 0; u < NPF; ++u) pre[u] = *reinterpret_cast<const f32x4*>(a.x + ((pf_off[u] + nb) & live));
+                }
+                if constexpr (RES) {
+                    if (s == 1) {
+#pragma unroll
+                        for (int u = 0; u < NPF; ++u) prer[u] = *reinterpret_cast<const f32x4*>(a.res + ((pf_off[u] + nb) & live));
+                    }
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -430,7 +447,75 @@ static void launch_conv2d_ex(const Conv2dArgs& a, int nwg, hipStream_t st) {
     hipLaunchKernelGGL((conv2d_mfma_kernel<COUT, 1, false, NTAP, EPI>), dim3(nwg), dim3(256), lds, st, a);
 }
 
+// Small-tap forms with the trunk's prologue / statistics epilogue: NTAP = 1 (1x1 convolution) or 4 (2x2 window ending at the
+// pixel: a stride-2 3x3 convolution on the space-to-depth image of its input)
+template <int COUT, int NTAP>
+static void launch_conv2d_taps(const Conv2dArgs& a, int nwg, hipStream_t st) {
+    constexpr int HS = kT2 + 2;
+    const size_t lds = (size_t)HS * HS * kSV * sizeof(float);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<COUT, 1, false, NTAP, 0>), dim3(nwg), dim3(256), lds, st, a);
+}
+
+// y[n][y][x][(py*2+px)*C + c] = x[n][2y+py][2x+px][c] (channels >= 4C zero): with it a stride-2 3x3 convolution is a 2x2-tap
+// stride-1 convolution (taps dy, dx in {-1, 0}) whose weights are the 3x3 weights re-indexed (row 2y+ky-1: ky = 0 -> dy = -1,
+// py = 1; ky = 1 -> dy = 0, py = 0; ky = 2 -> dy = 0, py = 1), the other (tap, phase) pairs zero.
+__global__ __launch_bounds__(256) void space_to_depth2_kernel(const float* __restrict__ x, int nchw, float* __restrict__ y,
+                                                              int N, int C, int H, int W, int Cp) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * Cp;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cp = (int)(idx % Cp);
+    long t = idx / Cp;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float v = 0.f;
+    if (cp < 4 * C) {
+        const int ph = cp / C, c = cp - ph * C;
+        const int yi = 2 * yo + (ph >> 1), xi = 2 * xo + (ph & 1);
+        v = nchw ? x[(((size_t)n * C + c) * H + yi) * W + xi] : x[(((size_t)n * H + yi) * W + xi) * C + c];
+    }
+    y[idx] = v;
+}
+
 }  // namespace nrgbd
+
+extern "C" int nrgbd_space_to_depth2(const float* x, int nchw, float* y, int N, int C, int H, int W, int Cp, void* stream) {
+    using namespace nrgbd;
+    if (!x || !y) return NRGBD_E_NULL;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cp < 4 * C) return NRGBD_E_SHAPE;
+    const long total = (long)N * (H / 2) * (W / 2) * Cp;
+    hipLaunchKernelGGL(space_to_depth2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, nchw,
+                       y, N, C, H, W, Cp);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+extern "C" int nrgbd_conv2d_taps_f32(const float* x, const float* x_ss, int x_relu, const float* w_packed, float* y,
+                                     float* stats, int N, int H, int W, int Cin, int Cout, int taps, void* stream) {
+    using namespace nrgbd;
+    if (!x || !w_packed || !y) return NRGBD_E_NULL;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB) return NRGBD_E_SHAPE;
+    if ((long)N * H * W * Cin >= (1L << 32)) return NRGBD_E_SHAPE;
+    if (taps != 1 && taps != 4) return NRGBD_E_ARG;
+    Conv2dArgs a{x, x_ss, nullptr, nullptr, nullptr, w_packed, nullptr, y, stats, x_relu, 0, 0, N, H, W, Cin,
+                 0, Cout, 0, Cout, 0, 0, 0, nullptr};
+    const int nwg = ceil_div(W, kT2) * ceil_div(H, kT2) * N;
+    hipStream_t st = (hipStream_t)stream;
+    if (taps == 1) {
+        if (Cout == 32) launch_conv2d_taps<32, 1>(a, nwg, st);
+        else if (Cout == 64) launch_conv2d_taps<64, 1>(a, nwg, st);
+        else if (Cout == 128) launch_conv2d_taps<128, 1>(a, nwg, st);
+        else return NRGBD_E_SHAPE;
+    } else {
+        if (Cout == 32) launch_conv2d_taps<32, 4>(a, nwg, st);
+        else if (Cout == 64) launch_conv2d_taps<64, 4>(a, nwg, st);
+        else return NRGBD_E_SHAPE;
+    }
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
 
 extern "C" int nrgbd_conv2d_workgroups(int N, int H, int W) {
     using namespace nrgbd;
@@ -441,7 +526,7 @@ extern "C" int nrgbd_conv2d_workgroups(int N, int H, int W) {
 extern "C" int nrgbd_conv_pack_weights(const float* w, float* wp, int Cin, int Cout, int taps, void* stream) {
     using namespace nrgbd;
     if (!w || !wp) return NRGBD_E_NULL;
-    if (Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 32 || (taps != 9 && taps != 27 && taps != 4)) return NRGBD_E_SHAPE;
+    if (Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 32 || (taps != 9 && taps != 27 && taps != 4 && taps != 1)) return NRGBD_E_SHAPE;
     const long total = (long)taps * Cin * Cout;
     hipLaunchKernelGGL(conv_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        w, wp, Cin, Cout, taps);

@@ -97,6 +97,25 @@ def _packed_wino(owner, conv):
     return hit[1]
 
 
+def _packed_s2(owner, conv):
+    """Weight stream of a stride-2 3x3 conv in its space-to-depth form (ops.conv_s2_pack), re-packed only when the weight changes."""
+    from . import ops
+    cache = owner.__dict__.setdefault("_wp_cache", {})
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device), "s2")
+    hit = cache.get(("s2", id(conv)))
+    if hit is None or hit[0] != key:
+        hit = (key, ops.conv_s2_pack(w.detach().contiguous()))
+        cache[("s2", id(conv))] = hit
+    return hit[1]
+
+
+def _small_convs_native():
+    """The stride-2 3x3 and the 1x1 convolutions of the trunk on csrc/conv2d.hip (round 2); NRGBD_CNN_SMALL=vendor keeps MIOpen /
+    rocBLAS for them (A/B)."""
+    return os.environ.get("NRGBD_CNN_SMALL", "native") != "vendor"
+
+
 def invalidate_packed_weights(module):
     """Drop every cached packed-weight stream below `module`.  The caches are keyed on (data_ptr, tensor version), which an
     update through `.data` (`w.data.copy_()`, EMA, manual surgery) does not bump — call this after such an update.
@@ -313,9 +332,15 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         else:
             mat = a.z if (a.ss is None and a.r is None and not a.relu) else \
                 ops.nhwc_act(a.z, a.ss, a.relu, a.r, a.r_ss, a.r_relu)
-            z = F.conv2d(mat.permute(0, 3, 1, 2), conv.weight, None, conv.stride, conv.padding, conv.dilation)
-            z = z.permute(0, 2, 3, 1).contiguous()
-            st = ops.nhwc_stats(z) if _needs_stats(bn) else None
+            s2 = (conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and d == 1
+                  and mat.shape[1] % 2 == 0 and mat.shape[2] % 2 == 0 and conv.out_channels in (32, 64) and _small_convs_native())
+            if s2:   # stride 2 = a 2x2-window convolution on the space-to-depth image of the input
+                z, st = ops.conv2d_taps(ops.space_to_depth2(mat), _packed_s2(self, conv), conv.out_channels, 4,
+                                        want_stats=_needs_stats(bn))
+            else:
+                z = F.conv2d(mat.permute(0, 3, 1, 2), conv.weight, None, conv.stride, conv.padding, conv.dilation)
+                z = z.permute(0, 2, 3, 1).contiguous()
+                st = ops.nhwc_stats(z) if _needs_stats(bn) else None
         count = z.shape[0] * z.shape[1] * z.shape[2]
         return _Act(z, _bn_scale_shift(bn, st, count, cm=wino), relu), mat
 
@@ -326,8 +351,11 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         if stride != 1:
             m = m[:, ::stride, ::stride, :]
         N, H, W, C = m.shape
-        z = torch.mm(m.reshape(-1, C), conv.weight.view(conv.out_channels, C).t()).view(N, H, W, conv.out_channels)
-        st = ops.nhwc_stats(z) if _needs_stats(bn) else None
+        if C % 16 == 0 and conv.out_channels in (32, 64, 128) and _small_convs_native():
+            z, st = ops.conv2d_taps(m.contiguous(), _packed_weights(self, conv), conv.out_channels, 1, want_stats=_needs_stats(bn))
+        else:
+            z = torch.mm(m.reshape(-1, C), conv.weight.view(conv.out_channels, C).t()).view(N, H, W, conv.out_channels)
+            st = ops.nhwc_stats(z) if _needs_stats(bn) else None
         return _Act(z, _bn_scale_shift(bn, st, N * H * W), False)
 
     def _block_cl(self, blk, a):
@@ -355,8 +383,14 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         layer's loader).  The three stride-2 / 3-channel convs and the 1x1 convs (GEMMs) use the vendor libraries."""
         from . import ops
         conv, bn = self.firstconv[0]
-        z = F.conv2d(x, conv.weight, None, conv.stride, conv.padding).permute(0, 2, 3, 1).contiguous()
-        a = _Act(z, _bn_scale_shift(bn, ops.nhwc_stats(z) if _needs_stats(bn) else None, z.numel() // z.shape[-1]), True)
+        if x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and _small_convs_native():
+            # 3 -> 32, stride 2: the image as a 12(+4)-channel space-to-depth tensor, then a 2x2-window convolution
+            z, st = ops.conv2d_taps(ops.space_to_depth2(x.contiguous(), nchw=True), _packed_s2(self, conv), conv.out_channels, 4,
+                                    want_stats=_needs_stats(bn))
+        else:
+            z = F.conv2d(x, conv.weight, None, conv.stride, conv.padding).permute(0, 2, 3, 1).contiguous()
+            st = ops.nhwc_stats(z) if _needs_stats(bn) else None
+        a = _Act(z, _bn_scale_shift(bn, st, z.numel() // z.shape[-1]), True)
         for i in (2, 4):
             a, _ = self._conv_bn_cl(self.firstconv[i], a, relu=True)
         for blk in self.layer1:
@@ -389,15 +423,22 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         pyramid = []
         for i in (4, 3, 2, 1):
             branch = getattr(self, "branch%d" % i)
-            y = _conv_bn_act(pools[self.SPP_WINDOWS[i - 1]].contiguous(), branch[1], relu=True)   # tiny maps
-            y = F.interpolate(y.contiguous(memory_format=torch.channels_last), size=(h, w), mode="bilinear",
-                              align_corners=True)
+            pool = pools[self.SPP_WINDOWS[i - 1]]
+            if _small_convs_native():                                      # 1x1 conv + BatchNorm + ReLU on the tiny map
+                pb = self._pointwise_bn_cl(branch[1], pool.permute(0, 2, 3, 1).contiguous())
+                y = ops.nhwc_act(pb.z, pb.ss, True).permute(0, 3, 1, 2)    # channels-last memory, NCHW view
+            else:
+                y = _conv_bn_act(pool.contiguous(), branch[1], relu=True).contiguous(memory_format=torch.channels_last)
+            y = F.interpolate(y, size=(h, w), mode="bilinear", align_corners=True)
             pyramid.append(y.permute(0, 2, 3, 1))                          # channels-last in memory already
         cat = torch.cat([quarter, deep] + pyramid, dim=3)                  # [N,h,w,320]
         y, _ = self._conv_bn_cl(self.lastconv[0], _Act(cat), relu=True)
-        y = ops.nhwc_act(y.z, y.ss, True)
         head = self.lastconv[2]
-        feat = torch.mm(y.view(-1, y.shape[-1]), head.weight.view(head.out_channels, -1).t()).view(N, h, w, head.out_channels)
+        if head.out_channels in (32, 64, 128) and _small_convs_native():   # 1x1 head; BatchNorm + ReLU of lastconv[0] in its loader
+            feat, _ = ops.conv2d_taps(y.z, _packed_weights(self, head), head.out_channels, 1, x_ss=y.ss, x_relu=True, want_stats=False)
+        else:
+            y = ops.nhwc_act(y.z, y.ss, True)
+            feat = torch.mm(y.view(-1, y.shape[-1]), head.weight.view(head.out_channels, -1).t()).view(N, h, w, head.out_channels)
         return half, feat
 
     def forward(self, x):

@@ -459,6 +459,51 @@ def conv2d(x, w_packed, cout, dilation=1, x_ss=None, x_relu=False, res=None, res
     return y, stats, mat
 
 
+def conv_s2_pack(w, cp=None):
+    """Weights of a stride-2, pad-1 3x3 convolution [Cout, C, 3, 3] -> packed stream of the equivalent 2x2-tap convolution on the
+    space-to-depth input (nrgbd_conv2d_taps_f32, taps = 4): w2[co, (py*2+px)*C + c, ty, tx] with (ty, py) -> ky: (0,1) -> 0,
+    (1,0) -> 1, (1,1) -> 2 and the same for x; (0,0) does not occur (zero).  cp = padded channel count (multiple of 16)."""
+    w = _need(w, "w")
+    cout, c = w.shape[:2]
+    cp = cp or -(-4 * c // 16) * 16
+    w2 = torch.zeros((cout, cp, 2, 2), dtype=torch.float32, device=w.device)
+    kmap = {(0, 1): 0, (1, 0): 1, (1, 1): 2}
+    for (ty, py), ky in kmap.items():
+        for (tx, px), kx in kmap.items():
+            ph = py * 2 + px
+            w2[:, ph * c:(ph + 1) * c, ty, tx] = w[:, :, ky, kx]
+    return conv_pack_weights(w2)
+
+
+def space_to_depth2(x, nchw=False, cp=None):
+    """[N,C,H,W] (nchw) or [N,H,W,C] -> [N,H/2,W/2,cp] with channel (py*2+px)*C + c = x[2y+py, 2x+px, c], zero-padded to cp."""
+    x = _need(x, "x")
+    if nchw:
+        N, C, H, W = x.shape
+    else:
+        N, H, W, C = x.shape
+    cp = cp or -(-4 * C // 16) * 16
+    y = torch.empty((N, H // 2, W // 2, cp), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_space_to_depth2(_p(x), int(nchw), _p(y), N, C, H, W, cp, _stream(x))
+    _lib.check(rc, "nrgbd_space_to_depth2")
+    return y
+
+
+def conv2d_taps(x, w_packed, cout, taps, x_ss=None, x_relu=False, want_stats=True):
+    """1x1 convolution (taps = 1) or the 2x2-window form of a stride-2 3x3 convolution on a space-to-depth input (taps = 4) on
+    the matrix-core kernel, with the trunk's prologue and statistics epilogue: x [N,H,W,Cin] -> (y [N,H,W,cout], stats | None)."""
+    x = _need(x, "x")
+    N, H, W, Cin = x.shape
+    y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
+    stats = torch.empty((conv2d_workgroups(N, H, W), 2 * cout), dtype=torch.float32, device=x.device) if want_stats else None
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv2d_taps_f32(_p(x), _p(x_ss), int(x_relu), _p(w_packed), _p(y), _p(stats), N, H, W, Cin,
+                                                int(cout), int(taps), _stream(x))
+    _lib.check(rc, "nrgbd_conv2d_taps_f32")
+    return y, stats
+
+
 def conv2d_rnet(x, w_packed, cout, bias=None, lrelu=True, out=None, ldy=None, ycoff=0, cout_valid=None, mode=0, pa=0, pb=0):
     """R-Net layer on the matrix cores (nrgbd_conv2d_rnet_f32).  x [N,H,W,Cin] channels-last.
     mode 0: 3x3 conv -> out[..., ycoff:ycoff+cout_valid] of a [N,H,W,ldy] buffer (allocated [N,H,W,cout_valid] if None);

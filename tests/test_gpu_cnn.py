@@ -203,3 +203,41 @@ def test_bn_finalize_cm_matches_row_major_finaliser():
     a = ops.bn_finalize(st, 12345, gamma, beta, 1e-5, 0.1, rm1, rv1)
     b = ops.bn_finalize_cm(st.t().contiguous(), 12345, gamma, beta, 1e-5, 0.1, rm2, rv2)
     assert torch.equal(a, b) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
+
+
+# ----------------------------------------------------------------------------- the trunk's stride-2 and 1x1 convolutions (conv2d.hip)
+@pytest.mark.parametrize("N,H,W,C,Cout,nchw", [(2, 32, 48, 3, 32, True), (1, 64, 96, 32, 64, False), (3, 18, 34, 3, 32, True)])
+def test_conv_stride2_via_space_to_depth_vs_torch(N, H, W, C, Cout, nchw):
+    """Stride-2 pad-1 3x3 convolution (psm_submodule.py:90,120) = 2x2-window convolution on the space-to-depth input."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(H + C)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * 0.1).to(DEV)
+    want = F.conv2d(x.double(), w.double(), stride=2, padding=1)
+    s2d = ops.space_to_depth2(x if nchw else _cl(x), nchw=nchw)
+    assert s2d.shape == (N, H // 2, W // 2, -(-4 * C // 16) * 16)
+    y, stats = ops.conv2d_taps(s2d, ops.conv_s2_pack(w), Cout, 4)
+    err = (y.permute(0, 3, 1, 2).double() - want).abs().max().item()
+    print("[parity] conv stride 2 (s2d) N%d %dx%d %d->%d max|d vs fp64|=%.3e (|y|max %.2f)" % (N, H, W, C, Cout, err, want.abs().max().item()))
+    assert err < 2e-5 * max(1.0, want.abs().max().item())
+    s = stats.double().sum(0)
+    assert torch.allclose(s[:Cout], want.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[Cout:], (want ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(5, 24, 32, 128, 32), (2, 3, 4, 128, 32), (2, 33, 47, 64, 128), (1, 40, 56, 32, 64), (1, 20, 20, 128, 64)])
+def test_conv_1x1_vs_torch(N, H, W, Cin, Cout):
+    """1x1 convolutions of the trunk (shortcuts, SPP branches, head) on the matrix-core kernel, with the loader prologue."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(H * 7 + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    ss = torch.randn(Cin, 2, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1).to(DEV)
+    inp = torch.relu(x * ss[:, 0].view(1, -1, 1, 1) + ss[:, 1].view(1, -1, 1, 1))
+    want = F.conv2d(inp.double(), w.double())
+    y, stats = ops.conv2d_taps(_cl(x), ops.conv_pack_weights(w), Cout, 1, x_ss=ss, x_relu=True)
+    err = (y.permute(0, 3, 1, 2).double() - want).abs().max().item()
+    print("[parity] conv 1x1 N%d %dx%d %d->%d max|d vs fp64|=%.3e (|y|max %.2f)" % (N, H, W, Cin, Cout, err, want.abs().max().item()))
+    assert err < 2e-5 * max(1.0, want.abs().max().item())
+    s = stats.double().sum(0)
+    assert torch.allclose(s[:Cout], want.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
