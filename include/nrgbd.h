@@ -318,6 +318,8 @@ int nrgbd_conv3d_wino_f32(const float* x, const float* x_ss, int x_relu, const f
  *   batch statistics, running-statistics side effect) for column-major partials [2C][rows]
  */
 int nrgbd_conv_wino_tiles(int N, int H, int W, int dilation);
+/* w [Cout][Cin][kd][3][3] (torch layout) -> w_wino [Cout*Cin*kd*16] floats in the order described above (on the device) */
+int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int Cout, int kd, void* stream);
 int nrgbd_bn_finalize_cm(const float* stats, int rows, int C, long count, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream);
 int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,

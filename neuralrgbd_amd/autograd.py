@@ -64,15 +64,22 @@ class DepthWarp(torch.autograd.Function):
 
 class Conv3dCL(torch.autograd.Function):
     """3x3x3 convolution (stride 1, padding 1, no bias, 64 outputs) on channels-last activations, both directions on
-    the fp32 matrix cores: forward = csrc/conv3d.hip; data gradient = the same kernel on the output gradient with
-    transposed + flipped weights; weight gradient = csrc/conv3d_wgrad.hip.
+    the fp32 matrix cores: forward = csrc/wino_pc.hip (64 -> 64 layers, Winograd domain) / csrc/conv3d.hip; data gradient = the
+    same kernel on the output gradient with transposed + flipped weights; weight gradient = csrc/conv3d_wgrad.hip.
 
     x [D,H,W,Cin] (Cin in {16, 64}), w [64,Cin,3,3,3] -> y [D,H,W,64].
     """
 
     @staticmethod
+    def _conv(x, w):
+        """y = conv(x, w): the Winograd-domain kernel (wino_pc.hip) for the 64 -> 64 layers, the direct kernel otherwise."""
+        if w.shape[0] == 64 and w.shape[1] == 64:
+            return ops.conv_wino(x, ops.conv_wino_pack(w), 64, 3, want_stats=False)[0]
+        return ops.conv3d(x, ops.conv3d_pack_weights(w.contiguous()), want_stats=False)[0]
+
+    @staticmethod
     def forward(ctx, x, w):
-        y, _, _ = ops.conv3d(x.contiguous(), ops.conv3d_pack_weights(w.contiguous()), want_stats=False)
+        y = Conv3dCL._conv(x.contiguous(), w)
         ctx.save_for_backward(x, w)
         return y
 
@@ -88,7 +95,7 @@ class Conv3dCL(torch.autograd.Function):
             wt = w.transpose(0, 1).flip(2, 3, 4)                      # [Cin, 64, 3,3,3]: correlation with the flipped kernel
             if cin < 64:                                              # the kernel produces 64 outputs: pad, then slice
                 wt = torch.cat((wt, wt.new_zeros(64 - cin, 64, 3, 3, 3)), dim=0)
-            gx, _, _ = ops.conv3d(gy, ops.conv3d_pack_weights(wt.contiguous()), want_stats=False)
+            gx = Conv3dCL._conv(gy, wt.contiguous())
             if cin < 64:
                 gx = gx[..., :cin].contiguous()
         return gx, gw

@@ -349,6 +349,19 @@ def conv_wino_pack(w):
     if w.dim() != 5 or tuple(w.shape[3:]) != (3, 3) or w.shape[2] not in (1, 3) or w.shape[0] % 64 or w.shape[1] % 16:
         raise ValueError("conv_wino_pack expects [Cout%%64, Cin%%16, (3,) 3, 3], got %s" % (tuple(w.shape),))
     Cout, Cin, KD = w.shape[:3]
+    wp = torch.empty(Cout * Cin * KD * 16, dtype=torch.float32, device=w.device)
+    wc = w.detach().contiguous()
+    with torch.cuda.device(w.device):
+        rc = _lib.load().nrgbd_conv_wino_pack(_p(wc), _p(wp), Cin, Cout, KD, _stream(w))
+    _lib.check(rc, "nrgbd_conv_wino_pack")
+    return wp
+
+
+def conv_wino_pack_reference(w):
+    """The same stream through torch (einsum in float64): what the device packer is tested against."""
+    if w.dim() == 4:
+        w = w[:, :, None]
+    Cout, Cin, KD = w.shape[:3]
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
     U = torch.einsum("ay,ockyx,bx->ockab", G, w.detach().double(), G).reshape(Cout, Cin, KD, 16)   # [co, ci, kd, xi]
     U = U.reshape(Cout // 64, 4, 16, Cin // 16, 4, 4, KD, 16)   # co -> (cg, wave, j); ci -> (cb, kq, e)

@@ -234,3 +234,14 @@ def test_conv_wino_pc_3d_fused_prologue_and_materialize():
     assert (y2.permute(3, 0, 1, 2) - F.conv3d(act2[None], w, padding=1)[0]).abs().max().item() < 2e-4
     y3, _, _ = ops.conv_wino(_cl(x), wp, 64, 3, x_ss=ss, res=_cl(r))
     assert torch.equal(y2, y3)                                  # deterministic
+
+
+def test_conv_wino_pack_device_vs_einsum():
+    """nrgbd_conv_wino_pack (device, float64 inside) == the torch einsum reference, bit for bit, for every form in use."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for shape in ((64, 64, 3, 3, 3), (128, 320, 3, 3), (64, 32, 3, 3), (128, 128, 3, 3)):
+        w = torch.randn(*shape, generator=g).to(DEV)
+        a, b = ops.conv_wino_pack(w), ops.conv_wino_pack_reference(w)
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 1e-7 * b.abs().max().item(), shape
