@@ -318,8 +318,10 @@ int nrgbd_conv3d_wino_f32(const float* x, const float* x_ss, int x_relu, const f
  *   batch statistics, running-statistics side effect) for column-major partials [2C][rows]
  */
 int nrgbd_conv_wino_tiles(int N, int H, int W, int dilation);
-/* w [Cout][Cin][kd][3][3] (torch layout) -> w_wino [Cout*Cin*kd*16] floats in the order described above (on the device) */
-int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int Cout, int kd, void* stream);
+/* w [Cout][Cin][kd][3][3] (torch layout) -> w_wino [Cout*Cin*kd*16] floats in the order described above (on the device).
+ * transposed = 1: the DATA-GRADIENT weights of w [Cin][Cout][kd][3][3] (roles of the channel axes swapped, every tap flipped),
+ * i.e. what the same kernel needs to turn dL/dy into dL/dx — without materialising w.transpose(0,1).flip(...) first. */
+int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int Cout, int kd, int transposed, void* stream);
 int nrgbd_bn_finalize_cm(const float* stats, int rows, int C, long count, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream);
 int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
@@ -383,6 +385,19 @@ int nrgbd_rnet_pack(const float* dpv_log, const float* feat, int feat_planar, fl
 int nrgbd_conv2d_taps_f32(const float* x, const float* x_ss, int x_relu, const float* w_packed, float* y, float* stats,
                           int N, int H, int W, int Cin, int Cout, int taps, void* stream);
 int nrgbd_space_to_depth2(const float* x, int nchw, float* y, int N, int C, int H, int W, int Cp, void* stream);
+/*
+ * nrgbd_conv2d_wgrad_f32 — weight gradient of a 3x3 stride-1 convolution (padding = dilation in {1, 2}) on channels-last
+ * activations, on the fp32 matrix cores (training: train_utils/train_KVNet.py:103-153 back-propagating through
+ * models/psm_submodule.py:10-16,31-50 and models/Refine.py:51-107):
+ *   dw [Cout][Cin][3][3] = sum over (n, y, x) of gy[n][y][x][co] * x[n][y+(ky-1)d][x+(kx-1)d][ci]
+ * x [N][H][W][Cin], gy [N][H][W][Cout]; Cin % 16 == 0, Cout % 16 == 0.
+ * partial: workspace of ceil(Cout/64) * ceil(Cin/64) * nrgbd_conv2d_wgrad_workgroups(N,H,W,Cin,Cout) * 9*64*64 floats (per-workgroup
+ * partial sums, reduced in a fixed order: bitwise reproducible).  The data gradient of the same convolution is the forward
+ * kernel on gy with the transposed, flipped weights.
+ */
+int nrgbd_conv2d_wgrad_workgroups(int N, int H, int W, int Cin, int Cout);
+int nrgbd_conv2d_wgrad_f32(const float* x, const float* gy, float* partial, float* dw, int N, int H, int W, int Cin, int Cout,
+                           int dilation, void* stream);
 int nrgbd_conv2d_workgroups(int N, int H, int W);
 int nrgbd_conv_pack_weights(const float* w, float* w_packed, int Cin, int Cout, int taps, void* stream);
 int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_relu,

@@ -43,7 +43,7 @@ SIGNATURES = {
     "nrgbd_conv3d_wino_workgroups": (_I, [_I, _I, _I]),
     "nrgbd_conv3d_wino_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "nrgbd_conv_wino_tiles": (_I, [_I, _I, _I, _I]),
-    "nrgbd_conv_wino_pack": (_I, [_P, _P, _I, _I, _I, _P]),
+    "nrgbd_conv_wino_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "nrgbd_bn_finalize_cm": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P]),
     "nrgbd_conv_wino_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv3d_wgrad_workgroups": (_I, []),
@@ -54,6 +54,8 @@ SIGNATURES = {
     "nrgbd_avgpool8": (_I, [_P, _P, _I, _I, _I, _P]),
     "nrgbd_bias_act_nchw": (_I, [_P, _P, _F, _I, _I, _L, _P]),
     "nrgbd_conv2d_workgroups": (_I, [_I, _I, _I]),
+    "nrgbd_conv2d_wgrad_workgroups": (_I, [_I, _I, _I, _I, _I]),
+    "nrgbd_conv2d_wgrad_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv2d_taps_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_space_to_depth2": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _P]),

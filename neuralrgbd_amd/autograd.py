@@ -71,10 +71,18 @@ class Conv3dCL(torch.autograd.Function):
     """
 
     @staticmethod
-    def _conv(x, w):
-        """y = conv(x, w): the Winograd-domain kernel (wino_pc.hip) for the 64 -> 64 layers, the direct kernel otherwise."""
+    def _conv(x, w, transposed=False):
+        """y = conv(x, w) (transposed: with w's data-gradient weights): the Winograd-domain kernel (wino_pc.hip) for the 64 -> 64
+        layers, the direct kernel otherwise."""
         if w.shape[0] == 64 and w.shape[1] == 64:
-            return ops.conv_wino(x, ops.conv_wino_pack(w), 64, 3, want_stats=False)[0]
+            return ops.conv_wino(x, ops.conv_wino_pack(w, transposed), 64, 3, want_stats=False)[0]
+        if transposed:
+            cin = w.shape[1]
+            wt = w.transpose(0, 1).flip(2, 3, 4)                      # [Cin, 64, 3,3,3]: correlation with the flipped kernel
+            if cin < 64:                                              # the kernel produces 64 outputs: pad, then slice
+                wt = torch.cat((wt, wt.new_zeros(64 - cin, 64, 3, 3, 3)), dim=0)
+            gx = ops.conv3d(x, ops.conv3d_pack_weights(wt.contiguous()), want_stats=False)[0]
+            return gx[..., :cin].contiguous() if cin < 64 else gx
         return ops.conv3d(x, ops.conv3d_pack_weights(w.contiguous()), want_stats=False)[0]
 
     @staticmethod
@@ -91,11 +99,71 @@ class Conv3dCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = ops.conv3d_wgrad(x.contiguous(), gy)
         if ctx.needs_input_grad[0]:
-            cin = w.shape[1]
-            wt = w.transpose(0, 1).flip(2, 3, 4)                      # [Cin, 64, 3,3,3]: correlation with the flipped kernel
-            if cin < 64:                                              # the kernel produces 64 outputs: pad, then slice
-                wt = torch.cat((wt, wt.new_zeros(64 - cin, 64, 3, 3, 3)), dim=0)
-            gx = Conv3dCL._conv(gy, wt.contiguous())
-            if cin < 64:
-                gx = gx[..., :cin].contiguous()
+            gx = Conv3dCL._conv(gy, w, transposed=True)
         return gx, gw
+
+
+class Conv2dCL(torch.autograd.Function):
+    """3x3 convolution (stride 1, padding = dilation, no bias) of the feature CNN / R-Net under autograd, all three directions
+    on the hand-written matrix-core kernels (models/psm_submodule.py:10-16, models/m_submodule.py:18-27 in training,
+    train_utils/train_KVNet.py:103-153):
+        forward        csrc/wino_pc.hip (Winograd domain; Cin % 32 == 0, Cout % 64 == 0) or csrc/conv2d.hip (direct)
+        data gradient  the same kernels on the output gradient with the transposed + flipped weights
+        weight grad.   csrc/conv2d_wgrad.hip
+    x is an NCHW tensor, ideally in channels_last memory format (then the NHWC views the kernels work on are free); the result
+    is an NCHW view of channels-last memory, so a trunk built from this op stays in that format.
+    """
+
+    DIRECT = {(32, 1), (64, 1), (96, 1), (128, 1), (128, 2)}    # (Cout, dilation) instantiated in conv2d.hip
+
+    @staticmethod
+    def eligible(cin, cout, dil):
+        """Forward, data gradient (roles of Cin / Cout swapped) and weight gradient all have a kernel."""
+        def fwd(ci, co):
+            return (ci % 32 == 0 and co % 64 == 0 and dil in (1, 2)) or (ci % 16 == 0 and (co, dil) in Conv2dCL.DIRECT)
+        return fwd(cin, cout) and fwd(cout, cin) and cin % 16 == 0 and cout % 16 == 0
+
+    @staticmethod
+    def _conv(x_cl, w, dil, transposed=False):
+        cout, cin = (w.shape[1], w.shape[0]) if transposed else w.shape[:2]
+        if cin % 32 == 0 and cout % 64 == 0:
+            return ops.conv_wino(x_cl, ops.conv_wino_pack(w, transposed), cout, 1, dil, want_stats=False)[0]
+        if transposed:
+            w = w.transpose(0, 1).flip(2, 3)                          # [Cin, Cout, 3, 3]: correlation with the flipped kernel
+        return ops.conv2d(x_cl, ops.conv_pack_weights(w.contiguous()), cout, dil, want_stats=False)[0]
+
+    @staticmethod
+    def forward(ctx, x, w, dil):
+        x_cl = x.permute(0, 2, 3, 1).contiguous()                 # free when x is channels_last
+        y = Conv2dCL._conv(x_cl, w, dil)
+        ctx.save_for_backward(x_cl, w)
+        ctx.dil = dil
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_cl, w = ctx.saved_tensors
+        gy_cl = gy.permute(0, 2, 3, 1).contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv2d_wgrad(x_cl, gy_cl, ctx.dil)
+        if ctx.needs_input_grad[0]:
+            gx = Conv2dCL._conv(gy_cl, w, ctx.dil, transposed=True).permute(0, 3, 1, 2)
+        return gx, gw, None
+
+
+def conv2d_module(conv, x):
+    """nn.Conv2d forward for the module (autograd) paths.  NRGBD_TRAIN_CONV=native routes every 3x3 stride-1 convolution with a
+    kernel in all three directions (CUDA, fp32, padding = dilation) through Conv2dCL; the default stays the vendor library:
+    at the 64x96 training grid the hand-written path is correct to 1e-6 but not faster — 54.1 vs 48.0 ms per iteration
+    launched from Python, 53.1 vs 51.4 ms replayed as a hipGraph (two extra launches per layer and direction for the weight
+    transforms, and weight-gradient partials whose reduction costs as much as the gradient on grids this small)."""
+    import os
+    d = conv.dilation[0]
+    if (x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (d, d) and conv.dilation == (d, d) and conv.groups == 1
+            and Conv2dCL.eligible(conv.in_channels, conv.out_channels, d)
+            and os.environ.get("NRGBD_TRAIN_CONV", "vendor") == "native"):
+        y = Conv2dCL.apply(x, conv.weight, d)
+        return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+    return conv(x)

@@ -575,7 +575,8 @@ __global__ __launch_bounds__(256) void bn_finalize_cm_kernel(const float* __rest
 
 // w [Cout][Cin][KD][3][3] -> U = G g G^T (float64, rounded once) in the kernel's B-operand order
 // [cg][stage = cb*KD + kd][xi][wave][lane = kq*16 + j][e], co = cg*64 + 16*wave + j, ci = cb*16 + 4*kq + e
-__global__ __launch_bounds__(256) void conv_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int KD) {
+__global__ __launch_bounds__(256) void conv_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int KD,
+                                                             int transposed) {
     const long total = (long)Cout * Cin * KD * 16;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -590,26 +591,27 @@ __global__ __launch_bounds__(256) void conv_wino_pack_kernel(const float* __rest
     const int cb = (int)(t % ncb);
     const int cg = (int)(t / ncb);
     const int co = cg * 64 + 16 * wave + j, ci = cb * kCB + 4 * kq + e;
-    const float* g = w + (((size_t)co * Cin + ci) * KD + kd) * 9;
+    // transposed: the stored tensor is [Cin][Cout][KD][3][3] (this kernel's ci is ITS output channel), taps flipped in every dimension
+    const float* g = transposed ? w + (((size_t)ci * Cout + co) * KD + (KD - 1 - kd)) * 9 : w + (((size_t)co * Cin + ci) * KD + kd) * 9;
     const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
     const int a = xi >> 2, b = xi & 3;
     double u = 0.0;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) u += G[a][ky] * (double)g[ky * 3 + kx] * G[b][kx];
+        for (int kx = 0; kx < 3; ++kx) u += G[a][ky] * (double)g[transposed ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx] * G[b][kx];
     wp[idx] = (float)u;
 }
 
 }  // namespace nrgbd
 
-extern "C" int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int Cout, int kd, void* stream) {
+extern "C" int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int Cout, int kd, int transposed, void* stream) {
     using namespace nrgbd;
     if (!w || !w_wino) return NRGBD_E_NULL;
     if (Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64 || (kd != 1 && kd != 3)) return NRGBD_E_SHAPE;
     const long total = (long)Cout * Cin * kd * 16;
     hipLaunchKernelGGL(conv_wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_wino,
-                       Cin, Cout, kd);
+                       Cin, Cout, kd, transposed);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -172,7 +172,11 @@ def _conv_bn_act(x, seq, relu, residual=None):
     (csrc/bn2d.hip) instead of MIOpen BN + separate ReLU + separate add.
     """
     conv, bn = seq[0], seq[1]
-    y = conv(x)
+    if torch.is_grad_enabled():
+        from .autograd import conv2d_module
+        y = conv2d_module(conv, x)           # training: forward / data gradient / weight gradient on the hand-written kernels
+    else:
+        y = conv(x)
     use_batch = bn.training or not bn.track_running_stats
     if _fused_ok(y) and use_batch:
         from . import ops
@@ -862,9 +866,13 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 and (dpv_raw.shape[2] * dpv_raw.shape[3]) % 4 == 0:
             return self._forward_fused_tail(dpv_raw, img_features)
         quarter, half, full = img_features
-        x = self.conv0_1(self.conv0(torch.cat([dpv_raw, quarter], dim=1)))
+        from .autograd import conv2d_module
+
+        def cl(m, x):   # conv2d_leakyRelu block: the convolution on the hand-written kernels where they apply
+            return F.leaky_relu(conv2d_module(m[0], x), 0.01)
+        x = cl(self.conv0_1, cl(self.conv0, torch.cat([dpv_raw, quarter], dim=1)))
         x = self.trans_conv0(x)
-        x = self.conv1_1(self.conv1(torch.cat([x, half], dim=1)))
+        x = cl(self.conv1_1, cl(self.conv1, torch.cat([x, half], dim=1)))
         x = self.trans_conv1(x)
-        x = self.conv2_2(self.conv2_1(self.conv2(torch.cat([x, full], dim=1))))
+        x = conv2d_module(self.conv2_2, cl(self.conv2_1, cl(self.conv2, torch.cat([x, full], dim=1))))
         return F.log_softmax(x, dim=1)

@@ -339,20 +339,24 @@ def conv3d_wino(x, w_wino, x_ss=None, x_relu=False, res=None, res_ss=None, res_r
     return y, stats, mat
 
 
-def conv_wino_pack(w):
+def conv_wino_pack(w, transposed=False):
     """w [Cout, Cin, 3, 3, 3] (kd = 3) or [Cout, Cin, 3, 3] (kd = 1) -> Winograd-domain B-operand stream of nrgbd_conv_wino_f32:
     U = G g G^T over (ky, kx) in float64, rounded once to fp32, laid out [cg][stage = cb*kd + depth tap][xi = 4*xi_y + xi_x]
-    [wave][lane = kq*16 + j][e] with ci = cb*16 + 4*kq + e and co = cg*64 + 16*wave + j."""
+    [wave][lane = kq*16 + j][e] with ci = cb*16 + 4*kq + e and co = cg*64 + 16*wave + j.
+    transposed: w is the FORWARD weight [Cin', Cout', ...] of a layer and the stream is the one of its data gradient (channel
+    axes swapped, taps flipped) — the kernel then maps dL/dy [.., Cin' of this call = the layer's Cout] to dL/dx."""
     w = _need(w, "w")
     if w.dim() == 4:
         w = w[:, :, None]
-    if w.dim() != 5 or tuple(w.shape[3:]) != (3, 3) or w.shape[2] not in (1, 3) or w.shape[0] % 64 or w.shape[1] % 16:
-        raise ValueError("conv_wino_pack expects [Cout%%64, Cin%%16, (3,) 3, 3], got %s" % (tuple(w.shape),))
-    Cout, Cin, KD = w.shape[:3]
+    if w.dim() != 5 or tuple(w.shape[3:]) != (3, 3) or w.shape[2] not in (1, 3):
+        raise ValueError("conv_wino_pack expects [Cout, Cin, (3,) 3, 3], got %s" % (tuple(w.shape),))
+    Cout, Cin, KD = (w.shape[1], w.shape[0], w.shape[2]) if transposed else w.shape[:3]
+    if Cout % 64 or Cin % 16:
+        raise ValueError("conv_wino_pack: Cout %% 64 and Cin %% 16 required, got Cout=%d Cin=%d" % (Cout, Cin))
     wp = torch.empty(Cout * Cin * KD * 16, dtype=torch.float32, device=w.device)
     wc = w.detach().contiguous()
     with torch.cuda.device(w.device):
-        rc = _lib.load().nrgbd_conv_wino_pack(_p(wc), _p(wp), Cin, Cout, KD, _stream(w))
+        rc = _lib.load().nrgbd_conv_wino_pack(_p(wc), _p(wp), Cin, Cout, KD, int(transposed), _stream(w))
     _lib.check(rc, "nrgbd_conv_wino_pack")
     return wp
 
@@ -515,6 +519,26 @@ def conv2d_taps(x, w_packed, cout, taps, x_ss=None, x_relu=False, want_stats=Tru
                                                 int(cout), int(taps), _stream(x))
     _lib.check(rc, "nrgbd_conv2d_taps_f32")
     return y, stats
+
+
+def conv2d_wgrad(x, gy, dilation=1):
+    """Weight gradient of the channels-last 3x3 stride-1 convolution: x [N,H,W,Cin], gy [N,H,W,Cout] -> dW [Cout,Cin,3,3]."""
+    x = _need(x, "x")
+    N, H, W, Cin = x.shape
+    gy = _need(gy, "gy")
+    Cout = gy.shape[-1]
+    if tuple(gy.shape[:3]) != (N, H, W):
+        raise ValueError("conv2d_wgrad: gy %s does not match x %s" % (tuple(gy.shape), tuple(x.shape)))
+    lib = _lib.load()
+    nwg = int(lib.nrgbd_conv2d_wgrad_workgroups(N, H, W, Cin, Cout))
+    _lib.check(min(nwg, 0), "nrgbd_conv2d_wgrad_workgroups")
+    blocks = -(-Cout // 64) * -(-Cin // 64)
+    partial = torch.empty(blocks * nwg * 9 * 64 * 64, dtype=torch.float32, device=x.device)
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.nrgbd_conv2d_wgrad_f32(_p(x), _p(gy), _p(partial), _p(dw), N, H, W, Cin, Cout, int(dilation), _stream(x))
+    _lib.check(rc, "nrgbd_conv2d_wgrad_f32")
+    return dw
 
 
 def conv2d_rnet(x, w_packed, cout, bias=None, lrelu=True, out=None, ldy=None, ycoff=0, cout_valid=None, mode=0, pa=0, pb=0):

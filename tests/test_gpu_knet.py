@@ -245,3 +245,7 @@ def test_conv_wino_pack_device_vs_einsum():
         a, b = ops.conv_wino_pack(w), ops.conv_wino_pack_reference(w)
         assert a.shape == b.shape
         assert (a - b).abs().max().item() <= 1e-7 * b.abs().max().item(), shape
+        if shape[1] % 64 == 0:             # the data-gradient stream straight from the forward weight == packing w^T flipped
+            t = ops.conv_wino_pack(w, transposed=True)
+            r = ops.conv_wino_pack_reference(w.transpose(0, 1).flip(*range(2, w.dim())).contiguous())
+            assert (t - r).abs().max().item() <= 1e-7 * r.abs().max().item(), ("transposed", shape)

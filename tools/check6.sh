@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/c6; mkdir -p $O
-timeout 1000 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 > $O/pytest.txt
-python bench.py --mode train 2>$O/bench.err | tail -1 | cut -c1-330 > $O/bench_train.txt
-python bench.py --no-cpu-baseline 2>>$O/bench.err | tail -1 | cut -c95-330 > $O/bench_B.txt
-cat $O/pytest.txt $O/bench_train.txt $O/bench_B.txt
+timeout 300 python -m pytest tests/test_gpu_train.py -m gpu -q -x -s -k "native_vs_vendor" 2>&1 | grep -E "parity|assert|Error|passed|failed" | head -8 > $O/pytest.txt
+timeout 300 python tools/bench_train.py --graph --iters 8 2>&1 | tail -2 > $O/g_native.txt
+NRGBD_TRAIN_CONV=vendor timeout 300 python tools/bench_train.py --graph --iters 8 2>&1 | tail -2 > $O/g_vendor.txt
+cat $O/pytest.txt $O/g_native.txt $O/g_vendor.txt
