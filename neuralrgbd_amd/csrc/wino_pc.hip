@@ -228,27 +228,57 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
             float* ybase = a.y + (((size_t)tl.n * a.H + tl.y0 + tl.py) * a.W + tl.x0 + tl.px) * a.Cout + tl.cg * 64 + wv * 16;
             const bool inside = tl.y0 + tl.py + DIL * (kPcTH - 1) < a.H && tl.x0 + tl.px + DIL * (kPcTW - 1) < a.W;
             float s1 = 0.f, s2 = 0.f;
+            if (inside) {
+                // interior tile: the whole inverse transform, the statistics and the stores on register PAIRS (tiles r, r+1 of a
+                // row block): v_pk_add_f32 / v_pk_fma_f32 halve the epilogue's VALU instructions; a - b is fma(b, -1, a) with
+                // an opaque -1 (same rounding; a literal would be folded into two scalar v_sub)
+                float neg1 = -1.f;
+                asm volatile("" : "+v"(neg1));
+                const f32x2 n1 = {neg1, neg1};
+                f32x2 S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < 2; ++m) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float tr[2][4];   // t[a][xi_x] = sum_xi_y A^T[a][xi_y] M[xi_y][xi_x]
+                    for (int rp = 0; rp < 2; ++rp) {
+                        f32x2 tr[2][4];   // t[a][xi_x] = sum_xi_y A^T[a][xi_y] M[xi_y][xi_x]
 #pragma unroll
-                    for (int xx = 0; xx < 4; ++xx) {
-                        const float m0 = acc[0 + xx][m][r], m1 = acc[4 + xx][m][r], m2 = acc[8 + xx][m][r], m3 = acc[12 + xx][m][r];
-                        tr[0][xx] = (m0 + m1) + m2;
-                        tr[1][xx] = (m1 - m2) - m3;
+                        for (int xx = 0; xx < 4; ++xx) {
+                            const f32x2 m0 = rp ? acc[0 + xx][m].hi : acc[0 + xx][m].lo, m1 = rp ? acc[4 + xx][m].hi : acc[4 + xx][m].lo;
+                            const f32x2 m2 = rp ? acc[8 + xx][m].hi : acc[8 + xx][m].lo, m3 = rp ? acc[12 + xx][m].hi : acc[12 + xx][m].lo;
+                            tr[0][xx] = (m0 + m1) + m2;
+                            tr[1][xx] = __builtin_elementwise_fma(m3, n1, __builtin_elementwise_fma(m2, n1, m1));   // (m1 - m2) - m3
+                        }
+#pragma unroll
+                        for (int aa = 0; aa < 2; ++aa) {
+                            const f32x2 o0 = (tr[aa][0] + tr[aa][1]) + tr[aa][2];
+                            const f32x2 o1 = __builtin_elementwise_fma(tr[aa][3], n1, __builtin_elementwise_fma(tr[aa][2], n1, tr[aa][1]));
+                            float* oa = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * (2 * rp) * DIL)) * a.Cout;       // tile r = 2 rp
+                            float* ob = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * (2 * rp + 1) * DIL)) * a.Cout;   // tile r + 1
+                            oa[lane_yoff] = o0.x; oa[lane_yoff + DIL * a.Cout] = o1.x;
+                            ob[lane_yoff] = o0.y; ob[lane_yoff + DIL * a.Cout] = o1.y;
+                            S1 = (S1 + o0) + o1;
+                            S2 = __builtin_elementwise_fma(o1, o1, __builtin_elementwise_fma(o0, o0, S2));
+                        }
                     }
+                }
+                s1 = S1.x + S1.y; s2 = S2.x + S2.y;
+            } else {
 #pragma unroll
-                    for (int aa = 0; aa < 2; ++aa) {
-                        const float o0 = (tr[aa][0] + tr[aa][1]) + tr[aa][2];
-                        const float o1 = (tr[aa][1] - tr[aa][2]) - tr[aa][3];
-                        float* o = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * r * DIL)) * a.Cout;   // uniform
-                        if (inside) {
-                            o[lane_yoff] = o0; o[lane_yoff + DIL * a.Cout] = o1;
-                            s1 += o0; s2 = __builtin_fmaf(o0, o0, s2);
-                            s1 += o1; s2 = __builtin_fmaf(o1, o1, s2);
-                        } else {
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float tr[2][4];
+#pragma unroll
+                        for (int xx = 0; xx < 4; ++xx) {
+                            const float m0 = acc[0 + xx][m][r], m1 = acc[4 + xx][m][r], m2 = acc[8 + xx][m][r], m3 = acc[12 + xx][m][r];
+                            tr[0][xx] = (m0 + m1) + m2;
+                            tr[1][xx] = (m1 - m2) - m3;
+                        }
+#pragma unroll
+                        for (int aa = 0; aa < 2; ++aa) {
+                            const float o0 = (tr[aa][0] + tr[aa][1]) + tr[aa][2];
+                            const float o1 = (tr[aa][1] - tr[aa][2]) - tr[aa][3];
+                            float* o = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * r * DIL)) * a.Cout;   // uniform
                             const int tile = 16 * m + 4 * kq + r;
                             const int gy = tl.y0 + tl.py + DIL * (2 * (tile >> 3) + aa), gx = tl.x0 + tl.px + DIL * (2 * (tile & 7));
                             if (gy < a.H) {
