@@ -7,6 +7,7 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke
 python bench.py 2>$O/bench.err | tail -1 > $O/bench_B.json
 for c in S K H; do python bench.py --config $c 2>/dev/null | tail -1 > $O/bench_$c.json; done
 python bench.py --mode train 2>/dev/null | tail -1 > $O/bench_train.json
+python bench.py --config H --steps 300 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_H_300frames.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $O/prof.log 2>&1
 find $O/prof -name "*kernel_trace.csv" -delete
