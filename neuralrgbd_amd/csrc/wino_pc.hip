@@ -12,15 +12,21 @@
 // stage in every wave: at 2 workgroups per CU the matrix pipe idles whenever both resident waves of a SIMD are in their
 // load / transform phases or wait for the first weight line after the barrier (measured: 3.36 ms per layer at the
 // 192x256x64 grid = 59 % of the Winograd-domain MFMA time).  Here the two kinds of work live in different waves:
-//   consumer wave c (0..3) = output channels 16c .. 16c+15 of ALL 16 transform points and all 32 tiles of the workgroup's
+//   consumer wave c (waves 4..7) = output channels 16c .. 16c+15 of ALL 16 transform points and all 32 tiles of the workgroup's
 //       8x16-pixel tile (128 accumulator VGPRs): per stage 16 x (2 LDS reads + 1 weight line + 8 v_mfma_f32_16x16x4_f32);
 //       weight lines (1 KB, packed per wave) run 7 steps ahead in an 8-deep register ring that continues across stages and
-//       tiles; the first A operand of the next stage is read before the stage barrier (three V buffers make that legal).
-//   producer wave p (0..3) = tile row p (8 Winograd tiles): raw rows 2p..2p+3 of the 10x18 halo of one 16-channel block
-//       global -> registers (issued one stage earlier) -> BatchNorm / ReLU / residual -> its PRIVATE 5 KB strip of LDS (no
-//       workgroup barrier: a wave's LDS operations execute in order) -> B^T d B per (tile, 16-byte word, half) -> V[q % 3].
+//       tiles; the first A operand of the next stage is read before the stage barrier (three V buffers make that legal);
+//       the first k-step of a tile takes a zero C operand (the accumulators are never cleared).
+//   producer wave p (waves 0..3: the older waves win the SIMD's VALU arbitration) = tile row p (8 Winograd tiles): raw rows
+//       2p..2p+3 of the 10x18 halo of one 16-channel block global -> registers (TWO stages ahead, two register sets, the
+//       stage's (scale, shift) with them) -> BatchNorm / ReLU / residual, packed and breadth-first -> its PRIVATE 5 KB
+//       strip of LDS (no workgroup barrier: a wave's LDS operations execute in order) -> B^T d B per (tile, 16-byte word,
+//       half) -> V[q % 3].
 //   One s_barrier per stage; the consumers never wait for data (producers are two stages ahead), the producers wait for
-//   the consumers — which is the point: the matrix pipe is the resource to keep busy.
+//   the consumers — which is the point: the matrix pipe is the resource to keep busy.  What was measured on the way
+//   (in-kernel clocks, profiles/r2_pmc_wino.txt): beside a wave that streams MFMAs a partner's VALU
+//   instruction issues about once per MFMA, a dependent one misses its slot, so the producers' code is written for
+//   instruction count and independence, not for FLOPs.
 //   Persistent: one workgroup per CU walks its share of the tile list (XCD-aware: an XCD's workgroups sweep neighbouring
 //   tiles, depth fastest, so the three slices a 3-D tile needs are shared in that XCD's L2), so a tile's epilogue and the
 //   next tile's first loads overlap with the producers' run-ahead instead of being exposed at every workgroup boundary.
