@@ -7,6 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $R/tools/bench_wino.py --config ${2:-B} --iters 2"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc1 -o p -- $CMD > $OUT/pmc1.log 2>&1 || true
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc2 -o p -- $CMD > $OUT/pmc2.log 2>&1 || true
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -o p -- $CMD > $OUT/pmc3.log 2>&1 || true
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -o p -- $CMD > $OUT/pmc4.log 2>&1 || true
 cd $R
-for k in "conv3d_wino_kernel<false>" "conv_wino_pc_kernel<3, 1, false>"; do python tools/pmc_summary.py $OUT "$k"; done > $OUT/summary.txt 2>&1
+for k in "conv3d_mfma_kernel<64, false, false>" "conv3d_wino_kernel<false>" "conv_wino_pc_kernel<3, 1, false>" "conv_wino_pc_kernel<3, 1, true>"; do python tools/pmc_summary.py $OUT "$k"; done > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
