@@ -334,6 +334,8 @@ int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu, const flo
  *   m_submodule.conv2dTranspose_leakyRelu (nn.ConvTranspose2d k4 s2 p1 + bias + LeakyReLU, :37-45)
  *                                             as four sub-pixel 2x2-tap launches (pa, pb in {0,1})   mode 1
  *   conv2_2 + F.log_softmax(dim=1) (:99-105)                                          mode 2
+ *   the four phases of a transposed convolution in ONE launch (blockIdx.y = phase; w_packed = the four phases' packed
+ *   weights back to back in the order (pa, pb) = (0,0), (0,1), (1,0), (1,1); pa / pb ignored)          mode 3
  *   the torch.cat of :88,93,98: a layer writes its cout_valid channels at channel offset ycoff of a wider
  *   channels-last pixel (pixel stride ldy floats), i.e. straight into the next layer's concat buffer.
  * x [N][H][W][Cin] channels-last, Cin % 16 == 0 (zero-padded channels carry zero weights);

@@ -81,7 +81,14 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
     const int wy = wv * 4;
     // m = 0, tap (0,0); m = 1 is two rows further.  A transposed-conv phase starts its 2x2 window at halo offset (pa, pb).
     // a 1x1 convolution reads the centre of the (unused) one-pixel halo
-    const int hv0 = (wy + dy) * HS + px + (NTAP == 4 ? a.pa * HS + a.pb : NTAP == 1 ? HS + 1 : 0);
+    // up == 2: all four sub-pixel phases of a transposed convolution in ONE launch (blockIdx.y = phase, its weights the
+    // phase's quarter of w_packed): four times the workgroups of a per-phase launch, which at the R-Net's grids fill half the chip
+    int pa = a.pa, pb = a.pb;
+    const float* wpk = a.wp;
+    if constexpr (NTAP == 4) {
+        if (a.up == 2) { pa = blockIdx.y >> 1; pb = blockIdx.y & 1; wpk += (size_t)blockIdx.y * 4 * a.Cin * COUT; }
+    }
+    const int hv0 = (wy + dy) * HS + px + (NTAP == 4 ? pa * HS + pb : NTAP == 1 ? HS + 1 : 0);
 
     f32x16 acc[2][NF];
 #pragma unroll
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
         __syncthreads();
 
         // ---- 9 taps x G4 k-groups; B operand streamed from L2 (packed: one 1 KB line per wave load) ----
-        const f32x4* wb = reinterpret_cast<const f32x4*>(a.wp) + (size_t)cblk * (G4 * NF * 64) + lane;
+        const f32x4* wb = reinterpret_cast<const f32x4*>(wpk) + (size_t)cblk * (G4 * NF * 64) + lane;
         // B runs BD steps ahead of its use: vmcnt retires in order, so a B load also waits for the (HBM-latency)
         // prefetch words issued before it; A (LDS) runs one step ahead
         constexpr int BD = NTAP == 1 ? 1 : (COUT <= 64 ? 3 : 1), NB = BD + 1;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
             row_to_yx(row, ry, rx);
             const int gy = y0 + wy + 2 * m + ry, gx = x0 + rx;
             if (gy < a.H && gx < a.W) {
-                const size_t pix = a.up ? ((size_t)n * (2 * a.H) + 2 * gy + a.pa) * (2 * a.W) + 2 * gx + a.pb
+                const size_t pix = a.up ? ((size_t)n * (2 * a.H) + 2 * gy + pa) * (2 * a.W) + 2 * gx + pb
                                         : ((size_t)n * a.H + gy) * a.W + gx;
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
@@ -441,10 +448,10 @@ static void launch_conv2d(const Conv2dArgs& a, int nwg, hipStream_t st) {
 
 // R-Net forms: no residual operand, dilation 1; NTAP = 4 (transposed-conv phase) or EPI = 1 (planar log-softmax)
 template <int COUT, int NTAP, int EPI>
-static void launch_conv2d_ex(const Conv2dArgs& a, int nwg, hipStream_t st) {
+static void launch_conv2d_ex(const Conv2dArgs& a, int nwg, hipStream_t st, int ny = 1) {
     constexpr int HS = kT2 + 2;
     const size_t lds = (size_t)HS * HS * kSV * sizeof(float);
-    hipLaunchKernelGGL((conv2d_mfma_kernel<COUT, 1, false, NTAP, EPI>), dim3(nwg), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<COUT, 1, false, NTAP, EPI>), dim3(nwg, ny), dim3(256), lds, st, a);
 }
 
 // Small-tap forms with the trunk's prologue / statistics epilogue: NTAP = 1 (1x1 convolution) or 4 (2x2 window ending at the
@@ -563,10 +570,10 @@ extern "C" int nrgbd_conv2d_rnet_f32(const float* x, const float* w_packed, cons
     if (!x || !w_packed || !y) return NRGBD_E_NULL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB) return NRGBD_E_SHAPE;
     if ((long)N * H * W * Cin >= (1L << 32)) return NRGBD_E_SHAPE;
-    if (mode < 0 || mode > 2 || (pa & ~1) || (pb & ~1)) return NRGBD_E_ARG;
+    if (mode < 0 || mode > 3 || (pa & ~1) || (pb & ~1)) return NRGBD_E_ARG;
     if (mode != 2 && (cout_valid <= 0 || cout_valid > Cout || ycoff < 0 || ldy < ycoff + cout_valid)) return NRGBD_E_SHAPE;
     Conv2dArgs a{x, nullptr, nullptr, nullptr, nullptr, w_packed, bias, y, nullptr, 0, 0, out_lrelu, N, H, W, Cin,
-                 0, ldy, ycoff, cout_valid, mode == 1 ? 1 : 0, pa, pb, mode == 2 ? y : nullptr};
+                 0, ldy, ycoff, cout_valid, mode == 1 ? 1 : (mode == 3 ? 2 : 0), pa, pb, mode == 2 ? y : nullptr};
     const int nwg = ceil_div(W, kT2) * ceil_div(H, kT2) * N;
     hipStream_t st = (hipStream_t)stream;
     if (mode == 0) {          // 3x3 convolution (+ bias, LeakyReLU), output anywhere inside a wider pixel
@@ -576,6 +583,9 @@ extern "C" int nrgbd_conv2d_rnet_f32(const float* x, const float* w_packed, cons
         else return NRGBD_E_SHAPE;
     } else if (mode == 1) {   // one phase of ConvTranspose2d(k4, s2, p1)
         if (Cout == 64) launch_conv2d_ex<64, 4, 0>(a, nwg, st);
+        else return NRGBD_E_SHAPE;
+    } else if (mode == 3) {   // all four phases, w_packed = [phase (pa, pb) = (0,0), (0,1), (1,0), (1,1)][4 taps * Cin * Cout]
+        if (Cout == 64) launch_conv2d_ex<64, 4, 0>(a, nwg, st, 4);
         else return NRGBD_E_SHAPE;
     } else {                  // last layer: bias + log_softmax over the channels, planar output
         if (Cout == 64) launch_conv2d_ex<64, 9, 1>(a, nwg, st);

@@ -795,6 +795,9 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                     wph = w[:, :, ky][:, :, :, kx].permute(1, 0, 2, 3)                # [Cout, Cin, 2, 2]
                     res[(pa, pb)] = [(ops.conv_pack_weights(wph[c0:c0 + 64].contiguous()), b[c0:c0 + 64].contiguous(), 64, c0, 64)
                                      for c0 in range(0, w.shape[1], 64)]
+            # all four phases for one launch (mode 3): per 64-column slice, the phases' streams back to back
+            res["all"] = [(torch.cat([res[(pa, pb)][i][0] for pa in (0, 1) for pb in (0, 1)]),) + res[(0, 0)][i][1:]
+                          for i in range(len(res[(0, 0)]))]
             return res
 
         val = {"conv0": conv(self.conv0), "conv0_1": conv(self.conv0_1), "t0": deconv(self.trans_conv0),
@@ -848,14 +851,12 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         x = conv(conv(x, pk["conv0"], buf["a0"]), pk["conv0_1"], buf["b0"])
         # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..D-1 of the concat buffer; features behind
         c1 = buf["c1"]
-        for (pa, pb), layer in pk["t0"].items():
-            conv(x, layer, c1, mode=1, pa=pa, pb=pb)
+        conv(x, pk["t0"]["all"], c1, mode=3)
         c1[..., D:].copy_(half.permute(0, 2, 3, 1))
         x = conv(conv(c1, pk["conv1"], buf["a1"]), pk["conv1_1"], buf["b1"])
         # full resolution: D + 3 channels in 16-aligned pixels (padding channels zero, with zero weights)
         c2 = buf["c2"]
-        for (pa, pb), layer in pk["t1"].items():
-            conv(x, layer, c2, mode=1, pa=pa, pb=pb)
+        conv(x, pk["t1"]["all"], c2, mode=3)
         c2[..., D:D + 3].copy_(full.permute(0, 2, 3, 1))
         x = conv(conv(c2, pk["conv2"], buf["g2"]), pk["conv2_1"], buf["h2"])
         wp, bias, wdt, _, _ = pk["conv2_2"][0]

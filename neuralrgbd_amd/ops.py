@@ -545,7 +545,8 @@ def conv2d_rnet(x, w_packed, cout, bias=None, lrelu=True, out=None, ldy=None, yc
     """R-Net layer on the matrix cores (nrgbd_conv2d_rnet_f32).  x [N,H,W,Cin] channels-last.
     mode 0: 3x3 conv -> out[..., ycoff:ycoff+cout_valid] of a [N,H,W,ldy] buffer (allocated [N,H,W,cout_valid] if None);
     mode 1: sub-pixel phase (pa, pb) of ConvTranspose2d(k4,s2,p1) -> the same inside a [N,2H,2W,ldy] buffer (required);
-    mode 2: conv + bias + log_softmax over the channels -> planar [N,cout,H,W]."""
+    mode 2: conv + bias + log_softmax over the channels -> planar [N,cout,H,W];
+    mode 3: all four phases of the transposed conv in one launch (w_packed = the phases' packed weights concatenated)."""
     x = _need(x, "x")
     N, H, W, Cin = x.shape
     cv = cout if cout_valid is None else cout_valid
@@ -553,8 +554,8 @@ def conv2d_rnet(x, w_packed, cout, bias=None, lrelu=True, out=None, ldy=None, yc
         out = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device)
         ldy = cout
     elif out is None:
-        if mode == 1:
-            raise ValueError("conv2d_rnet: a transposed-conv phase writes into a caller-provided [N,2H,2W,ldy] buffer")
+        if mode in (1, 3):
+            raise ValueError("conv2d_rnet: a transposed conv writes into a caller-provided [N,2H,2W,ldy] buffer")
         out = torch.empty((N, H, W, cv), dtype=torch.float32, device=x.device)
         ldy = cv
     elif ldy is None:

@@ -51,17 +51,23 @@ def test_transposed_conv_as_four_subpixel_phases(H, W, Cin):
     want = F.leaky_relu(F.conv_transpose2d(x, w, b, 2, 1), 0.01)
     xc = x.permute(0, 2, 3, 1).contiguous()
     out = torch.zeros(1, 2 * H, 2 * W, 80, device=DEV)
+    packed = []
     for pa in (0, 1):
         for pb in (0, 1):
             ky = [3, 1] if pa == 0 else [2, 0]
             kx = [3, 1] if pb == 0 else [2, 0]
             wph = w[:, :, ky][:, :, :, kx].permute(1, 0, 2, 3).contiguous()
-            ops.conv2d_rnet(xc, ops.conv_pack_weights(wph), 64, bias=b, out=out, ldy=80, ycoff=0, cout_valid=64, mode=1, pa=pa, pb=pb)
+            packed.append(ops.conv_pack_weights(wph))
+            ops.conv2d_rnet(xc, packed[-1], 64, bias=b, out=out, ldy=80, ycoff=0, cout_valid=64, mode=1, pa=pa, pb=pb)
     got = out[..., :64].permute(0, 3, 1, 2)
     err = (got - want).abs().max().item()
     print("[parity] R-Net transposed conv %d->64 %dx%d: max|d|=%.2e" % (Cin, H, W, err))
     assert err < 2e-5 * max(1.0, want.abs().max().item())
     assert bool((out[..., 64:] == 0).all())
+    # mode 3: the same four phases as ONE launch -> bit-identical
+    out3 = torch.zeros_like(out)
+    ops.conv2d_rnet(xc, torch.cat(packed), 64, bias=b, out=out3, ldy=80, ycoff=0, cout_valid=64, mode=3)
+    assert torch.equal(out3, out)
 
 
 @pytest.mark.parametrize("H,W", [(32, 48), (37, 45)])
