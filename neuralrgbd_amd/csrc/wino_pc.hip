@@ -577,19 +577,19 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
 // Column-major partials [2C][rows] -> BatchNorm (scale, shift) [C][2] + running statistics: workgroup c reads channel c's two
 // runs of `rows` floats coalesced (the row-major finaliser walks a 4-byte column of a [rows][2C] matrix: 64 us per K-Net layer
 // at 24,576 rows; this one 6 us), fixed-order fp64 tree.
-__global__ __launch_bounds__(256) void bn_finalize_cm_kernel(const float* __restrict__ stats, int rows, int C, double count,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             float eps, float momentum, float* __restrict__ running_mean,
-                                                             float* __restrict__ running_var, float* __restrict__ ss) {
-    __shared__ double sh[2][256];
+__global__ __launch_bounds__(1024) void bn_finalize_cm_kernel(const float* __restrict__ stats, int rows, int C, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float eps, float momentum, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float* __restrict__ ss) {
+    __shared__ double sh[2][1024];
     const int c = blockIdx.x, tid = threadIdx.x;
     const float* p1 = stats + (size_t)c * rows;
     const float* p2 = stats + (size_t)(C + c) * rows;
     double s1 = 0.0, s2 = 0.0;
-    for (int g = tid; g < rows; g += 256) { s1 += (double)p1[g]; s2 += (double)p2[g]; }
+    for (int g = tid; g < rows; g += 1024) { s1 += (double)p1[g]; s2 += (double)p2[g]; }
     sh[0][tid] = s1; sh[1][tid] = s2;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
         __syncthreads();
     }
@@ -659,7 +659,7 @@ extern "C" int nrgbd_bn_finalize_cm(const float* stats, int rows, int C, long co
     if (!stats || !gamma || !beta || !scale_shift) return NRGBD_E_NULL;
     if (rows <= 0 || count <= 0 || C <= 0) return NRGBD_E_SHAPE;
     if ((running_mean == nullptr) != (running_var == nullptr)) return NRGBD_E_NULL;
-    hipLaunchKernelGGL(bn_finalize_cm_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, rows, C, (double)count, gamma,
+    hipLaunchKernelGGL(bn_finalize_cm_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, stats, rows, C, (double)count, gamma,
                        beta, eps, momentum, running_mean, running_var, scale_shift);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
