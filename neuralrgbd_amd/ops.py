@@ -481,15 +481,21 @@ def conv_s2_pack(w, cp=None):
     space-to-depth input (nrgbd_conv2d_taps_f32, taps = 4): w2[co, (py*2+px)*C + c, ty, tx] with (ty, py) -> ky: (0,1) -> 0,
     (1,0) -> 1, (1,1) -> 2 and the same for x; (0,0) does not occur (zero).  cp = padded channel count (multiple of 16)."""
     w = _need(w, "w")
+    return conv_pack_weights(conv_s2_weights(w, cp))
+
+
+def conv_s2_weights(w, cp=None):
+    """The re-indexing itself (any device): w [Cout, C, 3, 3] of a stride-2, pad-1 convolution -> w2 [Cout, cp, 2, 2] of the
+    2x2-window convolution (window rows {y-1, y}, columns {x-1, x}) on the space-to-depth input."""
     cout, c = w.shape[:2]
     cp = cp or -(-4 * c // 16) * 16
-    w2 = torch.zeros((cout, cp, 2, 2), dtype=torch.float32, device=w.device)
+    w2 = torch.zeros((cout, cp, 2, 2), dtype=w.dtype, device=w.device)
     kmap = {(0, 1): 0, (1, 0): 1, (1, 1): 2}
     for (ty, py), ky in kmap.items():
         for (tx, px), kx in kmap.items():
             ph = py * 2 + px
             w2[:, ph * c:(ph + 1) * c, ty, tx] = w[:, :, ky, kx]
-    return conv_pack_weights(w2)
+    return w2
 
 
 def space_to_depth2(x, nchw=False, cp=None):

@@ -132,3 +132,27 @@ def test_division_by_the_principal_point_is_exact():
         cs.add(float(cam["intrinsic_M"][0, 2])); cs.add(float(cam["intrinsic_M"][1, 2]))
     for c in sorted(cs):
         assert co.div_const_mismatches(c, stride=7) == 0, c
+
+
+def test_stride2_conv_as_window_conv_on_space_to_depth_host_logic():
+    """ops.conv_s2_weights (the re-indexing behind nrgbd_conv2d_taps_f32, taps = 4) in plain torch on the CPU: a stride-2 pad-1 3x3
+    convolution equals the 2x2-window convolution {y-1, y} x {x-1, x} with the re-indexed weights on the space-to-depth input
+    (channel (py*2+px)*C + c = x[2y+py, 2x+px, c]) — psm_submodule.py:90,120."""
+    import torch
+    import torch.nn.functional as F
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for C, Cout, H, W in ((3, 32, 12, 20), (32, 64, 8, 10)):
+        x = torch.randn(2, C, H, W, generator=g, dtype=torch.float64)
+        w = torch.randn(Cout, C, 3, 3, generator=g, dtype=torch.float64)
+        want = F.conv2d(x, w, stride=2, padding=1)
+        w2 = ops.conv_s2_weights(w)
+        cp = w2.shape[1]
+        s2d = torch.zeros(2, cp, H // 2, W // 2, dtype=torch.float64)
+        for py in (0, 1):
+            for px in (0, 1):
+                s2d[:, (py * 2 + px) * C:(py * 2 + px + 1) * C] = x[:, :, py::2, px::2]
+        # window rows {y-1, y}, columns {x-1, x}: pad one pixel on the top / left only
+        got = F.conv2d(F.pad(s2d, (1, 0, 1, 0)), w2)
+        assert got.shape == want.shape
+        assert (got - want).abs().max().item() < 1e-12

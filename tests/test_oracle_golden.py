@@ -173,3 +173,25 @@ def test_export_epilogue_vs_reference_files():
     # truncation of (map * 1000): a last-ulp difference of the fp32 sum flips a value only when it sits on an integer
     assert (np.abs(du.astype(np.int32) - g["depth_u16"].astype(np.int32)) > 1).sum() == 0
     assert (du != g["depth_u16"]).mean() < 2e-3 and (cu != g["conf_u16"]).mean() < 2e-3
+
+
+def test_winograd_restatement_and_weight_stream_layout():
+    """oracle/wino_ref.py: F(2x2,3x3) with the kernel's matrices equals the direct convolution (float64), and the weight-stream
+    layout documented in include/nrgbd.h is what the host packer (ops.conv_wino_pack_reference, torch on the CPU) produces."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import wino_ref
+    from neuralrgbd_amd import ops
+    rng = np.random.RandomState(0)
+    x, w = rng.randn(5, 8, 12), rng.randn(7, 5, 3, 3)
+    want = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), padding=1)[0].numpy()
+    assert np.abs(wino_ref.conv2d_wino(x, w) - want).max() < 1e-12
+    for shape in ((64, 32, 3, 3), (128, 64, 3, 3, 3)):
+        wt = torch.from_numpy(rng.randn(*shape).astype(np.float32))
+        stream = ops.conv_wino_pack_reference(wt).numpy()
+        w5 = wt[:, :, None] if wt.dim() == 4 else wt
+        Cout, Cin, KD = w5.shape[:3]
+        U = np.einsum("ay,ockyx,bx->ockab", wino_ref.G, w5.numpy().astype(np.float64), wino_ref.G).reshape(Cout, Cin, KD, 16)
+        for co, ci, kd, xi in ((0, 0, 0, 0), (17, 5, KD - 1, 6), (Cout - 1, Cin - 1, 0, 15), (33, 18, KD // 2, 9)):
+            got = stream[wino_ref.packed_index(co, ci, kd, xi, Cin, KD)]
+            assert abs(got - np.float32(U[co, ci, kd, xi])) <= 1e-6 * max(1.0, abs(U[co, ci, kd, xi])), (shape, co, ci, kd, xi)
