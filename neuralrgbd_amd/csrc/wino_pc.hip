@@ -113,7 +113,7 @@ __device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-template <int KD, int DIL, bool RES>
+template <int KD, int DIL, bool RES, bool ODD = false>
 __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Vb = lds;                           // [3][16 xi][32 tiles][16]
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         setup(tl, cur_off, cur_keep, cur_own);
         Regs set0, set1;
         issue(false, 0, set0);
-        issue(false, 1, set1);               // NS is even and >= 2 (checked by the launcher)
+        issue(false, 1, set1);               // NS >= 2 (checked by the launcher)
         int qbuf = 0;
 #ifdef NRGBD_DEV
         long t_pub = 0, t_tr = 0, t_pbar = 0, t_q0 = 0, t_q1 = 0, t_q2 = 0;
@@ -551,10 +551,19 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         };
         for (int it = 0; it < count; ++it) {
             has_next = it + 1 < count;
-            for (int s = 0; s < NS; s += 2) {
-                if (s + 2 == NS && has_next) { tn = pc_decode<KD, DIL>(first + (it + 1) * step, a); setup(tn, nxt_off, nxt_keep, nxt_own); }
-                stage(s, set0);
-                stage(s + 1, set1);
+            if constexpr (!ODD) {   // stages in pairs: the register set of a stage is static
+                for (int s = 0; s < NS; s += 2) {
+                    // the book of the next tile is needed from the first refill that reaches into it (stage NS-2 refills stage 0)
+                    if (s + 2 == NS && has_next) { tn = pc_decode<KD, DIL>(first + (it + 1) * step, a); setup(tn, nxt_off, nxt_keep, nxt_own); }
+                    stage(s, set0);
+                    stage(s + 1, set1);
+                }
+            } else {                // odd stage count (16 input channels x 3 depth taps): set = parity of the running stage count
+                for (int s = 0; s < NS; ++s) {
+                    if (s + 2 == NS && has_next) { tn = pc_decode<KD, DIL>(first + (it + 1) * step, a); setup(tn, nxt_off, nxt_keep, nxt_own); }
+                    if (((unsigned)it * (unsigned)NS + (unsigned)s) & 1u) stage(s, set1);
+                    else stage(s, set0);
+                }
             }
             tl = tn;
 #pragma unroll
@@ -678,7 +687,7 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     if (!x || !w_wino || !y) return NRGBD_E_NULL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
     if ((kd != 1 && kd != 3) || (dilation != 1 && dilation != 2) || (kd == 3 && dilation != 1)) return NRGBD_E_ARG;
-    if (((Cin / kCB) * kd) & 1) return NRGBD_E_SHAPE;   // stages are produced in pairs (two register sets)
+    if ((Cin / kCB) * kd < 2) return NRGBD_E_SHAPE;      // two stages are always in flight (two register sets)
     if ((long)N * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;   // 32-bit BYTE offsets in the loader
     const int rows = nrgbd_conv_wino_tiles(N, H, W, dilation);
     const long nt = (long)rows * (Cout / 64);
@@ -701,7 +710,14 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
         if (e != hipSuccess) return (int)e;                                                                         \
         hipLaunchKernelGGL((conv_wino_pc_kernel<KD_, DIL_, RES_>), dim3(nwg), dim3(512), lds, st, a);               \
     } while (0)
-    if (kd == 3) {
+    const bool odd = (((Cin / kCB) * kd) & 1) != 0;
+    if (odd && (kd != 3 || res)) return NRGBD_E_SHAPE;   // an odd stage count is instantiated for the K-Net's first layer only
+    if (kd == 3 && odd) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<3, 1, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((conv_wino_pc_kernel<3, 1, false, true>), dim3(nwg), dim3(512), lds, st, a);
+    } else if (kd == 3) {
         if (res) NRGBD_WINO_PC_LAUNCH(3, 1, true); else NRGBD_WINO_PC_LAUNCH(3, 1, false);
     } else if (dilation == 1) {
         if (res) NRGBD_WINO_PC_LAUNCH(1, 1, true); else NRGBD_WINO_PC_LAUNCH(1, 1, false);

@@ -583,7 +583,7 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         import os
         # the ten 64 -> 64 layers in the Winograd domain (wino_pc.hip 3.0 / conv3d_wino.hip 3.3 / conv3d.hip 5.4 ms per layer at
         # config B, and closer to the float64 result than the direct kernel); NRGBD_KNET=wino1|direct select the others for A/B
-        mode = os.environ.get("NRGBD_KNET", "auto")   # auto = wino_pc.hip (generation 2) | wino1 = conv3d_wino.hip | direct
+        mode = os.environ.get("NRGBD_KNET", "auto")   # auto = wino_pc.hip | wino64 = only its 64 -> 64 layers | wino1 = conv3d_wino.hip | direct
         wino = mode != "direct"
 
         def run(i, x, x_ss, x_relu, res=None, materialize=False):
@@ -592,7 +592,8 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
             if wino and conv.in_channels == 64 and mode == "wino1":
                 y, st, mat = ops.conv3d_wino(x, self._packed_wino(conv), x_ss=x_ss, x_relu=x_relu, res=res,
                                              materialize=materialize, want_stats=need_stats(bn))
-            elif wino and conv.in_channels == 64:
+            elif wino and (conv.in_channels == 64 or (conv.in_channels == 16 and res is None and mode != "wino64")):
+                # 64 -> 64 (12 stages per tile) and the first layer 16 -> 64 (3 stages: the odd-stage-count instantiation)
                 y, st, mat = ops.conv_wino(x, _packed_wino(self, conv), 64, 3, x_ss=x_ss, x_relu=x_relu, res=res,
                                            materialize=materialize, want_stats=need_stats(bn))
                 cm = True

@@ -249,3 +249,21 @@ def test_conv_wino_pack_device_vs_einsum():
             t = ops.conv_wino_pack(w, transposed=True)
             r = ops.conv_wino_pack_reference(w.transpose(0, 1).flip(*range(2, w.dim())).contiguous())
             assert (t - r).abs().max().item() <= 1e-7 * r.abs().max().item(), ("transposed", shape)
+
+
+@pytest.mark.parametrize("D,H,W", [(4, 16, 32), (5, 13, 21), (40, 40, 72), (1, 8, 16)])
+def test_conv_wino_pc_3d_first_layer_16_channels(D, H, W):
+    """The K-Net's first layer (16 -> 64: 3 stages per tile, the odd-stage-count instantiation of the producer loop) vs
+    F.conv3d in float64; the 900-tile grid makes workgroups walk several tiles, so the register-set parity flips per tile."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(D * 100 + W)
+    x = torch.randn(16, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, 16, 3, 3, 3, generator=g) * 0.1).to(DEV)
+    want = F.conv3d(x[None].double(), w.double(), padding=1)[0]
+    y, stats, _ = ops.conv_wino(_cl(x), ops.conv_wino_pack(w), 64, 3)
+    err = (y.permute(3, 0, 1, 2).double() - want).abs().max().item()
+    print("[parity] conv_wino_pc 3d 16->64 %dx%dx%d max|d vs fp64|=%.3e (|y|max %.2f)" % (D, H, W, err, want.abs().max().item()))
+    assert err < 2e-5 * max(1.0, want.abs().max().item())
+    s = stats.double().sum(1)
+    assert torch.allclose(s[:64], want.sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[64:], (want ** 2).sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
