@@ -318,6 +318,10 @@ int nrgbd_conv3d_wino_f32(const float* x, const float* x_ss, int x_relu, const f
  *   batch statistics, running-statistics side effect) for column-major partials [2C][rows]
  */
 int nrgbd_conv_wino_tiles(int N, int H, int W, int dilation);
+/* R-Net form of the same kernel (models/m_submodule.py:18-27 conv2d_leakyRelu where Cin % 32 == 0 and Cout % 64 == 0:
+ * Refine.py:51-56 conv0 / conv0_1): y = leaky_relu(conv3x3(x) + bias, 0.01 if out_lrelu), x [N][H][W][Cin] -> y [N][H][W][Cout] */
+int nrgbd_conv_wino_rnet_f32(const float* x, const float* w_wino, const float* bias, int out_lrelu, float* y,
+                             int N, int H, int W, int Cin, int Cout, void* stream);
 /* w [Cout][Cin][kd][3][3] (torch layout) -> w_wino [Cout*Cin*kd*16] floats in the order described above (on the device).
  * transposed = 1: the DATA-GRADIENT weights of w [Cin][Cout][kd][3][3] (roles of the channel axes swapped, every tap flipped),
  * i.e. what the same kernel needs to turn dL/dy into dL/dx — without materialising w.transpose(0,1).flip(...) first. */

@@ -60,6 +60,8 @@ struct WinoPcArgs {
     int N, H, W, Cin, Cout;
     int ntiles;           // spatial tiles x Cout/64
     int rows;             // spatial tiles (statistics rows)
+    const float* bias;    // EPI = 1 (R-Net form): [Cout] added to the output, then LeakyReLU(0.01) if out_lrelu; no statistics
+    int out_lrelu;
     int abl;              // developer ablation bits, honoured by -DNRGBD_DEV builds only: 1 = producers only, 2 = consumers only,
                           // 4 = no transform, 8 = no publish, 16 / 32 = s_setprio 2 for the consumers / producers
 };
@@ -113,7 +115,7 @@ __device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
-template <int KD, int DIL, bool RES, bool ODD = false>
+template <int KD, int DIL, bool RES, bool ODD = false, int EPI = 0>
 __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Vb = lds;                           // [3][16 xi][32 tiles][16]
@@ -234,6 +236,8 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
             float* ybase = a.y + (((size_t)tl.n * a.H + tl.y0 + tl.py) * a.W + tl.x0 + tl.px) * a.Cout + tl.cg * 64 + wv * 16;
             const bool inside = tl.y0 + tl.py + DIL * (kPcTH - 1) < a.H && tl.x0 + tl.px + DIL * (kPcTW - 1) < a.W;
             float s1 = 0.f, s2 = 0.f;
+            float bval = 0.f;
+            if constexpr (EPI == 1) bval = a.bias ? a.bias[co] : 0.f;
             if (inside) {
                 // interior tile: the whole inverse transform, the statistics and the stores on register PAIRS (tiles r, r+1 of a
                 // row block): v_pk_add_f32 / v_pk_fma_f32 halve the epilogue's VALU instructions; a - b is fma(b, -1, a) with
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                 float neg1 = -1.f;
                 asm volatile("" : "+v"(neg1));
                 const f32x2 n1 = {neg1, neg1};
+                const f32x2 bias2 = {bval, bval};
                 f32x2 S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
@@ -256,8 +261,15 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                         }
 #pragma unroll
                         for (int aa = 0; aa < 2; ++aa) {
-                            const f32x2 o0 = (tr[aa][0] + tr[aa][1]) + tr[aa][2];
-                            const f32x2 o1 = __builtin_elementwise_fma(tr[aa][3], n1, __builtin_elementwise_fma(tr[aa][2], n1, tr[aa][1]));
+                            f32x2 o0 = (tr[aa][0] + tr[aa][1]) + tr[aa][2];
+                            f32x2 o1 = __builtin_elementwise_fma(tr[aa][3], n1, __builtin_elementwise_fma(tr[aa][2], n1, tr[aa][1]));
+                            if constexpr (EPI == 1) {   // m_submodule.py:18-27: bias, LeakyReLU(0.01) = max(z, 0.01 z)
+                                o0 = o0 + bias2; o1 = o1 + bias2;
+                                if (a.out_lrelu) {
+                                    const f32x2 sl = {0.01f, 0.01f};
+                                    o0 = __builtin_elementwise_max(o0, o0 * sl); o1 = __builtin_elementwise_max(o1, o1 * sl);
+                                }
+                            }
                             float* oa = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * (2 * rp) * DIL)) * a.Cout;       // tile r = 2 rp
                             float* ob = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * (2 * rp + 1) * DIL)) * a.Cout;   // tile r + 1
                             oa[lane_yoff] = o0.x; oa[lane_yoff + DIL * a.Cout] = o1.x;
@@ -282,8 +294,12 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                         }
 #pragma unroll
                         for (int aa = 0; aa < 2; ++aa) {
-                            const float o0 = (tr[aa][0] + tr[aa][1]) + tr[aa][2];
-                            const float o1 = (tr[aa][1] - tr[aa][2]) - tr[aa][3];
+                            float o0 = (tr[aa][0] + tr[aa][1]) + tr[aa][2];
+                            float o1 = (tr[aa][1] - tr[aa][2]) - tr[aa][3];
+                            if constexpr (EPI == 1) {
+                                o0 += bval; o1 += bval;
+                                if (a.out_lrelu) { o0 = fmaxf(o0, 0.01f * o0); o1 = fmaxf(o1, 0.01f * o1); }
+                            }
                             float* o = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * r * DIL)) * a.Cout;   // uniform
                             const int tile = 16 * m + 4 * kq + r;
                             const int gy = tl.y0 + tl.py + DIL * (2 * (tile >> 3) + aa), gx = tl.x0 + tl.px + DIL * (2 * (tile & 7));
@@ -693,7 +709,7 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     const long nt = (long)rows * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
     WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt, rows,
-                 dev_env_int("NRGBD_WINO_ABL")};
+                 nullptr, 0, dev_env_int("NRGBD_WINO_ABL")};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -725,6 +741,34 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
         if (res) NRGBD_WINO_PC_LAUNCH(1, 2, true); else NRGBD_WINO_PC_LAUNCH(1, 2, false);
     }
 #undef NRGBD_WINO_PC_LAUNCH
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+// R-Net form (models/m_submodule.py:18-27 conv2d_leakyRelu at widths with Cin % 32 == 0, Cout % 64 == 0: Refine.py:51-56 conv0,
+// conv0_1): 3x3 convolution + bias + LeakyReLU(0.01) in the Winograd domain, no prologue, no statistics
+extern "C" int nrgbd_conv_wino_rnet_f32(const float* x, const float* w_wino, const float* bias, int out_lrelu, float* y, int N,
+                                        int H, int W, int Cin, int Cout, void* stream) {
+    using namespace nrgbd;
+    if (!x || !w_wino || !y) return NRGBD_E_NULL;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
+    if ((long)N * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;
+    const int rows = nrgbd_conv_wino_tiles(N, H, W, 1);
+    const long nt = (long)rows * (Cout / 64);
+    if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
+    WinoPcArgs a{x, nullptr, nullptr, nullptr, nullptr, w_wino, y, nullptr, 0, 0, N, H, W, Cin, Cout, (int)nt, rows,
+                 bias, out_lrelu, 0};
+    int dev = 0, ncu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return (int)e;
+    if (ncu <= 0) return NRGBD_E_ARG;
+    const int nwg = nt < ncu ? (int)nt : ncu;
+    const size_t lds = (size_t)(kPcNBuf * kPcV + 4 * kPcRawWave) * sizeof(float);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, false, false, 1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((conv_wino_pc_kernel<1, 1, false, false, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -801,7 +801,14 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                           for i in range(len(res[(0, 0)]))]
             return res
 
+        def wino(m):   # Winograd-domain stream of a layer whose widths the persistent kernel covers (conv0, conv0_1 at D + C0 = 128)
+            c = m[0]
+            if c.in_channels % 32 or c.out_channels % 64 or os.environ.get("NRGBD_RNET_WINO", "1") == "0":
+                return None
+            return (ops.conv_wino_pack(c.weight.detach().contiguous()), c.bias.detach().contiguous(), c.out_channels)
+
         val = {"conv0": conv(self.conv0), "conv0_1": conv(self.conv0_1), "t0": deconv(self.trans_conv0),
+               "conv0_w": wino(self.conv0), "conv0_1_w": wino(self.conv0_1),
                "conv1": conv(self.conv1), "conv1_1": conv(self.conv1_1), "t1": deconv(self.trans_conv1),
                "conv2": conv(self.conv2), "conv2_1": conv(self.conv2_1), "conv2_2": conv(self.conv2_2)}
         cache["key"], cache["val"] = key, val
@@ -849,7 +856,12 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 ops.rnet_pack(dpv_log[b].contiguous(), q_cl[0], feat_planar=False, out=x[b:b + 1])
             else:
                 ops.rnet_pack(dpv_log[b].contiguous(), quarter[0].contiguous(), feat_planar=True, out=x[b:b + 1])
-        x = conv(conv(x, pk["conv0"], buf["a0"]), pk["conv0_1"], buf["b0"])
+        def conv_w(x, name, out):   # quarter-resolution layers: Winograd kernel when the widths allow it (0.16 vs 0.29 ms each)
+            w = pk.get(name + "_w")
+            if w is not None and out.shape[-1] == w[2]:
+                return ops.conv_wino_rnet(x, w[0], w[2], bias=w[1], lrelu=True, out=out)
+            return conv(x, pk[name], out)
+        x = conv_w(conv_w(x, "conv0", buf["a0"]), "conv0_1", buf["b0"])
         # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..D-1 of the concat buffer; features behind
         c1 = buf["c1"]
         conv(x, pk["t0"]["all"], c1, mode=3)

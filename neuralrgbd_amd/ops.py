@@ -601,6 +601,21 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, run
     return ss
 
 
+def conv_wino_rnet(x, w_wino, cout, bias=None, lrelu=True, out=None):
+    """R-Net conv2d_leakyRelu block in the Winograd domain: x [N,H,W,Cin] -> leaky_relu(conv3x3(x) + bias) [N,H,W,cout]."""
+    x = _need(x, "x")
+    N, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (N, H, W, cout) or not out.is_contiguous():
+        raise ValueError("conv_wino_rnet: out must be a contiguous [N,H,W,cout] tensor")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv_wino_rnet_f32(_p(x), _p(w_wino), _p(bias), int(bool(lrelu)), _p(out), N, H, W, Cin, int(cout),
+                                                   _stream(x))
+    _lib.check(rc, "nrgbd_conv_wino_rnet_f32")
+    return out
+
+
 def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
     """Column-major per-tile partials [2C, rows] (conv_wino) -> scale_shift [C,2]; updates the running statistics in place."""
     stats = _need(stats, "stats")

@@ -130,3 +130,18 @@ def test_batch_of_two_equals_two_calls(monkeypatch):
         ra, rb = net.forward_log(a, feats).clone(), net.forward_log(b, feats).clone()
         both = net.forward_log(torch.cat((a, b), 0), feats)
     assert torch.equal(both[0:1], ra) and torch.equal(both[1:2], rb)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 24, 40, 128, 128), (1, 19, 35, 64, 64)])
+def test_rnet_block_in_the_winograd_domain(N, H, W, Cin, Cout):
+    """nrgbd_conv_wino_rnet_f32: conv2d_leakyRelu (m_submodule.py:18-27) = 3x3 conv + bias + LeakyReLU(0.01) on the persistent
+    Winograd kernel (conv0 / conv0_1 of Refine.py:51-56) vs torch in float64."""
+    from neuralrgbd_amd import ops
+    x = _rand(N, Cin, H, W, seed=21)
+    w = _rand(Cout, Cin, 3, 3, seed=22, scale=0.05)
+    b = _rand(Cout, seed=23, scale=0.2)
+    want = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1), 0.01)
+    got = ops.conv_wino_rnet(x.permute(0, 2, 3, 1).contiguous(), ops.conv_wino_pack(w), Cout, bias=b, lrelu=True)
+    err = (got.permute(0, 3, 1, 2).double() - want).abs().max().item()
+    print("[parity] R-Net block (Winograd) N%d %dx%d %d->%d: max|d vs fp64|=%.2e" % (N, H, W, Cin, Cout, err))
+    assert err < 2e-5 * max(1.0, want.abs().max().item())
