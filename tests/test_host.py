@@ -39,6 +39,19 @@ def test_no_cpu_fallback():
         ops.pack_nhwc(torch.zeros(1, 4, 8, 8))
     with pytest.raises(_lib.NrgbdError):
         ops.dpv_resample(torch.zeros(4, 8, 8), torch.eye(4), torch.zeros(3, 64), torch.zeros(4), 1, 1, 1, 1, 0)
+    # the round-2 entry points fail the same way (and the shape errors of the C side need no GPU to be reported)
+    with pytest.raises(_lib.NrgbdError):
+        ops.conv_wino(torch.zeros(2, 8, 16, 64), torch.zeros(64 * 64 * 16), 64, 1)
+    with pytest.raises(_lib.NrgbdError):
+        ops.conv_wino_pack(torch.zeros(64, 64, 3, 3))
+    with pytest.raises(_lib.NrgbdError):
+        ops.conv2d_taps(torch.zeros(1, 8, 8, 16), torch.zeros(16 * 32), 32, 1)
+    lib = _lib.load()
+    assert lib.nrgbd_conv_wino_tiles(5, 192, 256, 1) == 5 * 24 * 16 and lib.nrgbd_conv_wino_tiles(5, 192, 256, 2) == 5 * 12 * 8 * 4
+    assert lib.nrgbd_conv_wino_tiles(1, 8, 16, 3) < 0                                     # dilation 3 is not a form of the kernel
+    assert lib.nrgbd_conv2d_wgrad_workgroups(5, 64, 96, 64, 64) == 60                     # 240 tiles -> 4 per workgroup
+    assert lib.nrgbd_conv2d_wgrad_workgroups(5, 192, 256, 320, 128) == 25                 # 10 weight blocks share the 256 workgroups
+    assert lib.nrgbd_conv_wino_f32(None, None, 0, None, None, 0, None, None, None, None, 1, 8, 16, 64, 64, 1, 1, None) < 0   # NULL
 
 
 def test_product_package_does_not_import_the_oracle():
