@@ -389,7 +389,7 @@ def main():
             with torch.no_grad():
                 _, r_kv, bv_cur, dpv = model(r_, s_, p_, torch.zeros(1), cam_intrinsics=[cam], BV_predict=pred, dpv_valid=True)
                 from neuralrgbd_amd import homography as warp_homo
-                nxt = warp_homo.resample_vol_cuda(dpv, torch.linalg.inv(p_[0, 2]), cam_intrinsic=cam, d_candi=d_candi,
+                nxt = warp_homo.resample_vol_cuda(dpv, ops.pose_inverse(p_[0, 2].contiguous()), cam_intrinsic=cam, d_candi=d_candi,
                                                   padding_value=float(np.log(1.0 / D)), clamp=(-1000., 0.)).unsqueeze(0)
             torch.cuda.synchronize()
             line["cpu_baseline"], o = cpu_baseline(args.config, cam, d_candi, sd, ring[0], pred, sigma)

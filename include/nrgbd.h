@@ -61,6 +61,20 @@ int nrgbd_homography_terms(const float* K, const float* R, long r_view_stride, l
                            int V, void* stream);
 
 /*
+ * nrgbd_pose_inverse — inverse of the 4x4 rigid motions the PREDICT step resamples through.
+ * Replaces: test_utils/test_KVNet.py:50,52 (`Src_CamPoses[ibatch, t_win_r].inverse()` / `cam_pose_next.inverse()`), the
+ * argument `rel_extM` of warping/homography.py:654 resample_vol_cuda.  The reference leaves the operation order to the
+ * host LAPACK; here it is fixed: Gauss-Jordan with partial pivoting on [A | I] in fp64 (every product / difference /
+ * quotient rounded once), result rounded to fp32 (<= 0.5 ulp + double rounding from exact); the CPU oracle executes the
+ * same sequence bit for bit.  General 4x4 (no rigidity assumed, like `.inverse()`).
+ *   T      n matrices, matrix m at T + m*matrix_stride, row-major 4x4 (matrix_stride >= 16)
+ *   T_inv  [n][16]
+ *   singular_count   optional device int, incremented once per matrix with a zero pivot column (its output is NaN:
+ *                    the reference raises on the host; a device entry point cannot, and never syncs)
+ */
+int nrgbd_pose_inverse(const float* T, long matrix_stride, float* T_inv, int* singular_count, int n, void* stream);
+
+/*
  * nrgbd_pack_nhwc — feature packing for the sampling kernels.
  * Replaces: models/basic.py:254-263 (F.avg_pool2d of the RGB frames + torch.cat onto the
  * CNN features) and the implicit NCHW layout handed to homography.py:293.
@@ -170,6 +184,20 @@ int nrgbd_dpv_resample(const float* dpv, const float* T, const float* rays,
                        float z_half, float z_radius, float pad_value,
                        int do_clamp, float clamp_lo, float clamp_hi,
                        float* out, int D, int h, int w, void* stream);
+
+/*
+ * nrgbd_dpv_resample_to — the same resample onto a DIFFERENT set of candidate depths.
+ * Replaces: warping/homography.py:654-723 resample_vol_cuda(..., d_candi_new=...) as called by the local bundle
+ * adjustment driver (test_KVNet_LBA.py:414-417): the sample points are d_candi_new[k] * ray (:675-682), the depth axis is
+ * normalised with z_half / z_radius of the SOURCE candidates (:686-687: float64 numpy min/max, cast to fp32 when it
+ * meets the fp32 tensor), the output has D_out = len(d_candi_new) planes.
+ *   dpv [D_src][h][w], d_candi_out [D_out], out [D_out][h][w]; other arguments as nrgbd_dpv_resample.
+ */
+int nrgbd_dpv_resample_to(const float* dpv, const float* T, const float* rays,
+                          const float* d_candi_out, float tan_hh, float tan_hv,
+                          float z_half, float z_radius, float pad_value,
+                          int do_clamp, float clamp_lo, float clamp_hi,
+                          float* out, int D_src, int D_out, int h, int w, void* stream);
 
 /*
  * nrgbd_logsoftmax_d — log-softmax over the depth axis of scale*a (+ b).

@@ -20,6 +20,7 @@ SIGNATURES = {
     "nrgbd_version": (_c.c_char_p, []),
     "nrgbd_strerror": (_c.c_char_p, [_I]),
     "nrgbd_homography_terms": (_I, [_P, _P, _L, _L, _P, _L, _L, _P, _P, _I, _P]),
+    "nrgbd_pose_inverse": (_I, [_P, _L, _P, _P, _I, _P]),
     "nrgbd_pack_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_costvol_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P,
                                _I, _I, _I, _I, _I, _I, _P]),
@@ -30,6 +31,7 @@ SIGNATURES = {
     "nrgbd_warp_volume": (_I, [_P, _L, _L, _L, _L, _P, _L, _L, _L, _P, _P, _P, _P, _F, _F, _I,
                                _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_dpv_resample": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _I, _I, _P]),
+    "nrgbd_dpv_resample_to": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _I, _I, _I, _P]),
     "nrgbd_logsoftmax_d": (_I, [_P, _P, _F, _P, _I, _L, _P]),
     "nrgbd_depth_regress": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "nrgbd_export_depth_u16": (_I, [_P, _P, _F, _F, _P, _P, _P, _P, _I, _L, _P]),

@@ -1,5 +1,5 @@
 // resample.hip — PREDICT: rigid 3-D resample of the depth-probability volume (K10).
-// Replaces warping/homography.py:654-723 (resample_vol_cuda, d_candi_new=None), :873-887
+// Replaces warping/homography.py:654-723 (resample_vol_cuda, d_candi_new = None or given), :873-887
 // (_set_vol_border) and the clamp of test_utils/test_KVNet.py:54-59.
 //
 // The reference builds the [1,D,h,w,3] back-projected point grid on the HOST in a Python loop and
@@ -15,7 +15,7 @@ struct ResampleArgs {
     const float* dpv; const float* T; const float* rays; const float* d_candi;
     float* out;
     float tan_hh, tan_hv, z_half, z_radius, pad, lo, hi;
-    int do_clamp, D, h, w;
+    int do_clamp, D, h, w;   // D = planes of the source volume; the launch's grid.y = planes of the output (d_candi's length)
 };
 
 // ATen GridSampler.h clip_coordinates: min(size-1, max(x, 0)) with std::min/max NaN behaviour
@@ -79,18 +79,26 @@ __global__ __launch_bounds__(256) void dpv_resample_kernel(const ResampleArgs a)
 
 }  // namespace nrgbd
 
+extern "C" int nrgbd_dpv_resample_to(const float* dpv, const float* T, const float* rays,
+                                     const float* d_candi_out, float tan_hh, float tan_hv, float z_half,
+                                     float z_radius, float pad_value, int do_clamp, float clamp_lo,
+                                     float clamp_hi, float* out, int D_src, int D_out, int h, int w, void* stream) {
+    using namespace nrgbd;
+    if (!dpv || !T || !rays || !d_candi_out || !out) return NRGBD_E_NULL;
+    if (dpv == out) return NRGBD_E_ARG;
+    if (D_src <= 0 || D_src > 65535 || D_out <= 0 || D_out > 65535 || h <= 0 || w <= 0) return NRGBD_E_SHAPE;
+    ResampleArgs a{dpv, T, rays, d_candi_out, out, tan_hh, tan_hv, z_half, z_radius, pad_value,
+                   clamp_lo, clamp_hi, do_clamp, D_src, h, w};
+    dim3 grid(ceil_div((long)h * w, 256), D_out);
+    hipLaunchKernelGGL(dpv_resample_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
 extern "C" int nrgbd_dpv_resample(const float* dpv, const float* T, const float* rays,
                                   const float* d_candi, float tan_hh, float tan_hv, float z_half,
                                   float z_radius, float pad_value, int do_clamp, float clamp_lo,
                                   float clamp_hi, float* out, int D, int h, int w, void* stream) {
-    using namespace nrgbd;
-    if (!dpv || !T || !rays || !d_candi || !out) return NRGBD_E_NULL;
-    if (dpv == out) return NRGBD_E_ARG;
-    if (D <= 0 || D > 65535 || h <= 0 || w <= 0) return NRGBD_E_SHAPE;
-    ResampleArgs a{dpv, T, rays, d_candi, out, tan_hh, tan_hv, z_half, z_radius, pad_value,
-                   clamp_lo, clamp_hi, do_clamp, D, h, w};
-    dim3 grid(ceil_div((long)h * w, 256), D);
-    hipLaunchKernelGGL(dpv_resample_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-    NRGBD_CHECK_LAUNCH();
-    return NRGBD_OK;
+    return nrgbd_dpv_resample_to(dpv, T, rays, d_candi, tan_hh, tan_hv, z_half, z_radius, pad_value, do_clamp, clamp_lo,
+                                 clamp_hi, out, D, D, h, w, stream);
 }

@@ -147,24 +147,45 @@ def z_range(d_candi):
     return float(np.float32((z_max + z_min) * np.float32(0.5))), float(np.float32((z_max - z_min) * np.float32(0.5)))
 
 
+def z_range_f64(d_candi):
+    """The d_candi_new form (homography.py:685-693): z_max / z_min are numpy float64 scalars of d_candi, z_half / z_radius
+    float64 products that torch casts to fp32 when they meet the fp32 coordinate tensor."""
+    d = np.asarray(d_candi)
+    z_max, z_min = d.max(), d.min()
+    return float(np.float32((z_max + z_min) * .5)), float(np.float32((z_max - z_min) * .5))
+
+
 def resample_vol_cuda(src_vol, rel_extM, cam_intrinsic=None, d_candi=None, d_candi_new=None,
                       padding_value=0., output_tensor=False, is_debug=False,
                       PointsDs_ref_cam_coord_in=None, clamp=None):
     """PREDICT step: resample the volume src_vol [1,D,h,w] under the rigid motion rel_extM [4,4].
 
-    Returns [D,h,w].  `clamp=(lo, hi)` fuses the `.clamp(min=lo, max=hi)` the callers apply
+    Returns [D,h,w].  d_candi_new (the LBA driver's form, test_KVNet_LBA.py:414-417): the planes are sampled at the new
+    candidates while the depth axis is normalised by the float64 range of d_candi.  `clamp=(lo, hi)` fuses the `.clamp(min=lo, max=hi)` the callers apply
     (test_utils/test_KVNet.py:59); the default None matches the reference function itself.
     """
     assert d_candi is not None, 'd_candi should be some np.array object'
-    if d_candi_new is not None or PointsDs_ref_cam_coord_in is not None or is_debug:
-        raise NotImplementedError("only the d_candi_new=None streaming PREDICT form is on this path")
+    if PointsDs_ref_cam_coord_in is not None or is_debug:
+        raise NotImplementedError("a caller-supplied point grid / the debug return are not on this path "
+                                  "(no reference script passes them)")
     D, h, w = src_vol.shape[1:]
     dev = src_vol.device
     _, rays = _cam_dev(cam_intrinsic, dev)
     hhfov = math.radians(cam_intrinsic['hfov']) * .5
     hvfov = math.radians(cam_intrinsic['vfov']) * .5
-    z_half, z_radius = z_range(d_candi)
     T = rel_extM.to(device=dev, dtype=torch.float32)
+    if d_candi_new is not None:
+        # test_KVNet_LBA.py:414-417: sample at the NEW candidates, depth axis normalised by the source candidates' range
+        # The reference allocates D (= source planes) point planes and fills the first len(d_candi_new) (:673-682): more
+        # candidates than planes is its IndexError, fewer leaves the remaining planes at the origin (d = 0).
+        z_half, z_radius = z_range_f64(d_candi)
+        d_new = np.asarray(d_candi_new, dtype=np.float64).reshape(-1)
+        if d_new.shape[0] > D:
+            raise IndexError("index %d is out of bounds for dimension 1 with size %d" % (D, D))
+        d_new = np.concatenate([d_new, np.zeros(D - d_new.shape[0])])
+        return ops.dpv_resample(src_vol[0], T, rays, _d_candi_dev(d_new, dev), math.tan(hhfov), math.tan(hvfov),
+                                z_half, z_radius, padding_value, clamp=clamp, new_candi=True)
+    z_half, z_radius = z_range(d_candi)
     return ops.dpv_resample(src_vol[0], T, rays, _d_candi_dev(d_candi, dev), math.tan(hhfov),
                             math.tan(hvfov), z_half, z_radius, padding_value, clamp=clamp)
 

@@ -63,6 +63,23 @@ def homography_terms(K, R, t):
     return KR, Kt
 
 
+def pose_inverse(T, singular_count=None):
+    """T [...,4,4] fp32 on the GPU -> its inverse, same shape (nrgbd_pose_inverse: fp64 Gauss-Jordan in a fixed operation
+    order, rounded to fp32; replaces `.inverse()` of test_utils/test_KVNet.py:50).  Capture-safe: no solver workspace,
+    no host sync.  `singular_count`: optional int32 device scalar that counts singular inputs (their output is NaN)."""
+    T = _need(T, "T")
+    if T.dim() < 2 or tuple(T.shape[-2:]) != (4, 4):
+        raise ValueError("pose_inverse: T %s, expected [...,4,4]" % (tuple(T.shape),))
+    n = T.numel() // 16
+    out = torch.empty_like(T)
+    if singular_count is not None and (singular_count.dtype != torch.int32 or not singular_count.is_cuda):
+        raise TypeError("singular_count must be an int32 CUDA tensor")
+    with torch.cuda.device(T.device):
+        rc = _lib.load().nrgbd_pose_inverse(_p(T), 16, _p(out), _p(singular_count), n, _stream(T))
+    _lib.check(rc, "nrgbd_pose_inverse")
+    return out
+
+
 def pack_nhwc(feat, rgb=None, Cp=None, channels_last=False):
     """feat [N,Cf,h,w] (or [N,h,w,Cf] if channels_last) (+ rgb [N,3,h*pool,w*pool]) -> texels [N,h,w,Cp] (nrgbd_pack_nhwc)."""
     feat = _need(feat, "feat")
@@ -166,21 +183,26 @@ def warp_volume(src, src_strides, ref, ref_strides, KR, Kt, rays, d_candi, cx, c
     return out
 
 
-def dpv_resample(dpv, T, rays, d_candi, tan_hh, tan_hv, z_half, z_radius, pad_value, clamp=(-1000.0, 0.0)):
-    """PREDICT: dpv [D,h,w], T [4,4] (device) -> resampled [D,h,w]."""
+def dpv_resample(dpv, T, rays, d_candi, tan_hh, tan_hv, z_half, z_radius, pad_value, clamp=(-1000.0, 0.0),
+                 new_candi=False):
+    """PREDICT: dpv [D,h,w], T [4,4] (device) -> resampled [len(d_candi),h,w].  `d_candi` = the depths of the OUTPUT planes
+    (= the source's unless new_candi: resample_vol_cuda's d_candi_new form, nrgbd_dpv_resample_to)."""
     dpv = _need(dpv, "dpv")
     D, h, w = dpv.shape
     T = _need(T, "T").reshape(16)
     rays = _need(rays, "rays", (3, h * w))
-    d_candi = _need(d_candi, "d_candi", (D,))
-    out = torch.empty_like(dpv)
+    d_candi = _need(d_candi, "d_candi") if new_candi else _need(d_candi, "d_candi", (D,))
+    if d_candi.dim() != 1:
+        raise ValueError("d_candi must be 1-D")
+    Do = d_candi.shape[0]
+    out = torch.empty((Do, h, w), dtype=torch.float32, device=dpv.device)
     lo, hi = clamp if clamp is not None else (0.0, 0.0)
     with torch.cuda.device(dpv.device):
-        rc = _lib.load().nrgbd_dpv_resample(_p(dpv), _p(T), _p(rays), _p(d_candi), float(tan_hh),
-                                            float(tan_hv), float(z_half), float(z_radius),
-                                            float(pad_value), int(clamp is not None), float(lo),
-                                            float(hi), _p(out), D, h, w, _stream(dpv))
-    _lib.check(rc, "nrgbd_dpv_resample")
+        rc = _lib.load().nrgbd_dpv_resample_to(_p(dpv), _p(T), _p(rays), _p(d_candi), float(tan_hh),
+                                               float(tan_hv), float(z_half), float(z_radius),
+                                               float(pad_value), int(clamp is not None), float(lo),
+                                               float(hi), _p(out), D, Do, h, w, _stream(dpv))
+    _lib.check(rc, "nrgbd_dpv_resample_to")
     return out
 
 

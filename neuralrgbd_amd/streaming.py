@@ -16,6 +16,7 @@ import math
 import torch
 
 from . import homography as warp_homo
+from . import ops
 
 
 class DepthStream:
@@ -42,9 +43,11 @@ class DepthStream:
         self.bv_predict = None
 
     # ------------------------------------------------------------------ one frame, eager
-    def _frame(self, ref, src, poses, pose_next_inv, bv_predict):
+    def _frame(self, ref, src, poses, pose_next, bv_predict):
         model = self.model
         with torch.no_grad():
+            # test_KVNet.py:50 `.inverse()` as a path kernel (fixed operation order, capture-safe): inside the hipGraph
+            pose_next_inv = ops.pose_inverse(pose_next)
             r_cur, r_kv, bv_cur, dpv = model(ref, src, poses, torch.zeros(1), cam_intrinsics=[self.cam],
                                              BV_predict=bv_predict, dpv_valid=bv_predict is not None)
             pad = math.log(1. / float(len(self.d_candi)))
@@ -52,8 +55,8 @@ class DepthStream:
                                               d_candi=self.d_candi, padding_value=pad, clamp=(-1000., 0.)).unsqueeze(0)
         return r_kv, dpv, nxt
 
-    def _capture(self, ref, src, poses, pose_next_inv):
-        st = {"ref": ref.clone(), "src": src.clone(), "poses": poses.clone(), "inv": pose_next_inv.clone(),
+    def _capture(self, ref, src, poses, pose_next):
+        st = {"ref": ref.clone(), "src": src.clone(), "poses": poses.clone(), "inv": pose_next.clone(),
               "bv": self.bv_predict.clone()}
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
@@ -67,7 +70,7 @@ class DepthStream:
         Returns (refined DPV [1,D,H,W], DPV [1,D,h,w]); the predicted state for the next frame is kept inside.
         With the hipGraph active and copy_outputs=False the returned tensors are only valid until the next step()."""
         pose = src_cam_poses[0, self.t_win_r] if cam_pose_next is None else cam_pose_next
-        pose_next_inv = torch.linalg.inv(pose)  # outside the graph: the solver may allocate / sync
+        pose_next_inv = pose.to(dtype=torch.float32).contiguous()   # inverted inside the frame (nrgbd_pose_inverse)
         if self.bv_predict is None:                      # first window of the stream: D-Net only
             r, dpv, nxt = self._frame(ref_frame, src_frames, src_cam_poses, pose_next_inv, None)
             self.bv_predict = nxt

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from . import homography as warp_homo
+from . import ops
 
 
 def test(model_KV, d_candi, Cam_Intrinsics, t_win_r, Ref_Dats, Src_Dats, Src_CamPoses, BV_predict,
@@ -34,7 +35,9 @@ def test(model_KV, d_candi, Cam_Intrinsics, t_win_r, Ref_Dats, Src_Dats, Src_Cam
         BVs_predict = []
         for ibatch in range(d_dpv.shape[0]):
             pose = Src_CamPoses[ibatch, t_win_r] if cam_pose_next is None else cam_pose_next.cuda()
-            rel_Rt = torch.linalg.inv(pose)  # stays on the device: no sync
+            # the reference's `.inverse()` (:50) in the path's own fixed operation order (nrgbd_pose_inverse): the host
+            # LAPACK / rocSOLVER order is opaque and one ulp of rel_Rt moves every resampling point of the DPV
+            rel_Rt = ops.pose_inverse(pose.to(dtype=torch.float32).contiguous())
             BVs_predict.append(warp_homo.resample_vol_cuda(
                 src_vol=kv_dpv[ibatch].unsqueeze(0), rel_extM=rel_Rt, cam_intrinsic=Cam_Intrinsics[ibatch],
                 d_candi=d_candi, padding_value=pad, clamp=(-1000., 0.)).unsqueeze(0))

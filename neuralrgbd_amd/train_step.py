@@ -60,7 +60,7 @@ def train(nGPU, model_KV, optimizer_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, Sr
     # PREDICT on the detached DPV (train_KVNet.py:155-171)
     with torch.no_grad():
         kv = kv_dpv.detach()
-        rel_Rt = torch.linalg.inv(poses[0, t_win_r])
+        rel_Rt = ops.pose_inverse(poses[0, t_win_r].to(dtype=torch.float32).contiguous())   # fixed-order inverse (test_step.py)
         BVs_predict_out = warp_homo.resample_vol_cuda(
             src_vol=kv, rel_extM=rel_Rt, cam_intrinsic=Cam_Intrinsics[0], d_candi=d_candi,
             padding_value=math.log(1. / float(len(d_candi))), clamp=(-1000., 0.)).unsqueeze(0)
@@ -120,7 +120,7 @@ class TrainGraph:
         return loss.detach(), nxt
 
     def step(self, ref_frame, src_frames, poses, dmap, dmap_full, bv_predict):
-        inv = torch.linalg.inv(poses[0, self.t_win_r])
+        inv = ops.pose_inverse(poses[0, self.t_win_r].to(dtype=torch.float32).contiguous())
         if self._graph is None and (self._eager_steps < self._warmup or self._optimizer_ready() is not None):
             if self._eager_steps >= max(self._warmup, 2):
                 raise RuntimeError("TrainGraph: parameter %s still has no optimizer state after %d eager iterations "

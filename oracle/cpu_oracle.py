@@ -58,6 +58,17 @@ def homography_terms(K, R, t):
     return KR, Kt
 
 
+def pose_inverse(T):
+    """T [...,4,4] -> inverse in the path's fixed fp64 Gauss-Jordan order, rounded to fp32 (oracle_pose_inverse; replaces the
+    host-LAPACK `.inverse()` of test_utils/test_KVNet.py:50).  Raises on a singular matrix like the reference does."""
+    t, pt = _f(np.asarray(T, np.float32))
+    out = np.empty_like(t)
+    bad = lib().oracle_pose_inverse(pt, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), t.size // 16)
+    if bad:
+        raise np.linalg.LinAlgError("pose_inverse: singular matrix")
+    return out
+
+
 def costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, sigma, dist="L2",
             align_corners=False):
     """feat_ref [C,h,w], feat_src [V,C,h,w] -> cost [D,h,w] (est_swp_volume_v4)."""
@@ -94,18 +105,26 @@ def z_range(d_candi):
     return np.float32((z_max + z_min) * np.float32(0.5)), np.float32((z_max - z_min) * np.float32(0.5))
 
 
-def dpv_resample(dpv, T, rays, d_candi, tan_hh, tan_hv, pad, clamp=(-1000.0, 0.0)):
-    """dpv [D,h,w], T [4,4] -> [D,h,w] (resample_vol_cuda + clamp)."""
+def dpv_resample(dpv, T, rays, d_candi, tan_hh, tan_hv, pad, clamp=(-1000.0, 0.0), d_candi_new=None):
+    """dpv [D,h,w], T [4,4] -> [D,h,w] (resample_vol_cuda + clamp); with d_candi_new -> [len(d_candi_new),h,w]
+    (homography.py:675-693: points at the new candidates, z range = float64 min/max of d_candi cast to fp32)."""
     D, h, w = dpv.shape
-    v, pv = _f(dpv); t, pt = _f(np.asarray(T).reshape(16)); ry, pry = _f(rays); dc, pdc = _f(d_candi)
-    z_half, z_rad = z_range(d_candi)
-    out = np.empty((D, h, w), np.float32)
+    v, pv = _f(dpv); t, pt = _f(np.asarray(T).reshape(16)); ry, pry = _f(rays)
+    if d_candi_new is None:
+        dc, pdc = _f(d_candi)
+        z_half, z_rad = z_range(d_candi)
+    else:
+        dc, pdc = _f(d_candi_new)
+        d64 = np.asarray(d_candi)
+        z_half, z_rad = float(np.float32((d64.max() + d64.min()) * .5)), float(np.float32((d64.max() - d64.min()) * .5))
+    Do = dc.shape[0]
+    out = np.empty((Do, h, w), np.float32)
     do_clamp = clamp is not None
     lo, hi = clamp if do_clamp else (0.0, 0.0)
-    rc = lib().oracle_dpv_resample(pv, pt, pry, pdc, ctypes.c_float(tan_hh), ctypes.c_float(tan_hv),
-                                   ctypes.c_float(z_half), ctypes.c_float(z_rad), ctypes.c_float(pad),
-                                   int(do_clamp), ctypes.c_float(lo), ctypes.c_float(hi), D, h, w,
-                                   out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    rc = lib().oracle_dpv_resample_to(pv, pt, pry, pdc, ctypes.c_float(tan_hh), ctypes.c_float(tan_hv),
+                                      ctypes.c_float(z_half), ctypes.c_float(z_rad), ctypes.c_float(pad),
+                                      int(do_clamp), ctypes.c_float(lo), ctypes.c_float(hi), D, Do, h, w,
+                                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
     assert rc == 0
     return out
 

@@ -338,15 +338,28 @@ def gen_fp64_S(ref):
     np.savez(os.path.join(OUT, "net_fp64_S.npz"), **out)
 
 
+def gen_pose_inv(ref):
+    """What the reference's PREDICT step feeds to resample_vol_cuda for the NET windows: `Src_CamPoses[0, t_win_r].inverse()`
+    (test_utils/test_KVNet.py:50) as torch's host LAPACK computes it HERE.  Its operation order is the library's (MKL), so
+    the fixture stores the matrices themselves; the path's own inverse (oracle_pose_inverse) is compared with them."""
+    n = NET
+    inv = [synth.noise_window(s, n["H"], n["W"])[2][0, 2].inverse().numpy() for s in n["seeds"]]
+    rng = np.random.RandomState(99)
+    extra = np.stack([synth.random_pose(rng, 0.3, 1.0).astype(np.float32) for _ in range(64)])
+    np.savez(os.path.join(OUT, "pose_inv_ref.npz"), net_inv=np.stack(inv), poses=extra,
+             poses_inv=torch.from_numpy(extra).inverse().numpy())
+    print("pose_inv_ref: written")
+
+
 def main():
     if not ref_shim.available():
         raise SystemExit("reference not present: golden vectors can only be generated in the build container")
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shim.load()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["ops", "net", "scene", "ops67", "fp64", "fp64S", "lba", "export", "train"]
+    which = sys.argv[1:] or ["ops", "net", "scene", "ops67", "fp64", "fp64S", "lba", "export", "train", "pose_inv"]
     for name in which:
-        {"ops": gen_ops, "net": gen_net, "scene": gen_scene, "ops67": gen_ops67, "fp64": gen_fp64, "fp64S": gen_fp64_S, "lba": gen_lba, "export": gen_export, "train": gen_train}[name](ref)
+        {"ops": gen_ops, "net": gen_net, "scene": gen_scene, "ops67": gen_ops67, "fp64": gen_fp64, "fp64S": gen_fp64_S, "lba": gen_lba, "export": gen_export, "train": gen_train, "pose_inv": gen_pose_inv}[name](ref)
 
 
 if __name__ == "__main__":

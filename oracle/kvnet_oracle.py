@@ -140,19 +140,22 @@ def kvnet_forward(sd, ref, src, poses, cam, d_candi, sigma, BV_predict=None):
     return R_cur, R_kv, BV_cur, DPV
 
 
-def predict(dpv, pose_next, cam, d_candi):
-    """test_utils/test_KVNet.py:47-62: resample by inverse(pose ref->next), pad log(1/D), clamp [-1000,0]."""
-    T = torch.linalg.inv(pose_next)
+def predict(dpv, pose_next, cam, d_candi, rel_extM=None):
+    """test_utils/test_KVNet.py:47-62: resample by inverse(pose ref->next), pad log(1/D), clamp [-1000,0].
+    The inverse is the path's fixed-order one (oracle_pose_inverse == nrgbd_pose_inverse); `rel_extM` substitutes a given
+    matrix — the golden tests pass the reference's own host-LAPACK result (tests/golden/pose_inv_ref.npz) to show that the
+    last bits of that matrix are the ONLY difference between this PREDICT and the reference's."""
+    T = co.pose_inverse(pose_next.numpy()) if rel_extM is None else np.asarray(rel_extM, np.float32)
     D = len(d_candi)
-    out = co.dpv_resample(dpv[0].numpy(), T.numpy(), cam["unit_ray_array_2D"].numpy(), d_candi,
+    out = co.dpv_resample(dpv[0].numpy(), T, cam["unit_ray_array_2D"].numpy(), d_candi,
                           math.tan(math.radians(cam["hfov"]) * .5), math.tan(math.radians(cam["vfov"]) * .5),
                           math.log(1. / float(D)))
     return torch.from_numpy(out)[None]
 
 
-def step(sd, ref, src, poses, cam, d_candi, sigma, BV_predict, t_win_r=2, pose_next=None):
+def step(sd, ref, src, poses, cam, d_candi, sigma, BV_predict, t_win_r=2, pose_next=None, rel_extM=None):
     """One iteration of the reference's test(): forward + PREDICT -> (R_kv, DPV, BV_cur, BV_predict_next)."""
     with torch.no_grad():
         R_cur, R_kv, BV_cur, DPV = kvnet_forward(sd, ref, src, poses, cam, d_candi, sigma, BV_predict)
-        nxt = predict(DPV, poses[0, t_win_r] if pose_next is None else pose_next, cam, d_candi)
+        nxt = predict(DPV, poses[0, t_win_r] if pose_next is None else pose_next, cam, d_candi, rel_extM)
     return R_kv, DPV, BV_cur, nxt

@@ -54,6 +54,40 @@ int oracle_homography_terms(const float* K, const float* R, const float* t, int 
     return 0;
 }
 
+/* test_utils/test_KVNet.py:50,52: `Src_CamPoses[ibatch, t_win_r].inverse()` — the motion the PREDICT step resamples through.
+ * The reference leaves the operation order to the host LAPACK (MKL sgetrf + sgetrs on the transposed matrix under torch
+ * 2.10; its LU is reproducible as a right-looking fma chain with reciprocal scaling, its triangular solves are not), so
+ * the path fixes it: Gauss-Jordan with partial pivoting on [A | I] in fp64, one rounding per operation, rounded to fp32.
+ * Same sequence as neuralrgbd_amd/csrc/geom.hip::pose_inverse_kernel.  tests/test_oracle_vs_reference.py bounds the
+ * distance to the live reference's `.inverse()` (a few fp32 ulps = the reference's own rounding error). */
+int oracle_pose_inverse(const float* T, float* out, int n) {
+    int singular = 0;
+    for (int m = 0; m < n; ++m) {
+        double a[4][8];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) { a[i][j] = (double)T[16 * m + 4 * i + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+        int bad = 0;
+        for (int c = 0; c < 4 && !bad; ++c) {
+            int p = c;
+            double best = fabs(a[c][c]);
+            for (int r = c + 1; r < 4; ++r) { double v = fabs(a[r][c]); if (v > best) { best = v; p = r; } }
+            if (!(best > 0.0)) { bad = 1; break; }
+            if (p != c) for (int j = 0; j < 8; ++j) { double tmp = a[c][j]; a[c][j] = a[p][j]; a[p][j] = tmp; }
+            double piv = a[c][c];
+            for (int j = 0; j < 8; ++j) a[c][j] = a[c][j] / piv;
+            for (int r = 0; r < 4; ++r) {
+                if (r == c) continue;
+                double f = a[r][c];
+                for (int j = 0; j < 8; ++j) a[r][j] = a[r][j] - f * a[c][j];
+            }
+        }
+        singular += bad;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) out[16 * m + 4 * i + j] = bad ? NAN : (float)a[i][4 + j];
+    }
+    return singular;
+}
+
 /* ATen GridSampler.h grid_sampler_unnormalize */
 static inline float unnormalize(float g, int size, int align_corners) {
     if (align_corners) return ((g + 1.f) / 2.f) * (float)(size - 1);
@@ -194,13 +228,15 @@ static inline float vol_at(const float* vol, int D, int h, int w, int z, int y, 
  * (resample_vol_cuda with d_candi_new=None), :873-887 (_set_vol_border) and the clamp of
  * test_utils/test_KVNet.py:54-59.  T is the row-major 4x4 rel_extM.
  */
-int oracle_dpv_resample(const float* dpv, const float* T, const float* rays,
-                        const float* d_candi, float tan_hh, float tan_hv, float z_half,
-                        float z_radius, float pad, int do_clamp, float lo, float hi,
-                        int D, int h, int w, float* out) {
+int oracle_dpv_resample_to(const float* dpv, const float* T, const float* rays,
+                           const float* d_candi, float tan_hh, float tan_hv, float z_half,
+                           float z_radius, float pad, int do_clamp, float lo, float hi,
+                           int D, int D_out, int h, int w, float* out) {
+    /* d_candi: depths of the D_out OUTPUT planes (= the source's candidates, or d_candi_new: homography.py:675-682);
+     * D: planes of the source volume dpv */
     const size_t hw = (size_t)h * w;
 #pragma omp parallel for schedule(static)
-    for (int k = 0; k < D; ++k)
+    for (int k = 0; k < D_out; ++k)
         for (size_t p = 0; p < hw; ++p) {
             /* :679-682  X = d * ray */
             float d = d_candi[k];
@@ -244,6 +280,13 @@ int oracle_dpv_resample(const float* dpv, const float* T, const float* rays,
             out[(size_t)k * hw + p] = acc;
         }
     return 0;
+}
+
+int oracle_dpv_resample(const float* dpv, const float* T, const float* rays,
+                        const float* d_candi, float tan_hh, float tan_hv, float z_half,
+                        float z_radius, float pad, int do_clamp, float lo, float hi,
+                        int D, int h, int w, float* out) {
+    return oracle_dpv_resample_to(dpv, T, rays, d_candi, tan_hh, tan_hv, z_half, z_radius, pad, do_clamp, lo, hi, D, D, h, w, out);
 }
 
 /* models/basic.py:299-300 and models/KVNET.py:172-173: log_softmax over D of scale*a + b */

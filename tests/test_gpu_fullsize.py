@@ -70,7 +70,7 @@ def test_predict_identity_and_bounds():
     cam, tex, KR, Kt, rays, d, poses = _setup(2)
     dpv = torch.log_softmax(torch.randn(1, D_, H_, W_, device=DEV) * 4, dim=1)
     pad = float(np.log(1.0 / D_))
-    out = Hm.resample_vol_cuda(dpv, torch.linalg.inv(poses[2]), cam_intrinsic=cam, d_candi=np.linspace(0.1, 5, D_),
+    out = Hm.resample_vol_cuda(dpv, ops.pose_inverse(poses[2].contiguous()), cam_intrinsic=cam, d_candi=np.linspace(0.1, 5, D_),
                                padding_value=pad, clamp=(-1000., 0.))
     assert out.shape == (D_, H_, W_) and bool(torch.isfinite(out).all())
     assert out.max().item() <= 0.0 and out.min().item() >= min(dpv.min().item(), pad) - 1e-4

@@ -484,3 +484,50 @@ def test_export_epilogue_vs_reference_files_and_oracle(tmp_path):
     do, co_, duo, cuo = co.export_depth_u16(big.numpy(), d64)
     assert np.abs(dg.cpu().numpy() - do).max() < 2e-6
     assert (dug.cpu().numpy() != duo).mean() < 1e-4 and (cug.cpu().numpy() != cuo).mean() < 1e-4
+
+
+def test_pose_inverse_bit_exact_vs_oracle():
+    """nrgbd_pose_inverse (fp64 Gauss-Jordan in a written-out order, rounded to fp32) == oracle_pose_inverse bit for bit:
+    the PREDICT coordinates of the GPU path and of the oracle come from the SAME matrix (test_utils/test_KVNet.py:50)."""
+    ops = _ops()
+    rng = np.random.RandomState(5)
+    T = np.stack([synth.random_pose(rng, 0.6, 2.0) for _ in range(1000)]).astype(np.float32)
+    T[500:] += (rng.standard_normal((500, 4, 4)) * 1e-2).astype(np.float32)        # general (non-rigid) 4x4: pivoting paths
+    T[10] = np.eye(4, dtype=np.float32)[[2, 0, 3, 1]]                               # permutation: every pivot is a swap
+    got = ops.pose_inverse(_dev(T)).cpu().numpy()
+    want = co.pose_inverse(T)
+    assert np.array_equal(got, want)
+    ex = np.linalg.inv(T.astype(np.float64))
+    assert np.abs(got - ex).max() <= 0.51 * np.spacing(np.abs(ex).astype(np.float32)).max()
+    # batch shapes, and one strided view as the host code passes it (poses[0, t_win_r])
+    P = _dev(T[:8].reshape(2, 4, 4, 4))
+    assert np.array_equal(ops.pose_inverse(P).cpu().numpy().reshape(8, 4, 4), want[:8])
+    assert np.array_equal(ops.pose_inverse(P[1, 2]).cpu().numpy(), want[6])
+    # singular input: NaN out + counted, no exception / sync on the device side
+    S = T[:3].copy(); S[1, :, 2] = 0
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = ops.pose_inverse(_dev(S), singular_count=cnt).cpu().numpy()
+    assert int(cnt.item()) == 1 and np.isnan(out[1]).all() and np.array_equal(out[[0, 2]], want[[0, 2]])
+
+
+def test_resample_vol_cuda_with_new_candidates():
+    """homography.resample_vol_cuda(..., d_candi_new=...) (the LBA driver's call, test_KVNet_LBA.py:414-417) against the
+    oracle form that tests/test_oracle_vs_reference.py holds bit-identical to the live reference."""
+    from neuralrgbd_amd import homography as H
+    h, w, D = 24, 40, 16
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(9)
+    d_candi = np.linspace(0.3, 8, D)
+    dpv = torch.log_softmax(torch.from_numpy(rng.standard_normal((1, D, h, w)).astype(np.float32)) * 4, 1)
+    T = co.pose_inverse(synth.random_pose(rng, 0.05, 0.2).astype(np.float32))
+    pad = math.log(1. / D)
+    tan_hh, tan_hv = math.tan(math.radians(cam["hfov"]) * .5), math.tan(math.radians(cam["vfov"]) * .5)
+    for d_new in (d_candi, np.linspace(0.5, 6.5, 11)):
+        got = H.resample_vol_cuda(dpv.to(DEV), _dev(T), cam_intrinsic=cam, d_candi=d_candi, d_candi_new=d_new,
+                                  padding_value=pad).cpu().numpy()
+        d_pad = np.concatenate([d_new, np.zeros(D - len(d_new))])
+        want = co.dpv_resample(dpv[0].numpy(), T, cam["unit_ray_array_2D"].numpy(), d_candi, tan_hh, tan_hv, pad,
+                               clamp=None, d_candi_new=d_pad)
+        assert got.shape == (D, h, w) and np.array_equal(got, want)
+    with pytest.raises(IndexError):
+        H.resample_vol_cuda(dpv.to(DEV), _dev(T), cam_intrinsic=cam, d_candi=d_candi, d_candi_new=np.linspace(1, 2, D + 1))

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, near_tie_mismatches, report
-from neuralrgbd_amd import camera, synth
+from neuralrgbd_amd import camera, ops, synth
 from oracle import cpu_oracle as co
 from oracle import gen_golden
 from oracle import kvnet_oracle as ko
@@ -32,7 +32,8 @@ def _model(cam, d_candi, sigma, seed=0):
 
 
 def _gpu_two_frames(model, cam, d_candi, windows):
-    """KVNET.forward + PREDICT per frame (the body of test_utils/test_KVNet.py::test, keeping BV_cur as well)."""
+    """KVNET.forward + PREDICT per frame (the body of test_utils/test_KVNet.py::test, keeping BV_cur as well).
+    Outputs are moved to the host frame by frame so that the big grids do not hold two frames of volumes on the device."""
     import math
     from neuralrgbd_amd import homography as Hm
     outs, pred = [], None
@@ -40,22 +41,29 @@ def _gpu_two_frames(model, cam, d_candi, windows):
     for (r, s, p) in windows:
         with torch.no_grad():
             _, _, bv_cur, dpv = model(r.cuda(), s.cuda(), p.cuda(), torch.zeros(1), cam_intrinsics=[cam], BV_predict=pred)
-            nxt = Hm.resample_vol_cuda(dpv, torch.linalg.inv(p[0, 2].cuda()), cam_intrinsic=cam, d_candi=d_candi,
+            nxt = Hm.resample_vol_cuda(dpv, ops.pose_inverse(p[0, 2].cuda().contiguous()), cam_intrinsic=cam, d_candi=d_candi,
                                        padding_value=pad, clamp=(-1000., 0.)).unsqueeze(0)
         outs.append((bv_cur, dpv, nxt))
         pred = nxt
     return outs
 
 
-def _check(name, got, want, argmax=True, fp64=None, oracle_err=None):
+MAX_TIE_FLIPS = 4    # per frame and volume; measured envelope over every config: <= 2 (round 2 allowed 1 per 1,000 pixels)
+
+
+def _check(name, got, want, argmax=True, fp64=None, oracle_err=None, max_abs=None):
     """L1 < 1e-4 always.  Arg-max depth index (BV_cur, DPV — BASELINE.json's gate; BV_predict is a resampled volume whose
     six faces are overwritten with the constant log(1/D), so its per-pixel maximum is a tie by construction and is not a
     depth estimate): identical, except that a pixel whose two best candidates are closer than 1e-3 in the ORACLE's own
     volume may flip (fp32 summation order of ~70 conv layers decides it; the reference's CPU and GPU executions differ
-    there too) — such flips are counted, printed and bounded by 1 per 1,000 pixels (measured: 0 at S and on every
-    reference-generated fixture, <= 6 of 12,288 at K, <= 2 of 49,152 at B)."""
+    there too) — such flips are counted, printed and bounded by MAX_TIE_FLIPS per frame.
+    `max_abs`: bound on max|d| (BV_predict: a trilinear resample is a convex combination, so with the SAME coordinates on
+    both sides — the pose inverse is a path kernel mirrored in the oracle — it cannot differ by more than the DPV it
+    resamples does)."""
     got, want = got[0].cpu().numpy(), want[0].numpy()
     mx, mean, mism = report(name, got, want)
+    if max_abs is not None:
+        assert mx <= max_abs, "%s: max|d| %.3e > %.3e" % (name, mx, max_abs)
     if mean >= L1_TOL and fp64 is not None:
         # two independent fp32 evaluations may differ by more than 1e-4 where the K-Net amplifies rounding noise (config S:
         # x4, oracle/gen_golden.py::gen_fp64_S); then the yardstick is exact arithmetic: the GPU result must be no further
@@ -71,7 +79,7 @@ def _check(name, got, want, argmax=True, fp64=None, oracle_err=None):
         if mism:
             print("[parity] %s: %d arg-max flips, %d of them NOT ties within 1e-3 in the oracle" % (name, mism, real))
         assert real == 0, "%s: %d arg-max depth indices differ beyond a tie" % (name, real)
-        assert mism <= max(2, got[0].size // 1000), "%s: %d arg-max flips" % (name, mism)
+        assert mism <= MAX_TIE_FLIPS, "%s: %d arg-max flips" % (name, mism)
     return mx
 
 
@@ -80,6 +88,9 @@ CASES = {
     "S": (256, 384, 64, 0.1, 5.0, "scannet", (101, 102)),
     "K": (256, 768, 64, 1.0, 60.0, "kitti", (111, 112)),
     "H128": (256, 256, 128, 0.1, 5.0, "scannet", (121, 122)),
+    # the TRUE headline and high-resolution grids (round 3; the oracle frames cost ~35 s / ~25 s of CPU)
+    "B": (768, 1024, 64, 0.1, 5.0, "scannet", (131, 132)),
+    "H": (480, 640, 128, 0.1, 5.0, "scannet", (141, 142)),
 }
 
 
@@ -95,13 +106,14 @@ def test_two_frames_vs_oracle_at_config(cid):
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     o1 = ko.step(sd, *windows[0], cam, d_candi, 10.0, None)
     o2 = ko.step(sd, *windows[1], cam, d_candi, 10.0, o1[3])
-    _check("config %s BV_cur f1" % cid, bv1, o1[2])
-    _check("config %s BV_predict f1" % cid, p1, o1[3], argmax=False)
+    m_bv1 = _check("config %s BV_cur f1" % cid, bv1, o1[2])
+    # BV_predict of frame 1 resamples BV_cur, of frame 2 the DPV: max|d| bounded by what it resamples (+ a few ulps of 1e3)
+    _check("config %s BV_predict f1" % cid, p1, o1[3], argmax=False, max_abs=m_bv1 + 2e-4)
     _check("config %s BV_cur f2" % cid, bv2, o2[2])
     f64 = dict(np.load(os.path.join(GOLDEN, "net_fp64_S.npz"))) if cid == "S" else None
-    _check("config %s DPV f2" % cid, dpv2, o2[1], fp64=None if f64 is None else f64["dpv_f2"],
-           oracle_err=None if f64 is None else float(f64["oracle_err_mean_sub_dpv_f2"]))
-    _check("config %s BV_predict f2" % cid, p2, o2[3], argmax=False)
+    m_dpv = _check("config %s DPV f2" % cid, dpv2, o2[1], fp64=None if f64 is None else f64["dpv_f2"],
+                   oracle_err=None if f64 is None else float(f64["oracle_err_mean_sub_dpv_f2"]))
+    _check("config %s BV_predict f2" % cid, p2, o2[3], argmax=False, max_abs=m_dpv + 2e-4)
 
 
 def test_costvol_c67_vs_reference_golden():

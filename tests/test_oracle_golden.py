@@ -70,8 +70,12 @@ def test_whole_path_two_frames(golden_net):
     cam, d_candi, sd = _net_setup(n)
     assert abs(gen_golden.checksum(sd.values()) - float(g["weights_checksum"])) < 1e-6 * float(g["weights_checksum"])
     w1, w2 = (synth.noise_window(s, n["H"], n["W"]) for s in n["seeds"])
-    o1 = ko.step(sd, *w1, cam, d_candi, n["sigma"], None)
-    o2 = ko.step(sd, *w2, cam, d_candi, n["sigma"], o1[3])
+    import os
+    from conftest import GOLDEN
+    inv = np.load(os.path.join(GOLDEN, "pose_inv_ref.npz"))["net_inv"]
+    # (1) with the matrices the reference's own `.inverse()` produced (host LAPACK, stored): everything as before
+    o1 = ko.step(sd, *w1, cam, d_candi, n["sigma"], None, rel_extM=inv[0])
+    o2 = ko.step(sd, *w2, cam, d_candi, n["sigma"], o1[3], rel_extM=inv[1])
     checks = [("BV_cur f1", o1[2][0], g["bv_cur_f1"], 2e-4), ("BV_predict f1", o1[3][0], g["pred_f1"], 2e-4),
               ("DPV f2", o2[1][0], g["dpv_f2"], 5e-4), ("BV_predict f2", o2[3][0], g["pred_f2"], 5e-4)]
     for name, got, want, tol in checks:
@@ -79,6 +83,18 @@ def test_whole_path_two_frames(golden_net):
         assert mx < tol and mean < 1e-4 and mism == 0
     assert (o2[0][0].argmax(0).numpy() != g["refined_f2_argmax"]).sum() == 0
     assert np.abs(o2[0][0, :, ::4, ::4].numpy() - g["refined_f2_sub"]).max() < 1e-4
+    # (2) with the path's own inverse (fixed operation order, what the product and the oracle run by default): it differs
+    # from the LAPACK result in the last bits, which moves every resampling coordinate by ~1e-7 — BV_predict follows with
+    # the DPV's slope.  Depth estimates (arg-max of BV_cur / DPV / refined) are unchanged; BV_predict's own arg-max is a tie
+    # by construction (border faces = log(1/D)) and is not compared.
+    p1 = ko.step(sd, *w1, cam, d_candi, n["sigma"], None)
+    p2 = ko.step(sd, *w2, cam, d_candi, n["sigma"], p1[3])
+    for name, got, want, tol in (("BV_predict f1", p1[3][0], g["pred_f1"], 1e-3), ("DPV f2", p2[1][0], g["dpv_f2"], 1e-3),
+                                 ("BV_predict f2", p2[3][0], g["pred_f2"], 1e-3)):
+        mx, mean, mism = report("oracle/own inverse " + name, got.numpy(), want)
+        assert mx < tol and mean < 1e-4
+    assert (p2[1][0].argmax(0).numpy() != g["dpv_f2"].argmax(0)).sum() == 0
+    assert (p2[0][0].argmax(0).numpy() != g["refined_f2_argmax"]).sum() == 0
 
 
 def test_rendered_scene(golden_scene):
@@ -195,3 +211,23 @@ def test_winograd_restatement_and_weight_stream_layout():
         for co, ci, kd, xi in ((0, 0, 0, 0), (17, 5, KD - 1, 6), (Cout - 1, Cin - 1, 0, 15), (33, 18, KD // 2, 9)):
             got = stream[wino_ref.packed_index(co, ci, kd, xi, Cin, KD)]
             assert abs(got - np.float32(U[co, ci, kd, xi])) <= 1e-6 * max(1.0, abs(U[co, ci, kd, xi])), (shape, co, ci, kd, xi)
+
+
+def test_pose_inverse_is_the_rounded_float64_inverse():
+    """oracle_pose_inverse: fp64 Gauss-Jordan with partial pivoting, rounded to fp32 — within half an fp32 ulp of the exact
+    inverse (the reference's `.inverse()`, test_utils/test_KVNet.py:50, is host LAPACK in fp32: ~4x further away)."""
+    rng = np.random.RandomState(3)
+    T = np.stack([synth.random_pose(rng, 0.6, 2.0) for _ in range(500)]).astype(np.float32)
+    T[250:] += (rng.standard_normal((250, 4, 4)) * 1e-2).astype(np.float32)
+    got = co.pose_inverse(T)
+    ex = np.linalg.inv(T.astype(np.float64))
+    ulp = np.spacing(np.abs(ex).astype(np.float32))
+    assert (np.abs(got - ex) <= 0.5000001 * ulp).all()
+    assert (got != ex.astype(np.float32)).mean() < 1e-3          # only double-rounding cases may differ from RN(exact)
+    ref = torch.from_numpy(T).inverse().numpy()                   # LAPACK fp32 on this host: a few ulps from exact
+    assert np.abs(got - ref).max() < 2e-5 and np.abs(got - ex).max() <= np.abs(ref - ex).max()
+    perm = np.eye(4, dtype=np.float32)[[2, 0, 3, 1]]
+    assert np.array_equal(co.pose_inverse(perm), perm.T)
+    import pytest
+    with pytest.raises(np.linalg.LinAlgError):
+        co.pose_inverse(np.zeros((4, 4), np.float32))

@@ -78,3 +78,76 @@ def test_homography_terms_order_is_what_torch_cpu_executes_here():
         want_KR = torch.stack([K.matmul(poses[v, :3, :3]) for v in range(4)]).reshape(4, 9).numpy()
         want_Kt = torch.stack([K.matmul(poses[v, :3, 3]) for v in range(4)]).numpy()
         assert np.array_equal(KR, want_KR) and np.array_equal(Kt, want_Kt)
+
+
+def test_pose_inverse_vs_live_reference_inverse():
+    """test_utils/test_KVNet.py:50 `Src_CamPoses[ibatch, t_win_r].inverse()` runs on the host LAPACK (MKL sgetrf + sgetrs of
+    the transposed matrix under torch 2.10: its LU is reproducible — right-looking fma chain, reciprocal scaling — its
+    triangular solves are not), so unlike K.R_v it cannot be pinned bit for bit.  What is pinned: the path's inverse
+    (oracle_pose_inverse == nrgbd_pose_inverse, fp64 Gauss-Jordan rounded to fp32) is within the reference's OWN rounding
+    error of the reference's result, and closer to the exact inverse than the reference is."""
+    rng = np.random.RandomState(77)
+    worst_ours, worst_ref, worst_gap = 0.0, 0.0, 0.0
+    for _ in range(500):
+        T = synth.random_pose(rng, 0.3, 1.0).astype(np.float32)
+        ref = torch.from_numpy(T).inverse().numpy()
+        ours = co.pose_inverse(T)
+        ex = np.linalg.inv(T.astype(np.float64))
+        e_ref, e_ours = np.abs(ref - ex).max(), np.abs(ours - ex).max()
+        worst_ours, worst_ref = max(worst_ours, e_ours), max(worst_ref, e_ref)
+        worst_gap = max(worst_gap, np.abs(ours - ref).max())
+        assert np.abs(ours - ref).max() <= e_ref + e_ours + 1e-12
+    print("[parity] pose inverse: |ours - exact| max %.2e, |reference - exact| max %.2e, |ours - reference| max %.2e" %
+          (worst_ours, worst_ref, worst_gap))
+    assert worst_ours <= worst_ref and worst_gap < 4e-6
+
+
+def test_predict_with_path_inverse_vs_live_reference_predict():
+    """The whole PREDICT step (inverse + resample + clamp) of the oracle against the reference's, on a peaked DPV: the two
+    differ ONLY through the last bits of the inverse (the resample itself is bit-identical given T, test_ops_fresh_shapes).
+    Mean stays far below 1e-4; the max is the DPV's slope times ~1e-7 of coordinate and is printed."""
+    ref = ref_shim.load()
+    h, w, D = 48, 64, 64
+    cam = camera.scannet_intrinsics(w, h)
+    d_candi = np.linspace(0.1, 5, D)
+    rng = np.random.RandomState(31)
+    dpv = torch.log_softmax(torch.from_numpy(rng.standard_normal((1, D, h, w)).astype(np.float32)) * 6, 1)
+    pad = math.log(1. / D)
+    worst = 0.0
+    for _ in range(5):
+        pose = torch.from_numpy(synth.random_pose(rng, 0.05, 0.2).astype(np.float32))
+        want = ref.homography.resample_vol_cuda(dpv, pose.inverse(), cam_intrinsic=cam, d_candi=d_candi, padding_value=pad) \
+            .clamp(max=0, min=-1000.).numpy()
+        got = co.dpv_resample(dpv[0].numpy(), co.pose_inverse(pose.numpy()), cam["unit_ray_array_2D"].numpy(), d_candi,
+                              math.tan(math.radians(cam["hfov"]) * .5), math.tan(math.radians(cam["vfov"]) * .5), pad)
+        mx, mean, _ = report("oracle PREDICT (own inverse) vs ref", got, want)
+        worst = max(worst, mx)
+        assert mean < 1e-4 and mx < 2e-2
+
+
+def test_resample_with_new_candidates_vs_live_reference():
+    """resample_vol_cuda(..., d_candi_new=...) — the LBA driver's form (test_KVNet_LBA.py:414-417): output planes at the NEW
+    candidates, z normalised by the source candidates' float64 range.  Bit-identical like the d_candi_new=None form."""
+    ref = ref_shim.load()
+    h, w, D, Dn = 20, 28, 12, 9
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(8)
+    d_candi, d_new = np.linspace(0.3, 8, D), np.linspace(0.5, 6.5, Dn)
+    dpv = torch.log_softmax(torch.from_numpy(rng.standard_normal((1, D, h, w)).astype(np.float32)) * 4, 1)
+    T = torch.from_numpy(synth.random_pose(rng, 0.05, 0.2).astype(np.float32)).inverse()
+    pad = math.log(1. / D)
+    want = ref.homography.resample_vol_cuda(dpv, T, cam_intrinsic=cam, d_candi=d_candi, d_candi_new=d_new,
+                                            padding_value=pad).numpy()
+    # the reference allocates D point planes and fills the first Dn: the rest sample the origin (d = 0)
+    d_pad = np.concatenate([d_new, np.zeros(D - Dn)])
+    got = co.dpv_resample(dpv[0].numpy(), T.numpy(), cam["unit_ray_array_2D"].numpy(), d_candi,
+                          math.tan(math.radians(cam["hfov"]) * .5), math.tan(math.radians(cam["vfov"]) * .5), pad,
+                          clamp=None, d_candi_new=d_pad)
+    assert got.shape == (D, h, w) and np.array_equal(got, want)
+    # the LBA call itself: d_candi_new = d_candi (same planes, but the float64 z range)
+    want = ref.homography.resample_vol_cuda(dpv, T, cam_intrinsic=cam, d_candi=d_candi, d_candi_new=d_candi,
+                                            padding_value=pad).numpy()
+    got = co.dpv_resample(dpv[0].numpy(), T.numpy(), cam["unit_ray_array_2D"].numpy(), d_candi,
+                          math.tan(math.radians(cam["hfov"]) * .5), math.tan(math.radians(cam["vfov"]) * .5), pad,
+                          clamp=None, d_candi_new=d_candi)
+    assert np.array_equal(got, want)

@@ -75,7 +75,7 @@ def main():
         "warpvol": (lambda: ops.warp_volume(tex[:V, :, :, 64:], (hw * 68, 1, w * 68, 68), tex[V, :, :, 64:],
                                             (1, w * 68, 68), KR, Kt, rays, d_dev, cx, cy, V, 3, h, w, bv_cur=bv, bv_pred=bv),
                     4 * ((V + 1) * 3 * hw + 2 * D * hw + 16 * D * hw)),
-        "resample": (lambda: ops.dpv_resample(bv, torch.linalg.inv(poses[2]), rays, d_dev, 0.55, 0.42, 2.55, 2.45, -4.16),
+        "resample": (lambda: ops.dpv_resample(bv, ops.pose_inverse(poses[2].contiguous()), rays, d_dev, 0.55, 0.42, 2.55, 2.45, -4.16),
                      8 * D * hw),
         "softmax": (lambda: ops.logsoftmax_d(bv, bv), 12 * D * hw),
     }
