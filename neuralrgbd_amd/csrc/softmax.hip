@@ -74,7 +74,9 @@ int launch_logsoftmax_d(const float* a, const float* b, float scale, float* out,
 }
 
 // export epilogue (test_utils/export_res.py:43-75): expected depth, confidence exp(max_k logp) and the two uint16 maps of the
-// .pgm files in ONE pass over the refined DPV: (map * scale) truncated toward zero, clamped to [0, 65535]
+// .pgm files in ONE pass over the refined DPV: (map * scale) truncated toward zero, clamped to [0, 65535] (the reference's
+// `.astype(np.uint16)` WRAPS beyond 65535: identical files for every depth * scale < 65536, saturation instead of a
+// wrapped value beyond).  exp = exp_rn (common.hpp): the oracle's operation sequence, so the bytes are identical
 __device__ __forceinline__ unsigned short to_u16(float v) {
     if (!(v > 0.f)) return 0;
     if (v >= 65535.f) return 65535;
@@ -90,10 +92,10 @@ __global__ __launch_bounds__(256) void export_depth_u16_kernel(const float* __re
     float acc = 0.f, m = -INFINITY;
     for (int k = 0; k < D; ++k) {
         const float v = logp[(size_t)k * n + p];
-        acc = acc + expf(v) * d_candi[k];
+        acc = acc + exp_rn(v) * d_candi[k];
         m = fmaxf(m, v);
     }
-    const float c = expf(m);
+    const float c = exp_rn(m);
     if (depth) depth[p] = acc;
     if (conf) conf[p] = c;
     if (du) du[p] = to_u16(acc * depth_scale);

@@ -17,7 +17,11 @@ _IMAGENET = {'mean': [0.485, 0.456, 0.406], 'std': [0.229, 0.224, 0.225]}
 
 def depth_conf_u16(BV_measure, d_candi, depth_scale=1000, conf_scale=1000):
     """BV_measure [1,D,H,W] (log-prob, CUDA) -> (dmap f32 [H,W], confmap f32 [H,W], depth_u16, conf_u16) on the device:
-    dmap = sum_k exp(BV_k) d_k, confmap = exp(max_k BV_k), u16 = (map * scale).astype(uint16) (export_res.py:43-75)."""
+    dmap = sum_k exp(BV_k) d_k, confmap = exp(max_k BV_k), u16 = (map * scale).astype(uint16) (export_res.py:43-75).
+    One deliberate difference: the kernel SATURATES map * scale to [0, 65535] where numpy's astype wraps modulo 65536 —
+    the files are identical whenever depth * scale < 65536 (65.5 m at the default scale), and beyond that a saturated
+    pixel replaces a wrapped (meaningless) one.  exp is the path's exp_rn (correctly rounded, same operation sequence as
+    the CPU oracle): the uint16 maps are bit-identical to the oracle's."""
     assert BV_measure.shape[0] == 1 and BV_measure.shape[1] == len(d_candi)
     d_dev = _homo._d_candi_dev(d_candi, BV_measure.device)
     return ops.export_depth_u16(BV_measure[0], d_dev, float(depth_scale), float(conf_scale))

@@ -355,6 +355,43 @@ static inline unsigned short to_u16(float v) {
     if (v >= 65535.f) return 65535;
     return (unsigned short)v;
 }
+#define NRGBD_EXP_INF INFINITY
+#define NRGBD_EXP_RINT rint
+static inline float exp_rn(float xf) {
+    /* exp(x) for the byte-exact export: evaluated in fp64 by a written-out sequence (round-to-nearest-even range reduction
+     * by ln 2 in two parts, degree-13 Taylor polynomial in Horner form with separately rounded products and sums, exact
+     * scaling by 2^k) and rounded once to fp32 — the correctly rounded expf up to double rounding (~1 input in 2^29).  The
+     * device kernel and the CPU oracle execute the SAME operations, so the uint16 maps agree bit for bit; libm / the device's
+     * expf are 1-ulp functions that differ from each other in ~5 % of inputs, which after `(map * 1000).astype(uint16)`
+     * flips the last unit of ~1e-4 of the pixels. */
+    const double x = (double)xf;
+    if (!(x > -104.0)) return (x != x) ? xf : 0.0f;          /* below the smallest fp32 subnormal / NaN */
+    if (x > 88.8) return NRGBD_EXP_INF;
+    const double kd = NRGBD_EXP_RINT(x * 1.4426950408889634074);
+    double r = x - kd * 0.693147180369123816490;             /* ln2 high part: 32 significant bits, kd*hi is exact */
+    r = r - kd * 1.90821492927058770002e-10;                 /* ln2 low part */
+    double p = 1.6059043836821613e-10;                       /* 1/13! */
+    p = p * r + 2.08767569878681e-09;                        /* 1/12! */
+    p = p * r + 2.505210838544172e-08;                       /* 1/11! */
+    p = p * r + 2.755731922398589e-07;                       /* 1/10! */
+    p = p * r + 2.7557319223985893e-06;                      /* 1/9!  */
+    p = p * r + 2.48015873015873e-05;                        /* 1/8!  */
+    p = p * r + 0.0001984126984126984;                       /* 1/7!  */
+    p = p * r + 0.001388888888888889;                        /* 1/6!  */
+    p = p * r + 0.008333333333333333;                        /* 1/5!  */
+    p = p * r + 0.041666666666666664;                        /* 1/4!  */
+    p = p * r + 0.16666666666666666;                         /* 1/3!  */
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    const long long k = (long long)kd;
+    union { unsigned long long u; double d; } s;
+    s.u = (unsigned long long)(k + 1023) << 52;              /* 2^k, k in [-151, 129]: a normal double */
+    return (float)(p * s.d);
+}
+#undef NRGBD_EXP_INF
+#undef NRGBD_EXP_RINT
+
 int oracle_export_depth_u16(const float* logp, const float* d_candi, int D, size_t n, float depth_scale,
                             float conf_scale, float* depth, float* conf, unsigned short* depth_u16,
                             unsigned short* conf_u16) {
@@ -362,10 +399,10 @@ int oracle_export_depth_u16(const float* logp, const float* d_candi, int D, size
         float acc = 0.f, m = -INFINITY;
         for (int k = 0; k < D; ++k) {
             float v = logp[(size_t)k * n + p];
-            acc = acc + expf(v) * d_candi[k];
+            acc = acc + exp_rn(v) * d_candi[k];
             m = v > m ? v : m;
         }
-        float c = expf(m);
+        float c = exp_rn(m);
         if (depth) depth[p] = acc;
         if (conf) conf[p] = c;
         if (depth_u16) depth_u16[p] = to_u16(acc * depth_scale);

@@ -470,8 +470,15 @@ def test_export_epilogue_vs_reference_files_and_oracle(tmp_path):
     depth, conf, du, cu = export_res.depth_conf_u16(bv.to(DEV), d_candi)
     assert np.abs(depth.cpu().numpy() - g["depth"]).max() < 1e-5 and np.abs(conf.cpu().numpy() - g["conf"]).max() < 1e-6
     du_n, cu_n = du.cpu().numpy(), cu.cpu().numpy()
+    # vs the reference's files: <= 1 LSB on a handful of pixels (torch.exp = sleef's 1-ulp expf and ATen's cascade sum there,
+    # exp_rn and the sequential sum here; tests/test_oracle_golden.py has the count for the oracle) ...
     assert (np.abs(du_n.astype(np.int32) - g["depth_u16"].astype(np.int32)) > 1).sum() == 0
-    assert (du_n != g["depth_u16"]).mean() < 2e-3 and (cu_n != g["conf_u16"]).mean() < 2e-3
+    nd, nc = int((du_n != g["depth_u16"]).sum()), int((cu_n != g["conf_u16"]).sum())
+    print("[parity] export u16 vs the reference's .pgm files: depth %d / conf %d of %d pixels differ by 1 LSB" % (nd, nc, du_n.size))
+    assert nd <= 4 and nc <= 4
+    # ... and BIT-IDENTICAL to the oracle (bytes are bytes: same exp_rn operation sequence, same sequential sum)
+    _, _, du_o, cu_o = co.export_depth_u16(bv[0].numpy(), d_candi)
+    assert np.array_equal(du_n, du_o) and np.array_equal(cu_n, cu_o)
     export_res.export_res_img({"img": img}, bv.to(DEV), d_candi, str(tmp_path), 7)
     assert np.array_equal(np.array(image.open(str(tmp_path / "d_00007.pgm"))).astype(np.uint16), du_n)
     assert np.array_equal(np.array(image.open(str(tmp_path / "conf_00007.pgm"))).astype(np.uint16), cu_n)
@@ -482,8 +489,13 @@ def test_export_epilogue_vs_reference_files_and_oracle(tmp_path):
     from neuralrgbd_amd import ops
     dg, cg, dug, cug = ops.export_depth_u16(big.to(DEV), _dev(d64))
     do, co_, duo, cuo = co.export_depth_u16(big.numpy(), d64)
-    assert np.abs(dg.cpu().numpy() - do).max() < 2e-6
-    assert (dug.cpu().numpy() != duo).mean() < 1e-4 and (cug.cpu().numpy() != cuo).mean() < 1e-4
+    assert np.array_equal(dg.cpu().numpy(), do) and np.array_equal(cg.cpu().numpy(), co_)
+    assert np.array_equal(dug.cpu().numpy(), duo) and np.array_equal(cug.cpu().numpy(), cuo)
+    # the whole fp32 range of exp_rn incl. subnormal results, through the D = 1 form of the kernel (depth = exp(x) * 1)
+    x = np.concatenate([np.linspace(-104.5, 0, 300001), np.linspace(0, 89, 50001), [-np.inf, np.inf, np.nan]]).astype(np.float32)
+    dg, _, _, _ = ops.export_depth_u16(_dev(x[None]), _dev(np.ones(1)))
+    do, _, _, _ = co.export_depth_u16(x[None], np.ones(1))
+    assert np.array_equal(dg.cpu().numpy(), do, equal_nan=True)
 
 
 def test_pose_inverse_bit_exact_vs_oracle():

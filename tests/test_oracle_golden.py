@@ -186,9 +186,16 @@ def test_export_epilogue_vs_reference_files():
     bv, _, d_candi = gen_golden.export_inputs()
     depth, conf, du, cu = co.export_depth_u16(bv[0].numpy(), d_candi)
     assert np.abs(depth - g["depth"]).max() < 1e-5 and np.abs(conf - g["conf"]).max() < 1e-6
-    # truncation of (map * 1000): a last-ulp difference of the fp32 sum flips a value only when it sits on an integer
+    # `(map * 1000).astype(uint16)` truncates: a last-ulp difference of the fp32 map flips a value only when map * 1000 sits
+    # within that ulp of an integer.  The reference's map comes from torch.exp (sleef expf, a 1-ulp function) and torch.sum
+    # (ATen's cascade order); the path's from exp_rn (correctly rounded, written out) and the sequential sum of
+    # depth_val_regression (misc.py:540-546).  Exact counts, printed; measured on this fixture: 0 and 0 of 960 pixels (round 2's expf-based path: <= 1 LSB on 0.2 %):
+    nd, nc = int((du != g["depth_u16"]).sum()), int((cu != g["conf_u16"]).sum())
+    print("[parity] export u16 vs the reference's .pgm files: depth %d / conf %d of %d pixels differ (all by 1 LSB)" %
+          (nd, nc, du.size))
     assert (np.abs(du.astype(np.int32) - g["depth_u16"].astype(np.int32)) > 1).sum() == 0
-    assert (du != g["depth_u16"]).mean() < 2e-3 and (cu != g["conf_u16"]).mean() < 2e-3
+    assert (np.abs(cu.astype(np.int32) - g["conf_u16"].astype(np.int32)) > 1).sum() == 0
+    assert nd <= 4 and nc <= 4
 
 
 def test_winograd_restatement_and_weight_stream_layout():
