@@ -58,16 +58,21 @@ class GradAllReduce:
     persistent flat fp32 buffer and the parameters' `.grad` are views into it, so autograd accumulates straight into the
     message (no per-step torch.cat / scatter-back copies).  Buckets are filled in reverse registration order — the order
     backward produces gradients — and a bucket's all-reduce (sum, asynchronous) is launched from a post-accumulate hook
-    the moment its last gradient lands, i.e. while backward is still running on the earlier layers; `__call__()` (after
-    backward) launches whatever did not fire (parameters unused in the step contribute zeros, so every rank issues the
-    same collectives), waits, and divides by the world size.  Few large buckets: xGMI is point-to-point and a ring
-    all-reduce is per-link bound (21.15 MB of fp32 gradient -> one or two messages at the default 32 MB).
+    once its last gradient has landed AND every earlier bucket has been launched, i.e. while backward is still running on
+    the earlier layers; `__call__()` (after backward) launches whatever did not fire (parameters unused in the step
+    contribute zeros), waits, and divides by the world size.
+    Collective ORDER is the same on every rank by construction: buckets are only ever launched in index order 0, 1, 2, ...
+    — a rank whose step leaves a sub-network unused (train() decides `valid_dpv(BVs_predict)` per rank: one rank may skip
+    the K-Net while another runs it) simply stops launching from hooks at the first incomplete bucket and issues the rest
+    from `__call__()`, in the same order as its peers; sizes are fixed at construction.  Few large buckets: xGMI is
+    point-to-point and a ring all-reduce is per-link bound — 21.15 MB of fp32 gradient -> four messages at the default
+    6 MB, so that the first three travel under the rest of backward.
 
     Use:  reducer.prepare(); loss.backward(); reducer(); optimizer.step()
     (`prepare` re-attaches the views — optimizers' zero_grad(set_to_none=True) drops them — and zeroes the buffers.)
     """
 
-    def __init__(self, module, bucket_mb=32.0, overlap=True):
+    def __init__(self, module, bucket_mb=6.0, overlap=True):
         seen, self.params = set(), []
         for p in module.parameters():
             if p.requires_grad and p.data_ptr() not in seen:
@@ -115,7 +120,9 @@ class GradAllReduce:
             p.grad = self._views[p]
         self._pending = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
+        self._next = 0                             # first bucket not launched yet: launches happen in index order only
         self.launched_in_backward = 0
+        self.launch_order = []                     # (bucket, "hook" | "call") of the last step, for tests / debugging
 
     def _launch(self, bi):
         if self._work[bi] is None and self._active():
@@ -129,9 +136,14 @@ class GradAllReduce:
             self._views[p].copy_(p.grad)
             p.grad = self._views[p]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and self.overlap and self._active():
-            self._launch(bi)
-            self.launched_in_backward += 1
+        if self.overlap and self._active():
+            # in index order only: a complete bucket behind an incomplete one waits (for __call__ at the latest), so that
+            # every rank issues the same sequence of collectives whatever sub-networks its step used
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next)
+                self.launch_order.append((self._next, "hook"))
+                self.launched_in_backward += 1
+                self._next += 1
 
     def __call__(self):
         if not self._active():
@@ -141,8 +153,10 @@ class GradAllReduce:
             if p.grad is not None and p.grad is not self._views[p] and self._work[self._bucket_of[p]] is None:
                 self._views[p].copy_(p.grad)
                 p.grad = self._views[p]
-        for bi in range(len(self.buckets)):
+        for bi in range(self._next, len(self.buckets)):
             self._launch(bi)
+            self.launch_order.append((bi, "call"))
+        self._next = len(self.buckets)
         for bi, w in enumerate(self._work):
             w.wait()
             self.flat[bi].div_(world)

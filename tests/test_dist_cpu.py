@@ -150,3 +150,65 @@ def test_gradient_allreduce_on_the_real_kvnet_parameter_set():
         assert abs(a["sums"][step] - (1.5 + step) * a["numel"]) < 1e-3 * a["numel"]
         assert a["sums"][step] == b["sums"][step]
     assert a["w"] == b["w"]
+
+
+def _uneven_worker(rank, world, port, q):
+    """Default bucket size on the real parameter set; in step 0 rank 1's loss does not touch the K-Net (what train() does
+    when `valid_dpv(BVs_predict)` fails on that rank only), in step 1 every rank uses everything."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    nd.init_from_env("gloo")
+    import neuralrgbd_amd
+    from neuralrgbd_amd import camera
+    cam = camera.scannet_intrinsics(24, 16)
+    d = np.linspace(.1, 5, 64)
+    model = neuralrgbd_amd.KVNET(64, cam, d, 10., 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    torch.manual_seed(0)
+    for p in model.parameters():
+        p.data.normal_(0, 0.1)
+    reducer = nd.GradAllReduce(model)                      # default bucket_mb
+    knet = {id(p) for p in model.kv_net.parameters()}
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    orders, hooks, sums = [], [], []
+    for step in range(2):
+        reducer.prepare()
+        used = [p for p in reducer.params if not (step == 0 and rank == 1 and id(p) in knet)]
+        loss = sum((p * float(rank + 1)).sum() for p in used)
+        loss.backward()
+        reducer()
+        opt.step()
+        orders.append([b for b, _ in reducer.launch_order])
+        hooks.append(reducer.launched_in_backward)
+        sums.append([float(reducer.flat[bi].double().sum()) for bi in range(len(reducer.buckets))])
+    n_knet = sum(p.numel() for p in reducer.params if id(p) in knet)
+    q.put((rank, {"orders": orders, "hooks": hooks, "sums": sums, "n_buckets": len(reducer.buckets), "numel": reducer.numel,
+                  "n_knet": n_knet, "w": float(sum(p.detach().double().sum() for p in reducer.params))}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_order_is_rank_independent_when_a_rank_skips_a_subnetwork():
+    """a bucket's collective may start from a backward hook only after every earlier bucket has started, so
+    two ranks whose steps used different sub-networks still issue the same collectives in the same order (before: the rank
+    that skipped the K-Net deferred that bucket while its peer launched it mid-backward -> mismatched sizes -> hang)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    n = a["n_buckets"]
+    assert n >= 3                                                   # default bucket size: the 21 MB gradient is >= 3 messages
+    for step in range(2):
+        assert a["orders"][step] == b["orders"][step] == list(range(n))
+    assert a["hooks"][0] >= 2 and a["hooks"][1] >= 2 and b["hooks"][1] >= 2     # overlap at the default size
+    assert b["hooks"][0] < a["hooks"][0]                            # rank 1 stopped at the first incomplete bucket in step 0
+    # step 0: d loss / d p = rank + 1, K-Net only on rank 0 -> mean = 1.5 outside the K-Net, 0.5 inside; step 1: 1.5 everywhere
+    want0 = 1.5 * (a["numel"] - a["n_knet"]) + 0.5 * a["n_knet"]
+    assert abs(sum(a["sums"][0]) - want0) < 1e-3 * a["numel"] and a["sums"][0] == b["sums"][0]
+    assert abs(sum(a["sums"][1]) - 1.5 * a["numel"]) < 1e-3 * a["numel"] and a["sums"][1] == b["sums"][1]
+    assert a["w"] == b["w"]
