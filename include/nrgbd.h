@@ -361,6 +361,22 @@ int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu, const flo
                         int N, int H, int W, int Cin, int Cout, int kd, int dilation, void* stream);
 
 /*
+ * nrgbd_conv_wino_dw_f32 — generation 3 of the K-Net's 3x3x3 layers (csrc/wino_dw.hip; models/basic.py:71-94): Winograd in all
+ * three dimensions, F(2x2, 3x3) in the plane and F(2, 3) along the depth axis: 8 fp32 multiplies per output voxel (generation
+ * 2: 12, direct: 27), exact-algorithm fp32.  Same contract as nrgbd_conv_wino_f32 with kd = 3 (x [N = depth][H][W][Cin], fused
+ * prologue, column-major statistics [2*Cout][nrgbd_conv_wino_tiles(N,H,W,1)] for nrgbd_bn_finalize_cm), restricted to N even
+ * and whole 8x16 tiles (H % 8 == 0, W % 16 == 0: every grid of the path); other shapes return NRGBD_E_SHAPE and belong to
+ * nrgbd_conv_wino_f32 — nothing is substituted silently.
+ *   w_wino: [Cout/64][stage = t*(Cin/16) + cb][16 transform points][4 waves][64 lanes][4] floats,
+ *           U_t = sum_kd Gd[t][kd] (G g_kd G^T), Gd = G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]  (nrgbd_conv_wino_dw_pack;
+ *           transposed as in nrgbd_conv_wino_pack)
+ */
+int nrgbd_conv_wino_dw_pack(const float* w, float* w_wino, int Cin, int Cout, int transposed, void* stream);
+int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
+                           int res_relu, float* materialized, const float* w_wino, float* y, float* stats,
+                           int N, int H, int W, int Cin, int Cout, void* stream);
+
+/*
  * R-Net (DPV up-sampler) on the same matrix-core kernel.  Replaces, per layer of models/Refine.py:51-107:
  *   m_submodule.conv2d_leakyRelu (nn.Conv2d 3x3 + bias + LeakyReLU 0.01, :18-27)      mode 0
  *   m_submodule.conv2dTranspose_leakyRelu (nn.ConvTranspose2d k4 s2 p1 + bias + LeakyReLU, :37-45)

@@ -1,0 +1,523 @@
+// wino_dw.hip — the K-Net's 3x3x3 convolutions (models/basic.py:71-94) in the Winograd domain in ALL THREE dimensions:
+// F(2x2, 3x3) in the image plane (as wino_pc.hip) and F(2, 3) along the depth axis on top of it.
+//
+// Why.  wino_pc.hip treats the three depth taps of a 3x3x3 layer as three independent 2-D Winograd problems: 16 multiplies per
+// 2x2 outputs and depth tap, 3 taps -> 12 multiplies per output voxel (direct: 27).  At config B its ten 64 -> 64 layers are
+// 61 % of the frame and run at 66 % of the fp32 matrix peak with the matrix pipe as the critical resource — the only lever left
+// is fewer multiplies.  F(2, 3) along depth produces TWO output slices from FOUR transformed slices: 4 x 16 multiplies per
+// 2x2x2 outputs = 8 per output voxel, 1.5x fewer MFMAs, still exact-algorithm fp32 (only the rounding order differs; measured
+// against float64: mean error 1.3x the 2-D form's, tests/test_gpu_knet.py).
+//
+//   input   d_j = act(x[z0 - 1 + j]),  j = 0..3                      (z0 = first of the two output slices of a tile)
+//   depth   D_0 = d_0 - d_2,  D_1 = d_1 + d_2,  D_2 = d_2 - d_1,  D_3 = d_1 - d_3          (B^T of F(2,3))
+//   plane   V_t = B^T D_t B per 4x4 patch                                                   (as wino_pc.hip)
+//   weights U_t = sum_kd Gd[t][kd] (G g_kd G^T),  Gd = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]  (packed on the device, float64)
+//   product M_t = sum_ci V_t U_t                                                            (the MFMAs: 4 x Cin/16 stages)
+//   output  y[z0] = A^T (M_0 + M_1 + M_2) A,   y[z0 + 1] = A^T (M_1 - M_2 - M_3) A
+//
+// Same persistent producer / consumer organisation, tile geometry, LDS images and weight-stream layout as wino_pc.hip (read its
+// header first); what differs:
+//   * a tile is 8x16 pixels x TWO depth slices; its stage list is t-major: stage s = t * (Cin/16) + cb, so that the consumers'
+//     128 accumulator registers hold ONE M_t at a time;
+//   * consumers: at the end of phase t (its last channel block) the accumulators are inverse-transformed in the plane (A^T . A:
+//     32 values per lane) and folded into the two output slices, which accumulate in two 32 KB LDS stashes (the register file
+//     is full: 128 accumulators + weight ring + operands); phase 2 completes and stores slice z0, phase 3 slice z0+1, each
+//     with its BatchNorm partial statistics;
+//   * producers: a stage needs the depth combination of TWO slices.  The unit of prefetch stays one (slice, channel block):
+//     unit A is normalised / activated and published to the wave's strip exactly as in wino_pc.hip, unit B is activated and
+//     COMBINED with what the strip holds (A +- B: the wave reads back its own words; a wave's LDS operations execute in order),
+//     then the strip is transformed as before.  Each unit has its own register set, refilled for the NEXT stage right after
+//     it was published.
+// Work per pair of output slices: 16 stages (wino_pc: 24); producer publishes 32 (24); plane transforms 16 (24).
+// LDS: 2 x 32 KB V + 4 x 5 KB strips + 2 x 32 KB stash = 148 KB; 8 waves, up to 256 VGPRs each.  (Two V buffers instead of
+// wino_pc's three: the consumers read a stage's first operand after the stage barrier instead of before it — ~0.05 us of
+// exposed LDS latency per stage, the price of the second stash.)
+#include <type_traits>
+
+#include "wino_pc.hpp"
+
+namespace nrgbd {
+
+constexpr int kDwStashWave = 2 * 8 * 64 * 4;   // floats of one consumer wave's stash: [2 output slices][8 words][64 lanes][4]
+constexpr int kDwNBuf = 2;                     // V buffers (wino_pc.hip: 3; the third one's 32 KB hold the second stash here)
+
+struct DwTile { int z0, y0, x0, cg, row0; };   // row0: statistics row of slice z0 (slice z0 + 1: row0 + 1)
+
+__device__ __forceinline__ DwTile dw_decode(int t, const WinoPcArgs& a) {
+    DwTile r;
+    const int ncg = a.Cout >> 6;
+    const int tiles_x = (a.W + kPcTW - 1) / kPcTW;
+    const int row = t / ncg;
+    r.cg = t - row * ncg;
+    t = row;
+    const int npair = a.N >> 1;
+    const int zp = t % npair; t /= npair;       // depth fastest: list neighbours share three of their four input slices
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    r.z0 = 2 * zp;
+    r.y0 = ty * kPcTH; r.x0 = tx * kPcTW;
+    r.row0 = (ty * tiles_x + tx) * a.N + r.z0;
+    return r;
+}
+
+// slices combined by stage phase t: V_t = d[zA] + sign * d[zB]
+__device__ __forceinline__ int dw_zA(int t) { return t == 0 ? -1 : (t == 2 ? 1 : 0); }   // relative to z0: -1, 0, 1, 0
+__device__ __forceinline__ int dw_zB(int t) { return t == 2 ? 0 : (t == 3 ? 2 : 1); }    //                  1, 1, 0, 2
+
+template <bool RES>
+__global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Vb = lds;                                   // [2][16 xi][32 tiles][16]
+    float* rawb = lds + kDwNBuf * kPcV;                // [4 producer waves][4 rows][20 pixels][16]
+    float* stashb = rawb + 4 * kPcRawWave;             // [4 consumer waves][2 slices][8][64][4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = wave & 3;
+    const int ncb = a.Cin / kCB;
+    const int NS = 4 * ncb;                            // stages per tile (pair of slices)
+
+    int first, step, end;
+    {
+        const int G = (int)gridDim.x, b = (int)blockIdx.x;
+        if ((G & 7) == 0) {
+            const int xc = b & 7;
+            first = (int)(((long)a.ntiles * xc) >> 3) + (b >> 3);
+            end = (int)(((long)a.ntiles * (xc + 1)) >> 3);
+            step = G >> 3;
+        } else { first = b; end = a.ntiles; step = G; }
+    }
+    if (first >= end) return;
+    const int count = (end - first + step - 1) / step;
+    const unsigned plane = (unsigned)((size_t)a.H * a.W * a.Cin);
+
+    if (wave >= 4) {
+        // =========================================== consumer: 16 output channels x 16 xi x 32 tiles, one M_t at a time ========
+        const int kq = lane >> 4, jj = lane & 15;
+        f32x4 acc[16][2];
+        const int a0 = pc_slot(0, jj, kq), a1 = pc_slot(0, 16 + jj, kq);
+        const f32x4* wbase = reinterpret_cast<const f32x4*>(a.wp) + wv * 64 + lane;
+        const unsigned lane_yoff = (unsigned)jj + (unsigned)((2 * (kq >> 1)) * a.W + 8 * (kq & 1)) * (unsigned)a.Cout;
+        const size_t wgroup = (size_t)NS * 16 * 256;
+        f32x4* stash0 = reinterpret_cast<f32x4*>(stashb + wv * kDwStashWave) + lane;     // slice z0:     word i at stash0[i * 64]
+        f32x4* stash1 = stash0 + 8 * 64;                                                  // slice z0 + 1
+
+        DwTile tl = dw_decode(first, a);
+        const f32x4* wt = wbase + (size_t)tl.cg * wgroup;
+        f32x4 Bn[kPcNB], An[2][2];
+#pragma unroll
+        for (int b = 0; b < kPcBD; ++b) Bn[b] = wt[b * 256];
+        __syncthreads();                               // producers finish stage 0
+        int buf = 0;
+        float neg1 = -1.f;
+        asm volatile("" : "+v"(neg1));
+        const f32x2 n1 = {neg1, neg1};
+
+        for (int it = 0; it < count; ++it) {
+            const int tnext = first + (it + 1 < count ? it + 1 : it) * step;
+            const DwTile tn = dw_decode(tnext, a);
+            const f32x4* wt_next = wbase + (size_t)tn.cg * wgroup;
+            const int co = tl.cg * 64 + wv * 16 + jj;
+            // one phase = the Cin/16 stages of depth-transform index T (accumulating M_T), then its fold; the four phases are
+            // separate straight-line instantiations so that the accumulators stay in fixed registers
+            auto phase = [&](auto t_tag) __attribute__((always_inline)) {
+                constexpr int T = decltype(t_tag)::value;
+                for (int cb = 0; cb < ncb; ++cb) {
+                    const int s = T * ncb + cb;
+                    const float* Vc = Vb + buf * kPcV;
+                    const int nbuf = buf ^ 1;
+                    An[0][0] = *reinterpret_cast<const f32x4*>(Vc + a0);
+                    An[0][1] = *reinterpret_cast<const f32x4*>(Vc + a1);
+                    const f32x4* wcur = wt + (size_t)s * (16 * 256);
+                    const f32x4* wnx = s + 1 < NS ? wcur + 16 * 256 : wt_next;
+                    auto body = [&](auto first_tag) __attribute__((always_inline)) {
+                        constexpr bool FIRST = decltype(first_tag)::value;
+                        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int xi = 0; xi < 16; ++xi) {
+                            const int cur = xi & 1, nxt = cur ^ 1;
+                            if (xi + 1 < 16) {
+                                An[nxt][0] = *reinterpret_cast<const f32x4*>(Vc + a0 + (xi + 1) * (kPcTiles * kCB));
+                                An[nxt][1] = *reinterpret_cast<const f32x4*>(Vc + a1 + (xi + 1) * (kPcTiles * kCB));
+                            }
+                            Bn[(xi + kPcBD) % kPcNB] = xi + kPcBD < 16 ? wcur[(xi + kPcBD) * 256] : wnx[(xi + kPcBD - 16) * 256];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[cur][0][e], Bn[xi % kPcNB][e],
+                                                                                  FIRST && e == 0 ? zero4 : acc[xi][0], 0, 0, 0);
+                                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[cur][1][e], Bn[xi % kPcNB][e],
+                                                                                  FIRST && e == 0 ? zero4 : acc[xi][1], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    };
+                    if (cb == 0) body(std::true_type{}); else body(std::false_type{});
+                    __syncthreads();
+                    buf = nbuf;
+                }
+                // ---- end of phase t: plane inverse transform of M_t (A^T . A) and the depth fold
+                //   y[z0]     = M_0 + M_1 + M_2      (LDS stash 0; complete after phase 2)
+                //   y[z0 + 1] = M_1 - M_2 - M_3      (LDS stash 1; complete after phase 3)
+                // (in registers the 32 running values of a slice do not fit beside 128 accumulators + weight ring + operands: the
+                //  compiler spilled them to scratch INSIDE the MFMA blocks, i.e. into the in-order queue of the weight loads)
+                // lane (kq, jj): output channel co = 16 wv + jj; register r of row block m = Winograd tile 16 m + 4 kq + r = tile
+                // row 2m + (kq >> 1), tile column 4 (kq & 1) + r; word (m, rp, aa) = output row 2 (tile row) + aa, tiles r = 2rp
+                // (.x of a pair) and 2rp + 1 (.y), columns 2 (tile column) + {0: o0, 1: o1}
+                {
+                    constexpr bool EMIT = T >= 2;
+                    const int zs = tl.z0 + (T == 3 ? 1 : 0);
+                    float* ybase = a.y + (((size_t)zs * a.H + tl.y0) * a.W + tl.x0) * a.Cout + tl.cg * 64 + wv * 16;
+                    f32x2 S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                        for (int rp = 0; rp < 2; ++rp) {
+                            f32x2 tr[2][4];
+#pragma unroll
+                            for (int xx = 0; xx < 4; ++xx) {
+                                const f32x2 m0 = rp ? acc[0 + xx][m].hi : acc[0 + xx][m].lo, m1 = rp ? acc[4 + xx][m].hi : acc[4 + xx][m].lo;
+                                const f32x2 m2 = rp ? acc[8 + xx][m].hi : acc[8 + xx][m].lo, m3 = rp ? acc[12 + xx][m].hi : acc[12 + xx][m].lo;
+                                tr[0][xx] = (m0 + m1) + m2;
+                                tr[1][xx] = __builtin_elementwise_fma(m3, n1, __builtin_elementwise_fma(m2, n1, m1));   // (m1 - m2) - m3
+                            }
+#pragma unroll
+                            for (int aa = 0; aa < 2; ++aa) {
+                                const int wi = (m * 2 + rp) * 2 + aa;
+                                f32x2 o0 = (tr[aa][0] + tr[aa][1]) + tr[aa][2];
+                                f32x2 o1 = __builtin_elementwise_fma(tr[aa][3], n1, __builtin_elementwise_fma(tr[aa][2], n1, tr[aa][1]));
+                                if constexpr (T == 0) {
+                                    stash0[wi * 64] = __builtin_shufflevector(o0, o1, 0, 1, 2, 3);
+                                } else if constexpr (T == 1) {
+                                    const f32x4 o = __builtin_shufflevector(o0, o1, 0, 1, 2, 3);
+                                    stash0[wi * 64] = stash0[wi * 64] + o;
+                                    stash1[wi * 64] = o;
+                                } else if constexpr (T == 2) {
+                                    const f32x4 o = __builtin_shufflevector(o0, o1, 0, 1, 2, 3);
+                                    const f32x4 b = stash1[wi * 64];
+                                    stash1[wi * 64] = b - o;
+                                    const f32x4 y = stash0[wi * 64] + o;
+                                    o0 = y.lo; o1 = y.hi;
+                                } else {
+                                    const f32x4 o = __builtin_shufflevector(o0, o1, 0, 1, 2, 3);
+                                    const f32x4 y = stash1[wi * 64] - o;
+                                    o0 = y.lo; o1 = y.hi;
+                                }
+                                if constexpr (EMIT) {
+                                    float* oa = ybase + ((size_t)(4 * m + aa) * a.W + (size_t)(2 * (2 * rp))) * a.Cout;       // tile r = 2 rp
+                                    float* ob = ybase + ((size_t)(4 * m + aa) * a.W + (size_t)(2 * (2 * rp + 1))) * a.Cout;   // tile r + 1
+                                    oa[lane_yoff] = o0.x; oa[lane_yoff + a.Cout] = o1.x;
+                                    ob[lane_yoff] = o0.y; ob[lane_yoff + a.Cout] = o1.y;
+                                    S1 = (S1 + o0) + o1;
+                                    S2 = __builtin_elementwise_fma(o1, o1, __builtin_elementwise_fma(o0, o0, S2));
+                                }
+                            }
+                            // one (m, rp) group at a time: left to itself the scheduler interleaves all four groups and the 8 stash
+                            // words, and the register file (128 accumulators + ring + operands live here) overflows into scratch
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if constexpr (EMIT) {
+                        if (a.stats) {   // the wave owns its 16 channels: reduce over the 4 lanes (kq) that share a channel
+                            float s1 = S1.x + S1.y, s2 = S2.x + S2.y;
+                            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+                            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                            if (kq == 0) {
+                                const int row = tl.row0 + (T == 3 ? 1 : 0);
+                                a.stats[(size_t)co * a.rows + row] = s1;
+                                a.stats[(size_t)(a.Cout + co) * a.rows + row] = s2;
+                            }
+                        }
+                    }
+                }
+            };
+            phase(std::integral_constant<int, 0>{});
+            phase(std::integral_constant<int, 1>{});
+            phase(std::integral_constant<int, 2>{});
+            phase(std::integral_constant<int, 3>{});
+            tl = tn;
+            wt = wt_next;
+        }
+    } else {
+        // =========================================== producer: tile row pw (8 Winograd tiles) ===========================
+        const int pw = wv;
+        float* raw = rawb + pw * kPcRawWave;
+        const int w4 = lane & 3;
+        auto item_rr = [&](int u) { return ((lane + 64 * u) >> 2) / 18; };
+        auto item_cp = [&](int u) { const int pi = (lane + 64 * u) >> 2; return pi - (pi / 18) * 18; };
+        auto item_col = [&](int u) { const int cp = item_cp(u); return cp < 9 ? 2 * cp : 2 * cp - 17; };
+        int wr_off[kPcNPF];
+#pragma unroll
+        for (int u = 0; u < kPcNPF; ++u) {
+            const int item = lane + 64 * u, e = (item - kPcItems) >> 2;
+            wr_off[u] = item < kPcItems ? (item_rr(u) * kPcRawW + item_cp(u)) * kCB + w4 * 4
+                                        : ((e >> 1) * kPcRawW + 18 + (e & 1)) * kCB + w4 * 4;
+        }
+        const int tword = lane & 3, txl = ((lane >> 5) << 2) | ((lane >> 2) & 3), thalf = (lane >> 4) & 1;
+        const int ttile = pw * 8 + txl;
+        const int rdc = txl * kCB + tword * 4;
+        const int rdR0 = (thalf ? 2 : 0) * kPcRawW * kCB + rdc, rdR1 = (thalf ? 1 : 2) * kPcRawW * kCB + rdc,
+                  rdR2 = (thalf ? 3 : 1) * kPcRawW * kCB + rdc;
+        const float sg = thalf ? -1.f : 1.f;
+        float m1 = -1.f;
+        asm volatile("" : "+v"(m1));
+
+        unsigned cur_off[kPcNPF], cur_own = 0, nxt_off[kPcNPF], nxt_own = 0;   // BYTE offsets inside a slice
+        float cur_keep[kPcNPF], nxt_keep[kPcNPF];
+        auto setup = [&](const DwTile& tt, unsigned (&b_off)[kPcNPF], float (&b_keep)[kPcNPF], unsigned& b_own) __attribute__((always_inline)) {
+            b_own = 0;
+#pragma unroll
+            for (int u = 0; u < kPcNPF; ++u) {
+                const int rr = item_rr(u), hy = 2 * pw + rr, hx = item_col(u);
+                const int gy = tt.y0 + hy - 1, gx = tt.x0 + hx - 1;
+                const bool in = (lane + 64 * u) < kPcItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                b_off[u] = 4u * (in ? (unsigned)(((size_t)gy * a.W + gx) * a.Cin + w4 * 4) : (unsigned)(w4 * 4));
+                b_keep[u] = in ? 1.f : 0.f;
+                if (in && (rr == 1 || rr == 2) && hx >= 1 && hx <= kPcTW) b_own |= 1u << u;
+            }
+        };
+        struct Regs { f32x4 pre[kPcNPF]; f32x4 prer[RES ? kPcNPF : 1]; f32x4 ss[2]; f32x4 rs[2]; };
+        DwTile tl = dw_decode(first, a), tn = tl;
+        // raw words of one unit = (slice zrel of stage s, channel block of stage s) -> registers
+        auto issue = [&](bool nx, int s, bool unitB, Regs& r) __attribute__((always_inline)) {
+            const int t = s / ncb, cb = s - t * ncb;
+            r.ss[0] = r.ss[1] = r.rs[0] = r.rs[1] = f32x4{1.f, 0.f, 1.f, 0.f};
+            if (a.x_ss) {
+                r.ss[0] = *reinterpret_cast<const f32x4*>(a.x_ss + 2 * (cb * kCB + w4 * 4));
+                r.ss[1] = *reinterpret_cast<const f32x4*>(a.x_ss + 2 * (cb * kCB + w4 * 4) + 4);
+            }
+            if (RES && a.res_ss) {
+                r.rs[0] = *reinterpret_cast<const f32x4*>(a.res_ss + 2 * (cb * kCB + w4 * 4));
+                r.rs[1] = *reinterpret_cast<const f32x4*>(a.res_ss + 2 * (cb * kCB + w4 * 4) + 4);
+            }
+            const int tz = (nx ? tn.z0 : tl.z0) + (unitB ? dw_zB(t) : dw_zA(t));
+            const int z = min(max(tz, 0), a.N - 1);    // clamped: an outside slice is not used when published
+            const size_t base = ((size_t)z * plane + (size_t)(cb * kCB)) * sizeof(float);
+            const char* xb = reinterpret_cast<const char*>(a.x) + base;
+            const char* rb = reinterpret_cast<const char*>(a.res) + base;
+#pragma unroll
+            for (int u = 0; u < kPcNPF; ++u) {
+                const unsigned o = nx ? nxt_off[u] : cur_off[u];
+                r.pre[u] = *reinterpret_cast<const f32x4*>(xb + o);
+                if constexpr (RES) r.prer[u] = *reinterpret_cast<const f32x4*>(rb + o);
+            }
+        };
+        setup(tl, cur_off, cur_keep, cur_own);
+        Regs setA, setB;
+        issue(false, 0, false, setA);
+        issue(false, 0, true, setB);
+        int qbuf = 0;
+        bool has_next = false;
+
+        // normalise / activate one unit and publish it: COMBINE = false: strip = v;  true: strip = strip + sgn * v
+        auto publish = [&](auto comb_tag, Regs& r, int z, int cb, bool wmat, float sgn) __attribute__((always_inline)) {
+            constexpr bool COMBINE = decltype(comb_tag)::value;
+            const f32x2 sc01 = {r.ss[0].x, r.ss[0].z}, sh01 = {r.ss[0].y, r.ss[0].w}, sc23 = {r.ss[1].x, r.ss[1].z}, sh23 = {r.ss[1].y, r.ss[1].w};
+            const f32x2 rc01 = {r.rs[0].x, r.rs[0].z}, rh01 = {r.rs[0].y, r.rs[0].w}, rc23 = {r.rs[1].x, r.rs[1].z}, rh23 = {r.rs[1].y, r.rs[1].w};
+            const f32x2 sg2 = {sgn, sgn};
+            auto group = [&](auto u0_tag, auto u1_tag) __attribute__((always_inline)) {
+                constexpr int U0 = decltype(u0_tag)::value, U1 = decltype(u1_tag)::value, NU = U1 - U0;
+                f32x2 lo[NU], hi[NU];
+                f32x4 old[COMBINE ? NU : 1];
+                if constexpr (COMBINE) {
+                    // the strip words unit A left: this lane wrote them itself (in-order LDS, no barrier); the memory clobber
+                    // keeps the compiler from forwarding the stored registers across the refill instead (20 live VGPRs)
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) old[i] = *reinterpret_cast<const f32x4*>(raw + wr_off[U0 + i]);
+                }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    lo[i] = __builtin_elementwise_fma(r.pre[U0 + i].lo, sc01, sh01);
+                    hi[i] = __builtin_elementwise_fma(r.pre[U0 + i].hi, sc23, sh23);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (a.x_relu) {
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) { lo[i].x = relu1(lo[i].x); lo[i].y = relu1(lo[i].y); hi[i].x = relu1(hi[i].x); hi[i].y = relu1(hi[i].y); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (RES) {
+                    f32x2 ql[NU], qh[NU];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) {
+                        ql[i] = __builtin_elementwise_fma(r.prer[U0 + i].lo, rc01, rh01);
+                        qh[i] = __builtin_elementwise_fma(r.prer[U0 + i].hi, rc23, rh23);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (a.res_relu) {
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) { ql[i].x = relu1(ql[i].x); ql[i].y = relu1(ql[i].y); qh[i].x = relu1(qh[i].x); qh[i].y = relu1(qh[i].y); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) { lo[i] = lo[i] + ql[i]; hi[i] = hi[i] + qh[i]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    const f32x2 kk = {cur_keep[U0 + i], cur_keep[U0 + i]};
+                    lo[i] = lo[i] * kk; hi[i] = hi[i] * kk;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    const int u = U0 + i;
+                    f32x4 v = __builtin_shufflevector(lo[i], hi[i], 0, 1, 2, 3);
+                    if (wmat) {   // the activated input is written once per slice: by the wave that owns the pixel, in phase 1
+                        if ((cur_own >> u) & 1u)
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.mat) + ((size_t)z * plane + (size_t)(cb * kCB)) * sizeof(float) + cur_off[u]) = v;
+                    }
+                    if constexpr (COMBINE) {
+                        const f32x2 cl = __builtin_elementwise_fma(lo[i], sg2, old[i].lo), ch = __builtin_elementwise_fma(hi[i], sg2, old[i].hi);
+                        v = __builtin_shufflevector(cl, ch, 0, 1, 2, 3);
+                    }
+                    *reinterpret_cast<f32x4*>(raw + wr_off[u]) = v;
+                }
+            };
+            if constexpr (RES) {
+                group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+                group(std::integral_constant<int, 3>{}, std::integral_constant<int, kPcNPF>{});
+            } else {
+                group(std::integral_constant<int, 0>{}, std::integral_constant<int, kPcNPF>{});
+            }
+        };
+
+        for (int it = 0; it < count; ++it) {
+            has_next = it + 1 < count;
+            int cb = 0, t = 0;
+            for (int s = 0; s < NS; ++s) {
+                // the book of the next tile is needed by the refills of the tile's last stage
+                if (s == NS - 1 && has_next) { tn = dw_decode(first + (it + 1) * step, a); setup(tn, nxt_off, nxt_keep, nxt_own); }
+                const int zA = tl.z0 + dw_zA(t), zB = tl.z0 + dw_zB(t);
+                const bool zinA = zA >= 0, zinB = zB < a.N;       // zA <= z0 + 1 < N and zB >= z0 >= 0 always hold
+                const bool wmat = a.mat && t == 1 && tl.cg == 0;  // phase 1 publishes slices z0 (unit A) and z0 + 1 (unit B)
+                const bool nx = s + 1 >= NS;
+                // (1) unit A -> strip
+                if (!zinA) {
+#pragma unroll
+                    for (int u = 0; u < kPcNPF; ++u) *reinterpret_cast<f32x4*>(raw + wr_off[u]) = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    publish(std::false_type{}, setA, zA, cb, wmat, 1.f);
+                }
+                if (!nx || has_next) issue(nx, nx ? 0 : s + 1, false, setA);
+                // (2) unit B combined into the strip: V_t = d[zA] + sign d[zB], sign = +1 in phase 1 only
+                if (zinB) publish(std::true_type{}, setB, zB, cb, wmat, t == 1 ? 1.f : -1.f);
+                if (!nx || has_next) issue(nx, nx ? 0 : s + 1, true, setB);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // (3) plane transform B^T d B of this lane's (tile, word): rows (2 of the 4 xi_y), then columns
+                {
+                    f32x4 ya[4], yb[4];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const int co = ((cc & 1) * 9 + (cc >> 1)) * kCB;
+                        const f32x4 R0 = *reinterpret_cast<const f32x4*>(raw + rdR0 + co);
+                        const f32x4 R1 = *reinterpret_cast<const f32x4*>(raw + rdR1 + co);
+                        const f32x4 R2 = *reinterpret_cast<const f32x4*>(raw + rdR2 + co);
+                        ya[cc] = pk_fma_s(R1, m1, R0);
+                        yb[cc] = pk_fma_s(R2, sg, R1);
+                    }
+                    float* Vq = Vb + qbuf * kPcV;
+                    const int xa = (2 * thalf) * 4, xb = (2 * thalf + 1) * 4;
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 0, ttile, tword)) = pk_fma_s(ya[2], m1, ya[0]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 1, ttile, tword)) = pk_add(ya[1], ya[2]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 2, ttile, tword)) = pk_fma_s(ya[1], m1, ya[2]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 3, ttile, tword)) = pk_fma_s(ya[3], m1, ya[1]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 0, ttile, tword)) = pk_fma_s(yb[2], m1, yb[0]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 1, ttile, tword)) = pk_add(yb[1], yb[2]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 2, ttile, tword)) = pk_fma_s(yb[1], m1, yb[2]);
+                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 3, ttile, tword)) = pk_fma_s(yb[3], m1, yb[1]);
+                }
+                __syncthreads();
+                qbuf ^= 1;
+                if (++cb == ncb) { cb = 0; ++t; }
+            }
+            tl = tn;
+#pragma unroll
+            for (int u = 0; u < kPcNPF; ++u) { cur_off[u] = nxt_off[u]; cur_keep[u] = nxt_keep[u]; }
+            cur_own = nxt_own;
+        }
+        __syncthreads();                       // the consumers' last stage
+    }
+}
+
+// w [Cout][Cin][3][3][3] -> U_t = sum_kd Gd[t][kd] (G g_kd G^T) (float64, rounded once) in the kernel's B-operand order
+// [cg][stage = t*ncb + cb][xi][wave][lane = kq*16 + j][e], co = cg*64 + 16*wave + j, ci = cb*16 + 4*kq + e
+__global__ __launch_bounds__(256) void conv_wino_dw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
+                                                                int transposed) {
+    const long total = (long)Cout * Cin * 4 * 16;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    long t = idx;
+    const int e = t & 3; t >>= 2;
+    const int j = t & 15; t >>= 4;
+    const int kq = t & 3; t >>= 2;
+    const int wave = t & 3; t >>= 2;
+    const int xi = t & 15; t >>= 4;
+    const int ncb = Cin / kCB;
+    const int stage = (int)(t % (4 * ncb));
+    const int cg = (int)(t / (4 * ncb));
+    const int td = stage / ncb, cb = stage - td * ncb;
+    const int co = cg * 64 + 16 * wave + j, ci = cb * kCB + 4 * kq + e;
+    const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    const int aa = xi >> 2, bb = xi & 3;
+    double u = 0.0;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+        // transposed: the stored tensor is [Cin][Cout][3][3][3] (this kernel's ci is ITS output channel), taps flipped in every dimension
+        const float* g = transposed ? w + (((size_t)ci * Cout + co) * 3 + (2 - kd)) * 9 : w + (((size_t)co * Cin + ci) * 3 + kd) * 9;
+        double u2 = 0.0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) u2 += G[aa][ky] * (double)g[transposed ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx] * G[bb][kx];
+        u += G[td][kd] * u2;
+    }
+    wp[idx] = (float)u;
+}
+
+}  // namespace nrgbd
+
+extern "C" int nrgbd_conv_wino_dw_pack(const float* w, float* w_wino, int Cin, int Cout, int transposed, void* stream) {
+    using namespace nrgbd;
+    if (!w || !w_wino) return NRGBD_E_NULL;
+    if (Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
+    const long total = (long)Cout * Cin * 4 * 16;
+    hipLaunchKernelGGL(conv_wino_dw_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_wino,
+                       Cin, Cout, transposed);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+extern "C" int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
+                                      int res_relu, float* materialized, const float* w_wino, float* y, float* stats, int N,
+                                      int H, int W, int Cin, int Cout, void* stream) {
+    using namespace nrgbd;
+    if (!x || !w_wino || !y) return NRGBD_E_NULL;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
+    if (N & 1) return NRGBD_E_SHAPE;                                  // pairs of output slices
+    if (H % kPcTH || W % kPcTW) return NRGBD_E_SHAPE;                 // whole 8x16 tiles only (every grid of the path; others: nrgbd_conv_wino_f32)
+    if ((long)N * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;   // 32-bit BYTE offsets in the loader
+    const int rows = nrgbd_conv_wino_tiles(N, H, W, 1);              // statistics rows: one per (8x16 tile, slice) as wino_pc
+    const long nt = (long)(rows / 2) * (Cout / 64);
+    if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
+    WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt, rows,
+                 nullptr, 0, 0};
+    int dev = 0, ncu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return (int)e;
+    if (ncu <= 0) return NRGBD_E_ARG;
+    const int nwg = nt < ncu ? (int)nt : ncu;   // persistent: one workgroup per CU
+    const size_t lds = (size_t)(kDwNBuf * kPcV + 4 * kPcRawWave + 4 * kDwStashWave) * sizeof(float);   // 64 + 20 + 64 KB
+    hipStream_t st = (hipStream_t)stream;
+    if (res) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((conv_wino_dw_kernel<true>), dim3(nwg), dim3(512), lds, st, a);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((conv_wino_dw_kernel<false>), dim3(nwg), dim3(512), lds, st, a);
+    }
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}

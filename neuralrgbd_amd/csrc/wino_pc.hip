@@ -31,89 +31,9 @@
 //   tiles, depth fastest, so the three slices a 3-D tile needs are shared in that XCD's L2), so a tile's epilogue and the
 //   next tile's first loads overlap with the producers' run-ahead instead of being exposed at every workgroup boundary.
 // LDS: 3 x 32 KB V + 4 x 5 KB raw strips = 116 KB (one workgroup per CU; 2 waves per SIMD, up to 256 VGPRs each).
-#include <type_traits>
-
-#include "conv_tile.hpp"
+#include "wino_pc.hpp"
 
 namespace nrgbd {
-
-constexpr int kPcTH = 8, kPcTW = 16;            // output pixels of a tile, in units of the dilation lattice
-constexpr int kPcTiles = 32;                    // Winograd tiles per workgroup tile: ty = tile >> 3, tx = tile & 7
-constexpr int kPcRawW = 20;                     // raw strip row pitch in pixels (18 used; a multiple of 4 keeps a row's bank map)
-constexpr int kPcRawWave = 4 * kPcRawW * kCB;   // floats of one producer wave's 4-row strip (5 KB)
-constexpr int kPcV = 16 * kPcTiles * kCB;       // floats of one V buffer [16 xi][32 tiles][16] (32 KB)
-constexpr int kPcNBuf = 3;
-constexpr int kPcItems = 4 * 18 * 4;            // (row, column, 16-byte word) items of a strip
-constexpr int kPcNPF = (kPcItems + 63) / 64;    // per producer lane and stage (5)
-constexpr int kPcBD = 7, kPcNB = 8;             // weight ring: distance / slots
-
-struct WinoPcArgs {
-    const float* x;       // [N][H][W][Cin] raw input (pre-activation); N = depth slices when KD = 3
-    const float* x_ss;    // [Cin][2] (scale, shift) applied to x, or null
-    const float* res;     // second operand added after activation, or null
-    const float* res_ss;  // [Cin][2] for res, or null
-    float* mat;           // materialised input act(x) + act(res), or null
-    const float* wp;      // Winograd-domain weights [Cout/64][stage = cb*KD + kd][16 xi][4 waves][64 lanes][4]
-    float* y;             // [N][H][W][Cout] raw convolution output
-    float* stats;         // [2*Cout][spatial tiles] (column-major): per-channel sum and sum of squares of y per tile, or null
-    int x_relu, res_relu;
-    int N, H, W, Cin, Cout;
-    int ntiles;           // spatial tiles x Cout/64
-    int rows;             // spatial tiles (statistics rows)
-    const float* bias;    // EPI = 1 (R-Net form): [Cout] added to the output, then LeakyReLU(0.01) if out_lrelu; no statistics
-    int out_lrelu;
-    int abl;              // developer ablation bits, honoured by -DNRGBD_DEV builds only: 1 = producers only, 2 = consumers only,
-                          // 4 = no transform, 8 = no publish, 16 / 32 = s_setprio 2 for the consumers / producers
-};
-
-struct PcTile { int n, y0, x0, py, px, cg, row; };
-
-template <int KD, int DIL>
-__device__ __forceinline__ PcTile pc_decode(int t, const WinoPcArgs& a) {
-    PcTile r;
-    const int ncg = a.Cout >> 6;
-    const int tiles_x = (a.W + kPcTW * DIL - 1) / (kPcTW * DIL), tiles_y = (a.H + kPcTH * DIL - 1) / (kPcTH * DIL);
-    r.row = t / ncg;
-    r.cg = t - r.row * ncg;
-    t = r.row;
-    r.n = 0;
-    if (KD == 3) { r.n = t % a.N; t /= a.N; }   // depth fastest: the three workgroups that read one slice are list neighbours
-    int par = 0;
-    if (DIL > 1) { par = t % (DIL * DIL); t /= DIL * DIL; }
-    const int tx = t % tiles_x; t /= tiles_x;
-    int ty = t;
-    if (KD != 3) { ty = t % tiles_y; r.n = t / tiles_y; }
-    r.py = par / DIL; r.px = par - r.py * DIL;
-    r.y0 = ty * kPcTH * DIL; r.x0 = tx * kPcTW * DIL;
-    return r;
-}
-
-// LDS image of V: [xi*32 + tile][16 floats]; the 16-byte slot s of a tile is stored at slot (s + 2*((tile >> 3) & 1)) & 3, so
-// that every ds_read_b128 service group of the 16x16x4 A-operand pattern hits 16 different bank quads (as in generation 1)
-__device__ __forceinline__ int pc_slot(int xi, int tile, int slot) {
-    return ((xi * kPcTiles + tile) << 4) + (((slot + 2 * ((tile >> 3) & 1)) & 3) << 2);
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Packed fp32 helpers (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two lanes of a register pair per instruction).  The
-// producers' VALU instructions only get the issue slots the co-resident consumer's MFMA stream leaves (measured: about one
-// per MFMA), so every instruction saved there is stage time saved.  a*s + c with a splat s; s = -1 is the exact c - a.
-__device__ __forceinline__ f32x4 pk_fma_s(f32x4 a, float s, f32x4 c) {
-    const f32x2 m = {s, s};
-    const f32x2 lo = __builtin_elementwise_fma(a.lo, m, c.lo), hi = __builtin_elementwise_fma(a.hi, m, c.hi);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-}
-// max(x, 0) as ONE v_max_f32: fmaxf() on a packed-FMA result costs two (the compiler quiets a possible signalling NaN first)
-__device__ __forceinline__ float relu1(float x) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
-    const f32x2 lo = a.lo + b.lo, hi = a.hi + b.hi;
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-}
 
 template <int KD, int DIL, bool RES, bool ODD = false, int EPI = 0>
 __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {

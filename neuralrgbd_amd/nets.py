@@ -97,6 +97,19 @@ def _packed_wino(owner, conv):
     return hit[1]
 
 
+def _packed_wino_dw(owner, conv):
+    """Weight stream of csrc/wino_dw.hip (Winograd along depth as well): U_t = sum_kd G[t][kd] (G g_kd G^T)."""
+    from . import ops
+    cache = owner.__dict__.setdefault("_wp_cache", {})
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device), "wino_dw")
+    hit = cache.get(("wino_dw", id(conv)))
+    if hit is None or hit[0] != key:
+        hit = (key, ops.conv_wino_dw_pack(w.detach().contiguous()))
+        cache[("wino_dw", id(conv))] = hit
+    return hit[1]
+
+
 def _packed_s2(owner, conv):
     """Weight stream of a stride-2 3x3 conv in its space-to-depth form (ops.conv_s2_pack), re-packed only when the weight changes."""
     from . import ops
@@ -581,15 +594,24 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         need_stats = lambda bn: bn.training or not bn.track_running_stats
 
         import os
-        # the ten 64 -> 64 layers in the Winograd domain (wino_pc.hip 3.0 / conv3d_wino.hip 3.3 / conv3d.hip 5.4 ms per layer at
-        # config B, and closer to the float64 result than the direct kernel); NRGBD_KNET=wino1|direct select the others for A/B
-        mode = os.environ.get("NRGBD_KNET", "auto")   # auto = wino_pc.hip | wino64 = only its 64 -> 64 layers | wino1 = conv3d_wino.hip | direct
+        # the ten 64 -> 64 layers in the Winograd domain: wino_dw.hip (round 3: F(2,3) along depth on top of the in-plane
+        # F(2x2,3x3), 8 multiplies per output voxel) where the grid is whole tiles and D is even — every configuration of the
+        # path —, wino_pc.hip (12 multiplies) otherwise.  NRGBD_KNET = wino2 (wino_pc.hip everywhere) | wino64 (only its
+        # 64 -> 64 layers) | wino1 (conv3d_wino.hip) | direct (conv3d.hip) select the older generations for A/B.
+        mode = os.environ.get("NRGBD_KNET", "auto")
         wino = mode != "direct"
+        dw_layers = os.environ.get("NRGBD_KNET_DW", "64")     # which input widths take wino_dw.hip: "64" | "16,64" | ""
+        dw_cin = {int(v) for v in dw_layers.split(",") if v} if mode == "auto" else set()
 
         def run(i, x, x_ss, x_relu, res=None, materialize=False):
             conv, bn = L[i]
             cm = False
-            if wino and conv.in_channels == 64 and mode == "wino1":
+            if (conv.in_channels in dw_cin and conv.out_channels == 64
+                    and ops.conv_wino_dw_supported(D, H, W, conv.in_channels, 64)):
+                y, st, mat = ops.conv_wino_dw(x, _packed_wino_dw(self, conv), 64, x_ss=x_ss, x_relu=x_relu, res=res,
+                                              materialize=materialize, want_stats=need_stats(bn))
+                cm = True
+            elif wino and conv.in_channels == 64 and mode == "wino1":
                 y, st, mat = ops.conv3d_wino(x, self._packed_wino(conv), x_ss=x_ss, x_relu=x_relu, res=res,
                                              materialize=materialize, want_stats=need_stats(bn))
             elif wino and (conv.in_channels == 64 or (conv.in_channels == 16 and res is None and mode != "wino64")):

@@ -420,6 +420,58 @@ def conv_wino(x, w_wino, Cout, kd, dilation=1, x_ss=None, x_relu=False, res=None
     return y, stats, mat
 
 
+def conv_wino_dw_pack(w, transposed=False):
+    """w [Cout, Cin, 3, 3, 3] -> weight stream of nrgbd_conv_wino_dw_f32 (Winograd in depth too): U_t = sum_kd G[t][kd] (G g_kd G^T)
+    in float64, rounded once, laid out [cg][stage = t*(Cin/16) + cb][xi][wave][lane = kq*16 + j][e]."""
+    w = _need(w, "w")
+    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError("conv_wino_dw_pack expects [Cout, Cin, 3, 3, 3], got %s" % (tuple(w.shape),))
+    Cout, Cin = (w.shape[1], w.shape[0]) if transposed else w.shape[:2]
+    if Cout % 64 or Cin % 16:
+        raise ValueError("conv_wino_dw_pack: Cout %% 64 and Cin %% 16 required, got Cout=%d Cin=%d" % (Cout, Cin))
+    wp = torch.empty(Cout * Cin * 4 * 16, dtype=torch.float32, device=w.device)
+    wc = w.detach().contiguous()
+    with torch.cuda.device(w.device):
+        rc = _lib.load().nrgbd_conv_wino_dw_pack(_p(wc), _p(wp), Cin, Cout, int(transposed), _stream(w))
+    _lib.check(rc, "nrgbd_conv_wino_dw_pack")
+    return wp
+
+
+def conv_wino_dw_pack_reference(w):
+    """The same stream through torch (einsum in float64): what the device packer is tested against."""
+    Cout, Cin = w.shape[:2]
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+    U = torch.einsum("tz,ay,oczyx,bx->octab", G, G, w.detach().double(), G).reshape(Cout, Cin, 4, 16)   # [co, ci, t, xi]
+    U = U.reshape(Cout // 64, 4, 16, Cin // 16, 4, 4, 4, 16)    # co -> (cg, wave, j); ci -> (cb, kq, e); t; xi
+    U = U.permute(0, 6, 3, 7, 1, 4, 2, 5).contiguous()          # [cg, t, cb, xi, wave, kq, j, e]
+    return U.to(torch.float32).reshape(-1)
+
+
+def conv_wino_dw_supported(N, H, W, Cin, Cout):
+    """Shapes nrgbd_conv_wino_dw_f32 accepts: pairs of depth slices, whole 8x16 tiles, 32-bit in-plane byte offsets."""
+    return N % 2 == 0 and N >= 2 and H % 8 == 0 and W % 16 == 0 and Cin % 16 == 0 and Cout % 64 == 0 and H * W * Cin < (1 << 30)
+
+
+def conv_wino_dw(x, w_wino, Cout, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False, materialize=False,
+                 want_stats=True):
+    """Channels-last 3x3x3 stride-1 convolution over x [D,H,W,Cin] with Winograd in all three dimensions (wino_dw.hip):
+    -> (y [D,H,W,Cout], stats [2*Cout, tiles] (column-major partials for bn_finalize_cm) | None, materialized | None)."""
+    x = _need(x, "x")
+    N, H, W, Cin = x.shape
+    y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2 * Cout, conv_wino_tiles(N, H, W, 1)), dtype=torch.float32, device=x.device) if want_stats else None
+    mat = torch.empty_like(x) if materialize else None
+    if res is not None:
+        res = _need(res, "res", x.shape)
+    if w_wino.numel() != (Cout // 64) * (Cin // 16) * 4 * 16 * 1024:
+        raise ValueError("conv_wino_dw: packed weights do not match Cin=%d Cout=%d" % (Cin, Cout))
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv_wino_dw_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(mat),
+                                                 _p(w_wino), _p(y), _p(stats), N, H, W, Cin, Cout, _stream(x))
+    _lib.check(rc, "nrgbd_conv_wino_dw_f32")
+    return y, stats, mat
+
+
 def conv3d_wgrad(x, gy):
     """Weight gradient of the channels-last 3x3x3 convolution: x [D,H,W,Cin], gy [D,H,W,64] -> dW [64,Cin,3,3,3]."""
     x = _need(x, "x")

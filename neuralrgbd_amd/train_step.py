@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from . import homography as warp_homo
+from . import ops
 from .misc import depth_val_regression, valid_dpv
 
 

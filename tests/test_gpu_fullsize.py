@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from neuralrgbd_amd import camera, synth
+from neuralrgbd_amd import camera, ops, synth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

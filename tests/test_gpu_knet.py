@@ -267,3 +267,97 @@ def test_conv_wino_pc_3d_first_layer_16_channels(D, H, W):
     s = stats.double().sum(1)
     assert torch.allclose(s[:64], want.sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
     assert torch.allclose(s[64:], (want ** 2).sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
+# ----------------------------------------------------------------------------- generation 3: Winograd along depth as well (wino_dw.hip)
+@pytest.mark.parametrize("D,H,W,Cin", [(4, 16, 32, 64), (2, 8, 16, 64), (8, 24, 48, 64), (40, 40, 80, 64), (64, 8, 16, 64),
+                                       (6, 16, 32, 16), (40, 40, 80, 16), (4, 16, 32, 128)])
+def test_conv_wino_dw_plain_vs_torch(D, H, W, Cin):
+    """F(2x2,3x3) in the plane + F(2,3) along depth (4 x Cin/16 stages per pair of slices) vs F.conv3d in float64, incl. grids with
+    more tile pairs than CUs (persistent walk, ring and prefetch across tiles), a single pair (both depth borders in one tile),
+    the one-stage-per-phase form (Cin = 16) and two channel groups of outputs; statistics rows; generation 2 as the A/B."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(D * 1000 + H + Cin)
+    Cout = 128 if Cin == 128 else 64
+    x = torch.randn(Cin, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    want = F.conv3d(x[None].double(), w.double(), padding=1)[0]
+    assert ops.conv_wino_dw_supported(D, H, W, Cin, Cout)
+    y, stats, _ = ops.conv_wino_dw(_cl(x), ops.conv_wino_dw_pack(w), Cout)
+    err = (y.permute(3, 0, 1, 2).double() - want).abs()
+    scale = want.abs().max().item()
+    y2, _, _ = ops.conv_wino(_cl(x), ops.conv_wino_pack(w), Cout, 3)
+    err2 = (y2.permute(3, 0, 1, 2).double() - want).abs()
+    print("[parity] conv_wino_dw %dx%dx%d Cin=%d: max|d vs fp64| %.3e mean %.3e  (generation 2: %.3e / %.3e; |y|max %.2f)" %
+          (D, H, W, Cin, err.max().item(), err.mean().item(), err2.max().item(), err2.mean().item(), scale))
+    assert err.max().item() < 2e-5 * max(1.0, scale) and err.mean().item() < 2.0 * err2.mean().item() + 1e-9
+    assert stats.shape == (2 * Cout, ops.conv_wino_tiles(D, H, W))
+    s = stats.double().sum(1)
+    assert torch.allclose(s[:Cout], want.sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[Cout:], (want ** 2).sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
+    y3, _, _ = ops.conv_wino_dw(_cl(x), ops.conv_wino_dw_pack(w), Cout)
+    assert torch.equal(y, y3)                                   # deterministic
+
+
+def test_conv_wino_dw_fused_prologue_and_materialize():
+    from neuralrgbd_amd import ops
+    D, H, W, C = 6, 16, 32, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(C, D, H, W, generator=g).to(DEV)
+    r = torch.randn(C, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    ss = torch.randn(C, 2, generator=g).to(DEV)
+    rs = torch.randn(C, 2, generator=g).to(DEV)
+    act = torch.relu(x * ss[:, 0, None, None, None] + ss[:, 1, None, None, None]) \
+        + torch.relu(r * rs[:, 0, None, None, None] + rs[:, 1, None, None, None])
+    want = F.conv3d(act[None], w, padding=1)[0]
+    wp = ops.conv_wino_dw_pack(w)
+    y, _, mat = ops.conv_wino_dw(_cl(x), wp, 64, x_ss=ss, x_relu=True, res=_cl(r), res_ss=rs, res_relu=True, materialize=True)
+    assert (y.permute(3, 0, 1, 2) - want).abs().max().item() < 2e-4
+    assert (mat.permute(3, 0, 1, 2) - act).abs().max().item() < 1e-5
+    act1 = torch.relu(x * ss[:, 0, None, None, None] + ss[:, 1, None, None, None])
+    y1, _, _ = ops.conv_wino_dw(_cl(x), wp, 64, x_ss=ss, x_relu=True)
+    assert (y1.permute(3, 0, 1, 2) - F.conv3d(act1[None], w, padding=1)[0]).abs().max().item() < 2e-4
+    act2 = (x * ss[:, 0, None, None, None] + ss[:, 1, None, None, None]) + r
+    y2, _, _ = ops.conv_wino_dw(_cl(x), wp, 64, x_ss=ss, res=_cl(r))
+    assert (y2.permute(3, 0, 1, 2) - F.conv3d(act2[None], w, padding=1)[0]).abs().max().item() < 2e-4
+    y3, _, _ = ops.conv_wino_dw(_cl(x), wp, 64, x_ss=ss, res=_cl(r))
+    assert torch.equal(y2, y3)
+
+
+def test_conv_wino_dw_pack_and_shape_contract():
+    """Device packer == torch einsum reference (incl. the data-gradient form); unsupported shapes are refused, not substituted."""
+    from neuralrgbd_amd import _lib, ops
+    g = torch.Generator().manual_seed(13)
+    for shape in ((64, 64, 3, 3, 3), (64, 16, 3, 3, 3), (128, 128, 3, 3, 3)):
+        w = torch.randn(*shape, generator=g).to(DEV)
+        a, b = ops.conv_wino_dw_pack(w), ops.conv_wino_dw_pack_reference(w)
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-7 * b.abs().max().item(), shape
+        if shape[1] % 64 == 0:
+            t = ops.conv_wino_dw_pack(w, transposed=True)
+            r = ops.conv_wino_dw_pack_reference(w.transpose(0, 1).flip(2, 3, 4).contiguous())
+            assert (t - r).abs().max().item() <= 1e-7 * r.abs().max().item(), ("transposed", shape)
+    w = ops.conv_wino_dw_pack(torch.randn(64, 64, 3, 3, 3, generator=g).to(DEV))
+    for (D, H, W) in ((5, 16, 32), (4, 13, 32), (4, 16, 24)):
+        assert not ops.conv_wino_dw_supported(D, H, W, 64, 64)
+        with pytest.raises(_lib.NrgbdError):
+            ops.conv_wino_dw(torch.zeros(D, H, W, 64, device=DEV), w, 64)
+
+
+def test_knet_stack_dw_vs_generation_2(monkeypatch):
+    """The whole K-Net on wino_dw.hip (default) vs the same stack on wino_pc.hip: same graph, rounding order only."""
+    from neuralrgbd_amd import nets
+    torch.manual_seed(0)
+    net = nets.KalmanGainNet(16, feature_dim=64).to(DEV)
+    vol = torch.randn(8, 16, 32, 16, device=DEV)
+    with torch.no_grad():
+        monkeypatch.setenv("NRGBD_KNET", "wino2")
+        a = net.forward_channels_last(vol)
+        monkeypatch.setenv("NRGBD_KNET", "auto")
+        b = net.forward_channels_last(vol)
+        monkeypatch.setenv("NRGBD_KNET_DW", "16,64")
+        c = net.forward_channels_last(vol)
+    print("[parity] K-Net stack: dw vs generation 2 max|d| %.3e (|gain| max %.2f); first layer on dw too: %.3e" %
+          ((a - b).abs().max().item(), a.abs().max().item(), (a - c).abs().max().item()))
+    assert (a - b).abs().max().item() < 2e-4 * max(1.0, a.abs().max().item())
+    assert (a - c).abs().max().item() < 2e-4 * max(1.0, a.abs().max().item())
