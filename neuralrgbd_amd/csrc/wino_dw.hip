@@ -30,8 +30,9 @@
 //     it was published.
 // Work per pair of output slices: 16 stages (wino_pc: 24); producer publishes 32 (24); plane transforms 16 (24).
 // LDS: 2 x 32 KB V + 4 x 5 KB strips + 2 x 32 KB stash = 148 KB; 8 waves, up to 256 VGPRs each.  (Two V buffers instead of
-// wino_pc's three: the consumers read a stage's first operand after the stage barrier instead of before it — ~0.05 us of
-// exposed LDS latency per stage, the price of the second stash.)
+// wino_pc's three — the third one's 32 KB hold the second stash.  A consumer therefore cannot read the first operand of the
+// next stage before the stage barrier; instead it ARRIVES at the barrier early, as soon as its last LDS operand of the stage is
+// in registers, and reads the next stage's first operand under its own last 8 MFMAs.)
 #include <type_traits>
 
 #include "wino_pc.hpp"
@@ -39,6 +40,7 @@
 namespace nrgbd {
 
 constexpr int kDwStashWave = 2 * 8 * 64 * 4;   // floats of one consumer wave's stash: [2 output slices][8 words][64 lanes][4]
+constexpr int kDwMaxCin = 512;                 // (scale, shift) tables of x and res live in LDS: 2 x 2 x Cin floats
 constexpr int kDwNBuf = 2;                     // V buffers (wino_pc.hip: 3; the third one's 32 KB hold the second stash here)
 
 struct DwTile { int z0, y0, x0, cg, row0; };   // row0: statistics row of slice z0 (slice z0 + 1: row0 + 1)
@@ -63,18 +65,31 @@ __device__ __forceinline__ DwTile dw_decode(int t, const WinoPcArgs& a) {
 __device__ __forceinline__ int dw_zA(int t) { return t == 0 ? -1 : (t == 2 ? 1 : 0); }   // relative to z0: -1, 0, 1, 0
 __device__ __forceinline__ int dw_zB(int t) { return t == 2 ? 0 : (t == 3 ? 2 : 1); }    //                  1, 1, 0, 2
 
-template <bool RES>
+// RES: a second operand (res) is added after activation.  MAT: the activated input is also written out (a.mat).  MAT is a
+// template parameter because of what its stores do to the OTHER variants: with loads and stores of one wave both pending the
+// compiler cannot rely on in-order completion and turns every s_waitcnt on a prefetched register into vmcnt(0) — which also
+// waits for the refill issued a few instructions earlier, i.e. exposes a full memory latency per stage.
+// RSID: the residual operand comes with identity (scale, shift) and no ReLU (the K-Net's four residual layers: a materialised
+// skip tensor) — its normalisation FMAs are dropped.
+template <bool RES, bool MAT, bool RSID>
 __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Vb = lds;                                   // [2][16 xi][32 tiles][16]
     float* rawb = lds + kDwNBuf * kPcV;                // [4 producer waves][4 rows][20 pixels][16]
     float* stashb = rawb + 4 * kPcRawWave;             // [4 consumer waves][2 slices][8][64][4]
+    float* ssl = stashb + 4 * kDwStashWave;            // [Cin][2] (scale, shift) of x, then [Cin][2] of res
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wv = wave & 3;
     const int ncb = a.Cin / kCB;
     const int NS = 4 * ncb;                            // stages per tile (pair of slices)
+#ifdef NRGBD_DEV
+    const int abl = a.abl;   // developer ablations (results invalid): 1 no MFMAs, 2 no producer work, 4 no transform, 8 no publish A,
+                             // 16 no publish B, 32 no refills, 64 no fold
+#else
+    constexpr int abl = 0;
+#endif
 
     int first, step, end;
     {
@@ -89,6 +104,14 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
     if (first >= end) return;
     const int count = (end - first + step - 1) / step;
     const unsigned plane = (unsigned)((size_t)a.H * a.W * a.Cin);
+    // The per-channel (scale, shift) pairs go to LDS once (identity where the pointer is null).  Loading a stage's pairs from
+    // global memory with its raw words — as wino_pc.hip does — puts them FIRST in the refill's queue, and the compiler moves them
+    // into their home registers immediately: an s_waitcnt right behind the loads, i.e. one exposed L2 round trip per unit.
+    for (int i = tid; i < 2 * a.Cin; i += 512) {
+        ssl[i] = a.x_ss ? a.x_ss[i] : ((i & 1) ? 0.f : 1.f);
+        ssl[2 * a.Cin + i] = (RES && a.res_ss) ? a.res_ss[i] : ((i & 1) ? 0.f : 1.f);
+    }
+    __syncthreads();
 
     if (wave >= 4) {
         // =========================================== consumer: 16 output channels x 16 xi x 32 tiles, one M_t at a time ========
@@ -108,6 +131,8 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
         for (int b = 0; b < kPcBD; ++b) Bn[b] = wt[b * 256];
         __syncthreads();                               // producers finish stage 0
         int buf = 0;
+        An[0][0] = *reinterpret_cast<const f32x4*>(Vb + a0);
+        An[0][1] = *reinterpret_cast<const f32x4*>(Vb + a1);
         float neg1 = -1.f;
         asm volatile("" : "+v"(neg1));
         const f32x2 n1 = {neg1, neg1};
@@ -125,8 +150,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                     const int s = T * ncb + cb;
                     const float* Vc = Vb + buf * kPcV;
                     const int nbuf = buf ^ 1;
-                    An[0][0] = *reinterpret_cast<const f32x4*>(Vc + a0);
-                    An[0][1] = *reinterpret_cast<const f32x4*>(Vc + a1);
+                    const float* Vn = Vb + nbuf * kPcV;
                     const f32x4* wcur = wt + (size_t)s * (16 * 256);
                     const f32x4* wnx = s + 1 < NS ? wcur + 16 * 256 : wt_next;
                     auto body = [&](auto first_tag) __attribute__((always_inline)) {
@@ -148,10 +172,24 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                                                                                   FIRST && e == 0 ? zero4 : acc[xi][1], 0, 0, 0);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
+                            if (xi == 14) {
+                                // EARLY stage barrier: the last LDS operands of this stage (xi = 15) are in registers, so the wave
+                                // can let the producers overwrite this V buffer already — and read the first operand of the next
+                                // stage (complete once the barrier is passed) under its own last 8 MFMAs.  With two V buffers this
+                                // hides the LDS latency a third buffer hides in wino_pc.hip.
+                                __syncthreads();
+                                An[0][0] = *reinterpret_cast<const f32x4*>(Vn + a0);
+                                An[0][1] = *reinterpret_cast<const f32x4*>(Vn + a1);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     };
-                    if (cb == 0) body(std::true_type{}); else body(std::false_type{});
-                    __syncthreads();
+                    if (!(abl & 1)) { if (cb == 0) body(std::true_type{}); else body(std::false_type{}); }
+                    else {
+                        __syncthreads();
+                        An[0][0] = *reinterpret_cast<const f32x4*>(Vn + a0);
+                        An[0][1] = *reinterpret_cast<const f32x4*>(Vn + a1);
+                    }
                     buf = nbuf;
                 }
                 // ---- end of phase t: plane inverse transform of M_t (A^T . A) and the depth fold
@@ -162,7 +200,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                 // lane (kq, jj): output channel co = 16 wv + jj; register r of row block m = Winograd tile 16 m + 4 kq + r = tile
                 // row 2m + (kq >> 1), tile column 4 (kq & 1) + r; word (m, rp, aa) = output row 2 (tile row) + aa, tiles r = 2rp
                 // (.x of a pair) and 2rp + 1 (.y), columns 2 (tile column) + {0: o0, 1: o1}
-                {
+                if (!(abl & 64)) {
                     constexpr bool EMIT = T >= 2;
                     const int zs = tl.z0 + (T == 3 ? 1 : 0);
                     float* ybase = a.y + (((size_t)zs * a.H + tl.y0) * a.W + tl.x0) * a.Cout + tl.cg * 64 + wv * 16;
@@ -277,16 +315,13 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
         struct Regs { f32x4 pre[kPcNPF]; f32x4 prer[RES ? kPcNPF : 1]; f32x4 ss[2]; f32x4 rs[2]; };
         DwTile tl = dw_decode(first, a), tn = tl;
         // raw words of one unit = (slice zrel of stage s, channel block of stage s) -> registers
-        auto issue = [&](bool nx, int s, bool unitB, Regs& r) __attribute__((always_inline)) {
-            const int t = s / ncb, cb = s - t * ncb;
-            r.ss[0] = r.ss[1] = r.rs[0] = r.rs[1] = f32x4{1.f, 0.f, 1.f, 0.f};
-            if (a.x_ss) {
-                r.ss[0] = *reinterpret_cast<const f32x4*>(a.x_ss + 2 * (cb * kCB + w4 * 4));
-                r.ss[1] = *reinterpret_cast<const f32x4*>(a.x_ss + 2 * (cb * kCB + w4 * 4) + 4);
-            }
-            if (RES && a.res_ss) {
-                r.rs[0] = *reinterpret_cast<const f32x4*>(a.res_ss + 2 * (cb * kCB + w4 * 4));
-                r.rs[1] = *reinterpret_cast<const f32x4*>(a.res_ss + 2 * (cb * kCB + w4 * 4) + 4);
+        auto issue = [&](bool nx, int t, int cb, bool unitB, Regs& r) __attribute__((always_inline)) {
+            r.rs[0] = r.rs[1] = f32x4{1.f, 0.f, 1.f, 0.f};
+            r.ss[0] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4));
+            r.ss[1] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4) + 4);
+            if constexpr (RES && !RSID) {
+                r.rs[0] = *reinterpret_cast<const f32x4*>(ssl + 2 * a.Cin + 2 * (cb * kCB + w4 * 4));
+                r.rs[1] = *reinterpret_cast<const f32x4*>(ssl + 2 * a.Cin + 2 * (cb * kCB + w4 * 4) + 4);
             }
             const int tz = (nx ? tn.z0 : tl.z0) + (unitB ? dw_zB(t) : dw_zA(t));
             const int z = min(max(tz, 0), a.N - 1);    // clamped: an outside slice is not used when published
@@ -302,14 +337,19 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
         };
         setup(tl, cur_off, cur_keep, cur_own);
         Regs setA, setB;
-        issue(false, 0, false, setA);
-        issue(false, 0, true, setB);
+        issue(false, 0, 0, false, setA);
+        issue(false, 0, 0, true, setB);
         int qbuf = 0;
         bool has_next = false;
 
         // normalise / activate one unit and publish it: COMBINE = false: strip = v;  true: strip = strip + sgn * v
-        auto publish = [&](auto comb_tag, Regs& r, int z, int cb, bool wmat, float sgn) __attribute__((always_inline)) {
+        auto publish = [&](auto comb_tag, auto interior_tag, Regs& r, int z, int cb, bool wmat, float sgn) __attribute__((always_inline)) {
             constexpr bool COMBINE = decltype(comb_tag)::value;
+            constexpr bool INTERIOR = decltype(interior_tag)::value;   // every item of every lane inside the image: no padding mask
+            // the (scale, shift) words are re-paired for the packed FMAs HERE and not where they were loaded: without this the
+            // compiler hoists the eight moves to right behind the loads, i.e. waits for the prefetch the moment it is issued
+            asm volatile("" : "+v"(r.ss[0]), "+v"(r.ss[1]));
+            if constexpr (RES && !RSID) asm volatile("" : "+v"(r.rs[0]), "+v"(r.rs[1]));
             const f32x2 sc01 = {r.ss[0].x, r.ss[0].z}, sh01 = {r.ss[0].y, r.ss[0].w}, sc23 = {r.ss[1].x, r.ss[1].z}, sh23 = {r.ss[1].y, r.ss[1].w};
             const f32x2 rc01 = {r.rs[0].x, r.rs[0].z}, rh01 = {r.rs[0].y, r.rs[0].w}, rc23 = {r.rs[1].x, r.rs[1].z}, rh23 = {r.rs[1].y, r.rs[1].w};
             const f32x2 sg2 = {sgn, sgn};
@@ -335,7 +375,11 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                     for (int i = 0; i < NU; ++i) { lo[i].x = relu1(lo[i].x); lo[i].y = relu1(lo[i].y); hi[i].x = relu1(hi[i].x); hi[i].y = relu1(hi[i].y); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (RES) {
+                if constexpr (RES && RSID) {
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) { lo[i] = lo[i] + r.prer[U0 + i].lo; hi[i] = hi[i] + r.prer[U0 + i].hi; }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if constexpr (RES) {
                     f32x2 ql[NU], qh[NU];
 #pragma unroll
                     for (int i = 0; i < NU; ++i) {
@@ -352,17 +396,19 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                     for (int i = 0; i < NU; ++i) { lo[i] = lo[i] + ql[i]; hi[i] = hi[i] + qh[i]; }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (!INTERIOR) {
 #pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    const f32x2 kk = {cur_keep[U0 + i], cur_keep[U0 + i]};
-                    lo[i] = lo[i] * kk; hi[i] = hi[i] * kk;
+                    for (int i = 0; i < NU; ++i) {
+                        const f32x2 kk = {cur_keep[U0 + i], cur_keep[U0 + i]};
+                        lo[i] = lo[i] * kk; hi[i] = hi[i] * kk;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
                     const int u = U0 + i;
                     f32x4 v = __builtin_shufflevector(lo[i], hi[i], 0, 1, 2, 3);
-                    if (wmat) {   // the activated input is written once per slice: by the wave that owns the pixel, in phase 1
+                    if (MAT && wmat) {   // the activated input is written once per slice: by the wave that owns the pixel, in phase 1
                         if ((cur_own >> u) & 1u)
                             *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.mat) + ((size_t)z * plane + (size_t)(cb * kCB)) * sizeof(float) + cur_off[u]) = v;
                     }
@@ -383,28 +429,51 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
 
         for (int it = 0; it < count; ++it) {
             has_next = it + 1 < count;
+            // a tile whose 10x18 halo lies inside the image needs no zero-padding mask (80 % of the tiles at config B)
+            const bool interior = tl.y0 >= 1 && tl.y0 + kPcTH + 1 <= a.H && tl.x0 >= 1 && tl.x0 + kPcTW + 1 <= a.W;
             int cb = 0, t = 0;
             for (int s = 0; s < NS; ++s) {
                 // the book of the next tile is needed by the refills of the tile's last stage
                 if (s == NS - 1 && has_next) { tn = dw_decode(first + (it + 1) * step, a); setup(tn, nxt_off, nxt_keep, nxt_own); }
                 const int zA = tl.z0 + dw_zA(t), zB = tl.z0 + dw_zB(t);
                 const bool zinA = zA >= 0, zinB = zB < a.N;       // zA <= z0 + 1 < N and zB >= z0 >= 0 always hold
-                const bool wmat = a.mat && t == 1 && tl.cg == 0;  // phase 1 publishes slices z0 (unit A) and z0 + 1 (unit B)
+                const bool wmat = MAT && t == 1 && tl.cg == 0;    // phase 1 publishes slices z0 (unit A) and z0 + 1 (unit B)
                 const bool nx = s + 1 >= NS;
+                const int cbn = cb + 1 == ncb ? 0 : cb + 1, tnx = nx ? 0 : (cb + 1 == ncb ? t + 1 : t);   // (t, cb) of stage s + 1
+                if constexpr (MAT) {
+                    // With materialise stores in the queue the compiler cannot count it (loads and stores of one wave pending =
+                    // "may complete out of order" = every wait becomes vmcnt(0)), and the wait for set B would also wait for the
+                    // refill of set A issued just before it.  So BOTH sets are waited for here, at the one point of the stage where
+                    // nothing else is in flight, and passed through an opaque asm: later uses no longer depend on the loads.
+#pragma unroll
+                    for (int u = 0; u < kPcNPF; ++u) {
+                        asm volatile("" : "+v"(setA.pre[u]), "+v"(setB.pre[u]));
+                        if constexpr (RES) asm volatile("" : "+v"(setA.prer[u]), "+v"(setB.prer[u]));
+                    }
+                    asm volatile("" : "+v"(setA.ss[0]), "+v"(setA.ss[1]), "+v"(setB.ss[0]), "+v"(setB.ss[1]));
+                    if constexpr (RES && !RSID) asm volatile("" : "+v"(setA.rs[0]), "+v"(setA.rs[1]), "+v"(setB.rs[0]), "+v"(setB.rs[1]));
+                }
                 // (1) unit A -> strip
-                if (!zinA) {
+                if (abl & (2 | 8)) {
+                } else if (!zinA) {
 #pragma unroll
                     for (int u = 0; u < kPcNPF; ++u) *reinterpret_cast<f32x4*>(raw + wr_off[u]) = f32x4{0.f, 0.f, 0.f, 0.f};
                 } else {
-                    publish(std::false_type{}, setA, zA, cb, wmat, 1.f);
+                    if (interior) publish(std::false_type{}, std::true_type{}, setA, zA, cb, wmat, 1.f);
+                    else publish(std::false_type{}, std::false_type{}, setA, zA, cb, wmat, 1.f);
                 }
-                if (!nx || has_next) issue(nx, nx ? 0 : s + 1, false, setA);
+                // refills are UNCONDITIONAL (the last stage of the last tile re-reads this tile's stage 0: harmless, never used);
+                // a set is refilled right after it was published (longest time to land)
+                if (!(abl & (2 | 32))) issue(nx && has_next, tnx, cbn, false, setA);
                 // (2) unit B combined into the strip: V_t = d[zA] + sign d[zB], sign = +1 in phase 1 only
-                if (zinB) publish(std::true_type{}, setB, zB, cb, wmat, t == 1 ? 1.f : -1.f);
-                if (!nx || has_next) issue(nx, nx ? 0 : s + 1, true, setB);
+                if (zinB && !(abl & (2 | 16))) {
+                    if (interior) publish(std::true_type{}, std::true_type{}, setB, zB, cb, wmat, t == 1 ? 1.f : -1.f);
+                    else publish(std::true_type{}, std::false_type{}, setB, zB, cb, wmat, t == 1 ? 1.f : -1.f);
+                }
+                if (!(abl & (2 | 32))) issue(nx && has_next, tnx, cbn, true, setB);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // (3) plane transform B^T d B of this lane's (tile, word): rows (2 of the 4 xi_y), then columns
-                {
+                if (!(abl & (2 | 4))) {
                     f32x4 ya[4], yb[4];
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
@@ -492,7 +561,7 @@ extern "C" int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_r
                                       int H, int W, int Cin, int Cout, void* stream) {
     using namespace nrgbd;
     if (!x || !w_wino || !y) return NRGBD_E_NULL;
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cin > kDwMaxCin || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
     if (N & 1) return NRGBD_E_SHAPE;                                  // pairs of output slices
     if (H % kPcTH || W % kPcTW) return NRGBD_E_SHAPE;                 // whole 8x16 tiles only (every grid of the path; others: nrgbd_conv_wino_f32)
     if ((long)N * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;   // 32-bit BYTE offsets in the loader
@@ -500,24 +569,27 @@ extern "C" int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_r
     const long nt = (long)(rows / 2) * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
     WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt, rows,
-                 nullptr, 0, 0};
+                 nullptr, 0, dev_env_int("NRGBD_WINO_ABL")};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return (int)e;
     if (ncu <= 0) return NRGBD_E_ARG;
     const int nwg = nt < ncu ? (int)nt : ncu;   // persistent: one workgroup per CU
-    const size_t lds = (size_t)(kDwNBuf * kPcV + 4 * kPcRawWave + 4 * kDwStashWave) * sizeof(float);   // 64 + 20 + 64 KB
+    const size_t lds = (size_t)(kDwNBuf * kPcV + 4 * kPcRawWave + 4 * kDwStashWave + 4 * Cin) * sizeof(float);   // 64 + 20 + 64 KB + tables
     hipStream_t st = (hipStream_t)stream;
-    if (res) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv_wino_dw_kernel<true>), dim3(nwg), dim3(512), lds, st, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv_wino_dw_kernel<false>), dim3(nwg), dim3(512), lds, st, a);
-    }
+#define NRGBD_WINO_DW_LAUNCH(RES_, MAT_, RSID_)                                                                               \
+    do {                                                                                                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw_kernel<RES_, MAT_, RSID_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                        \
+        if (e != hipSuccess) return (int)e;                                                                                   \
+        hipLaunchKernelGGL((conv_wino_dw_kernel<RES_, MAT_, RSID_>), dim3(nwg), dim3(512), lds, st, a);                        \
+    } while (0)
+    const bool rsid = res && !res_ss && !res_relu;
+    if (res && rsid) { if (materialized) NRGBD_WINO_DW_LAUNCH(true, true, true); else NRGBD_WINO_DW_LAUNCH(true, false, true); }
+    else if (res) { if (materialized) NRGBD_WINO_DW_LAUNCH(true, true, false); else NRGBD_WINO_DW_LAUNCH(true, false, false); }
+    else { if (materialized) NRGBD_WINO_DW_LAUNCH(false, true, false); else NRGBD_WINO_DW_LAUNCH(false, false, false); }
+#undef NRGBD_WINO_DW_LAUNCH
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }
