@@ -600,7 +600,7 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         # 64 -> 64 layers) | wino1 (conv3d_wino.hip) | direct (conv3d.hip) select the older generations for A/B.
         mode = os.environ.get("NRGBD_KNET", "auto")
         wino = mode != "direct"
-        dw_layers = os.environ.get("NRGBD_KNET_DW", "64")     # which input widths take wino_dw.hip: "64" | "16,64" | ""
+        dw_layers = os.environ.get("NRGBD_KNET_DW", "16,64")  # which input widths take wino_dw.hip: "16,64" | "64" | ""
         dw_cin = {int(v) for v in dw_layers.split(",") if v} if mode == "auto" else set()
 
         def run(i, x, x_ss, x_relu, res=None, materialize=False):

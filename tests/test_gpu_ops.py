@@ -339,7 +339,11 @@ def test_homography_terms_match_oracle_bitwise():
     (48, 64, 32, 3, 67, "L2", 0.4, 1.0, 19),      # large motions: most taps out of view, planes crossing the camera
     (48, 64, 32, 4, 67, "L2", 0.0, 0.3, 20),      # pure translation 0.3 m: strong zoom on the nearest planes
 ])
-def test_costvol_quad_vs_oracle(h, w, D, V, C, dist, rot, trans, seed):
+@pytest.mark.parametrize("gen", ["quad4", "quad"])
+def test_costvol_quad_vs_oracle(h, w, D, V, C, dist, rot, trans, seed, gen):
+    """gen = quad: generation 3 (the default; a candidate's cost meets its other views in global memory); quad4: generation 4
+    (accumulation in LDS, every output written once — measured slower, kept as the A/B).  Same arithmetic, same order:
+    bit-identical to each other."""
     cam = camera.scannet_intrinsics(w, h)
     rng = np.random.RandomState(seed)
     feat_ref = rng.standard_normal((C, h, w)).astype(np.float32)
@@ -352,15 +356,20 @@ def test_costvol_quad_vs_oracle(h, w, D, V, C, dist, rot, trans, seed):
     co.set_threads(32)
     want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist)
     want_lp = co.logsoftmax_d(want, scale=-1.0)
-    cost, lp = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist, logp=True, generation="quad")
+    cost, lp = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist, logp=True, generation=gen)
     _, lp_only = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist, logp=True,
-                              generation="quad", want_cost=False)     # raw costs parked in out_logp, overwritten in place
+                              generation=gen, want_cost=False)        # generation 3 parks the raw costs in out_logp
     mx, _, _ = report("quad costvol %dx%dx%d V%d C%d %s" % (h, w, D, V, C, dist), -cost, -want)
     assert mx < 1e-5 * max(10.0, float(np.abs(want).max()))
     mx, mean, _ = report("quad BV_cur", lp, want_lp)
     assert mx < 1e-4 and mean < 1e-5
     assert near_tie_mismatches(lp, want_lp, tol=1e-4) == 0
     assert np.array_equal(lp, lp_only)
+    if gen == "quad4":
+        c3, l3 = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist, logp=True, generation="quad")
+        assert np.array_equal(c3, cost) and np.array_equal(l3, lp)
+        c0, l0 = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist, logp=True)   # automatic
+        assert np.array_equal(c0, cost) and np.array_equal(l0, lp)
     if C == 67:   # against generation 2 on the same inputs (independent decomposition of the same arithmetic)
         c2, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, dist=dist, generation="lds")
         assert np.abs(c2 - cost).max() < 1e-5 * max(10.0, float(np.abs(want).max()))
@@ -379,9 +388,10 @@ def test_costvol_quad_align_corners_and_determinism():
     cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
     for align in (False, True):
         want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 3.0, align_corners=align)
-        a, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 3.0, align=align, generation="quad")
-        b, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 3.0, align=align, generation="quad")
-        assert np.array_equal(a, b)                      # no races, no atomics: bitwise reproducible
+        a, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 3.0, align=align, generation="quad4")
+        b, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 3.0, align=align, generation="quad4")
+        c, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 3.0, align=align, generation="quad")
+        assert np.array_equal(a, b) and np.array_equal(a, c)   # no races, no atomics: bitwise reproducible
         assert np.abs(a - want).max() < 1e-5 * max(10.0, float(want.max()))
 
 
