@@ -46,6 +46,7 @@ SIGNATURES = {
     "nrgbd_conv3d_wino_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "nrgbd_conv_wino_tiles": (_I, [_I, _I, _I, _I]),
     "nrgbd_conv_wino_rnet_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_conv_wino_rnet_ex_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "nrgbd_bn_finalize_cm": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P]),
     "nrgbd_conv_wino_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

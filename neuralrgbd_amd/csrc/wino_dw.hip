@@ -569,7 +569,7 @@ extern "C" int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_r
     const long nt = (long)(rows / 2) * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
     WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt, rows,
-                 nullptr, 0, dev_env_int("NRGBD_WINO_ABL")};
+                 nullptr, 0, 0, 0, 0, dev_env_int("NRGBD_WINO_ABL")};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);

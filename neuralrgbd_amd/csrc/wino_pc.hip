@@ -75,7 +75,8 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         f32x4 acc[16][2];                      // written by the first stage of every tile (C operand = 0): never cleared
         const int a0 = pc_slot(0, jj, kq), a1 = pc_slot(0, 16 + jj, kq);   // + xi * 512 floats + buffer
         const f32x4* wbase = reinterpret_cast<const f32x4*>(a.wp) + wv * 64 + lane;
-        const unsigned lane_yoff = (unsigned)jj + (unsigned)((DIL * 2 * (kq >> 1)) * a.W + 8 * (kq & 1) * DIL) * (unsigned)a.Cout;
+        const unsigned ldy = (EPI == 1 && a.ldy) ? (unsigned)a.ldy : (unsigned)a.Cout;   // pixel stride of the output
+        const unsigned lane_yoff = (unsigned)jj + (unsigned)((DIL * 2 * (kq >> 1)) * a.W + 8 * (kq & 1) * DIL) * ldy;
         const size_t wgroup = (size_t)NS * 16 * 256;                        // f32x4 per 64-column output group
 
         PcTile tl = pc_decode<KD, DIL>(first, a);
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
             // 2m + (kq >> 1), tile column 4 (kq & 1) + r: the lane part of an output's address is loop-invariant (lane_yoff),
             // the (m, r, a) part is uniform -> scalar base + 32-bit lane offset stores, no per-store address arithmetic
             const int co = tl.cg * 64 + wv * 16 + jj;
-            float* ybase = a.y + (((size_t)tl.n * a.H + tl.y0 + tl.py) * a.W + tl.x0 + tl.px) * a.Cout + tl.cg * 64 + wv * 16;
+            float* ybase = a.y + (((size_t)tl.n * a.H + tl.y0 + tl.py) * a.W + tl.x0 + tl.px) * ldy + (EPI == 1 ? a.ycoff : 0) + tl.cg * 64 + wv * 16;
+            const bool cok = EPI != 1 || a.cout_valid == 0 || co < a.cout_valid;   // EPI = 1: a padded output column is not stored
             const bool inside = tl.y0 + tl.py + DIL * (kPcTH - 1) < a.H && tl.x0 + tl.px + DIL * (kPcTW - 1) < a.W;
             float s1 = 0.f, s2 = 0.f;
             float bval = 0.f;
@@ -190,10 +192,12 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                                     o0 = __builtin_elementwise_max(o0, o0 * sl); o1 = __builtin_elementwise_max(o1, o1 * sl);
                                 }
                             }
-                            float* oa = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * (2 * rp) * DIL)) * a.Cout;       // tile r = 2 rp
-                            float* ob = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * (2 * rp + 1) * DIL)) * a.Cout;   // tile r + 1
-                            oa[lane_yoff] = o0.x; oa[lane_yoff + DIL * a.Cout] = o1.x;
-                            ob[lane_yoff] = o0.y; ob[lane_yoff + DIL * a.Cout] = o1.y;
+                            float* oa = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * (2 * rp) * DIL)) * ldy;       // tile r = 2 rp
+                            float* ob = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * (2 * rp + 1) * DIL)) * ldy;   // tile r + 1
+                            if (cok) {
+                                oa[lane_yoff] = o0.x; oa[lane_yoff + DIL * ldy] = o1.x;
+                                ob[lane_yoff] = o0.y; ob[lane_yoff + DIL * ldy] = o1.y;
+                            }
                             S1 = (S1 + o0) + o1;
                             S2 = __builtin_elementwise_fma(o1, o1, __builtin_elementwise_fma(o0, o0, S2));
                         }
@@ -220,12 +224,12 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                                 o0 += bval; o1 += bval;
                                 if (a.out_lrelu) { o0 = fmaxf(o0, 0.01f * o0); o1 = fmaxf(o1, 0.01f * o1); }
                             }
-                            float* o = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * r * DIL)) * a.Cout;   // uniform
+                            float* o = ybase + ((size_t)(DIL * (4 * m + aa)) * a.W + (size_t)(2 * r * DIL)) * ldy;   // uniform
                             const int tile = 16 * m + 4 * kq + r;
                             const int gy = tl.y0 + tl.py + DIL * (2 * (tile >> 3) + aa), gx = tl.x0 + tl.px + DIL * (2 * (tile & 7));
-                            if (gy < a.H) {
+                            if (gy < a.H && cok) {
                                 if (gx < a.W) { o[lane_yoff] = o0; s1 += o0; s2 = __builtin_fmaf(o0, o0, s2); }
-                                if (gx + DIL < a.W) { o[lane_yoff + DIL * a.Cout] = o1; s1 += o1; s2 = __builtin_fmaf(o1, o1, s2); }
+                                if (gx + DIL < a.W) { o[lane_yoff + DIL * ldy] = o1; s1 += o1; s2 = __builtin_fmaf(o1, o1, s2); }
                             }
                         }
                     }
@@ -629,7 +633,7 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     const long nt = (long)rows * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
     WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt, rows,
-                 nullptr, 0, dev_env_int("NRGBD_WINO_ABL")};
+                 nullptr, 0, 0, 0, 0, dev_env_int("NRGBD_WINO_ABL")};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -667,17 +671,19 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
 
 // R-Net form (models/m_submodule.py:18-27 conv2d_leakyRelu at widths with Cin % 32 == 0, Cout % 64 == 0: Refine.py:51-56 conv0,
 // conv0_1): 3x3 convolution + bias + LeakyReLU(0.01) in the Winograd domain, no prologue, no statistics
-extern "C" int nrgbd_conv_wino_rnet_f32(const float* x, const float* w_wino, const float* bias, int out_lrelu, float* y, int N,
-                                        int H, int W, int Cin, int Cout, void* stream) {
+extern "C" int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, const float* bias, int out_lrelu, float* y, int N,
+                                           int H, int W, int Cin, int Cout, int ldy, int ycoff, int cout_valid, void* stream) {
     using namespace nrgbd;
     if (!x || !w_wino || !y) return NRGBD_E_NULL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
     if ((long)N * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;
+    if (cout_valid < 0 || cout_valid > Cout || ycoff < 0 || (ldy != 0 && ldy < ycoff + (cout_valid ? cout_valid : Cout))) return NRGBD_E_ARG;
+    if ((long)N * H * W * (ldy ? ldy : Cout) >= (1L << 32)) return NRGBD_E_SHAPE;   // 32-bit lane offsets into a tile's rows only, but keep it sane
     const int rows = nrgbd_conv_wino_tiles(N, H, W, 1);
     const long nt = (long)rows * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
     WinoPcArgs a{x, nullptr, nullptr, nullptr, nullptr, w_wino, y, nullptr, 0, 0, N, H, W, Cin, Cout, (int)nt, rows,
-                 bias, out_lrelu, 0};
+                 bias, out_lrelu, ldy, ycoff, cout_valid, 0};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -691,4 +697,9 @@ extern "C" int nrgbd_conv_wino_rnet_f32(const float* x, const float* w_wino, con
     hipLaunchKernelGGL((conv_wino_pc_kernel<1, 1, false, false, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
+}
+
+extern "C" int nrgbd_conv_wino_rnet_f32(const float* x, const float* w_wino, const float* bias, int out_lrelu, float* y, int N,
+                                        int H, int W, int Cin, int Cout, void* stream) {
+    return nrgbd_conv_wino_rnet_ex_f32(x, w_wino, bias, out_lrelu, y, N, H, W, Cin, Cout, 0, 0, 0, stream);
 }

@@ -33,6 +33,8 @@ struct WinoPcArgs {
     int rows;             // spatial tiles (statistics rows)
     const float* bias;    // EPI = 1 (R-Net form): [Cout] added to the output, then LeakyReLU(0.01) if out_lrelu; no statistics
     int out_lrelu;
+    int ldy, ycoff, cout_valid;   // EPI = 1 only: pixel stride of y (0 = Cout), first output column, columns that exist (0 = Cout):
+                                  // the R-Net writes into concat buffers and pads 67 / 96 outputs to the 64-column groups
     int abl;              // developer ablation bits, honoured by -DNRGBD_DEV builds only: 1 = producers only, 2 = consumers only,
                           // 4 = no transform, 8 = no publish, 16 / 32 = s_setprio 2 for the consumers / producers
 };

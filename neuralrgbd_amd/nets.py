@@ -763,17 +763,16 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         return (D, C0, C1, C2) if ok else None
 
     def mfma_ok(self, dpv):
-        """The R-Net on csrc/conv2d.hip (inference, batch 1 or 2).  NRGBD_RNET = mfma | vendor | auto (default).
-        auto: the matrix-core path when the quarter-resolution grid has >= 64 tiles of 16x16 pixels (configs B and H:
-        79.9 vs 80.8 ms and 63.4 vs 63.8 ms per frame, same box).  Below that its two quarter-resolution layers cannot
-        fill 256 CUs with 16x16-pixel workgroups and MIOpen's Winograd kernels win (config S 14.2 vs 14.4 ms, K equal):
-        those grids, and widths without an instantiation, use the vendor path."""
+        """The R-Net on the hand-written kernels (inference, batch 1 or 2) at EVERY grid (round 3; rounds 1-2 handed grids below
+        64 16x16-tiles — configs S and K — to MIOpen): the six conv2d_leakyRelu layers on the Winograd kernel's R-Net form
+        (csrc/wino_pc.hip, 8x16-pixel tiles of a persistent launch fill the chip at every grid), the transposed convolutions
+        and the log-softmax layer on csrc/conv2d.hip.  NRGBD_RNET=vendor keeps the vendor path as the A/B; widths without an
+        instantiation (D not in {64, 128}) and autograd use it too."""
         import os
         mode = os.environ.get("NRGBD_RNET", "auto")
         if mode == "vendor" or self._widths() is None or not dpv.is_cuda or torch.is_grad_enabled() or dpv.shape[0] not in (1, 2):
             return False
-        tiles = ((dpv.shape[2] + 15) // 16) * ((dpv.shape[3] + 15) // 16)
-        return mode == "mfma" or tiles >= 64
+        return True
 
     def _rnet_packed(self):
         """Per layer a list of output-column slices (packed B-operand stream, padded bias, kernel width, first column,
@@ -784,6 +783,7 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         if cache.get("key") == key:
             return cache["val"]
         pad16 = lambda c: (c + 15) // 16 * 16
+        pad32 = lambda c: (c + 31) // 32 * 32        # pixel width of the concat buffers (a whole number of Winograd stage pairs)
 
         def slices(cout):
             cp = pad16(cout)
@@ -797,7 +797,7 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         def conv(m):
             c = m[0] if isinstance(m, nn.Sequential) else m
             w, b = c.weight.detach(), c.bias.detach()
-            cin_p = pad16(w.shape[1])
+            cin_p = pad32(w.shape[1])                # = the width of the buffer the layer reads (zero weights for its padding)
             res = []
             for c0, wdt, valid in slices(w.shape[0]):
                 wp = w.new_zeros(wdt, cin_p, 3, 3)
@@ -823,14 +823,23 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                           for i in range(len(res[(0, 0)]))]
             return res
 
-        def wino(m):   # Winograd-domain stream of a layer whose widths the persistent kernel covers (conv0, conv0_1 at D + C0 = 128)
+        def wino(m):
+            """Winograd-domain stream of a conv2d_leakyRelu layer for the persistent kernel's R-Net form, widths padded with zero
+            weights to Cin % 32 == 0 (the buffer it reads) and Cout % 64 == 0; (stream, bias, packed columns, valid columns)."""
             c = m[0]
-            if c.in_channels % 32 or c.out_channels % 64 or os.environ.get("NRGBD_RNET_WINO", "1") == "0":
+            if os.environ.get("NRGBD_RNET_WINO", "1") == "0":
                 return None
-            return (ops.conv_wino_pack(c.weight.detach().contiguous()), c.bias.detach().contiguous(), c.out_channels)
+            w, b = c.weight.detach(), c.bias.detach()
+            cin_p, cout_p = pad32(w.shape[1]), (w.shape[0] + 63) // 64 * 64
+            wp = w.new_zeros(cout_p, cin_p, 3, 3)
+            wp[:w.shape[0], :w.shape[1]] = w
+            bp = b.new_zeros(cout_p)
+            bp[:w.shape[0]] = b
+            return (ops.conv_wino_pack(wp.contiguous()), bp.contiguous(), cout_p, w.shape[0])
 
         val = {"conv0": conv(self.conv0), "conv0_1": conv(self.conv0_1), "t0": deconv(self.trans_conv0),
-               "conv0_w": wino(self.conv0), "conv0_1_w": wino(self.conv0_1),
+               "conv0_w": wino(self.conv0), "conv0_1_w": wino(self.conv0_1), "conv1_w": wino(self.conv1),
+               "conv1_1_w": wino(self.conv1_1), "conv2_w": wino(self.conv2), "conv2_1_w": wino(self.conv2_1),
                "conv1": conv(self.conv1), "conv1_1": conv(self.conv1_1), "t1": deconv(self.trans_conv1),
                "conv2": conv(self.conv2), "conv2_1": conv(self.conv2_1), "conv2_2": conv(self.conv2_2)}
         cache["key"], cache["val"] = key, val
@@ -846,9 +855,10 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 del cache[k]
             D, C0, C1, C2 = self._widths()
             z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-            w2 = (D + C2 + 15) // 16 * 16
-            cache[key] = {"x0": z(n, h, w, D + C0), "a0": z(n, h, w, D + C0), "b0": z(n, h, w, D + C0),
-                          "c1": z(n, 2 * h, 2 * w, D + C1), "a1": z(n, 2 * h, 2 * w, D + C1), "b1": z(n, 2 * h, 2 * w, D + C1),
+            p32 = lambda c: (c + 31) // 32 * 32
+            w0, w1, w2 = p32(D + C0), p32(D + C1), p32(D + C2)        # 128, 96, 96 at D = 64
+            cache[key] = {"x0": z(n, h, w, w0), "a0": z(n, h, w, w0), "b0": z(n, h, w, w0),
+                          "c1": z(n, 2 * h, 2 * w, w1), "a1": z(n, 2 * h, 2 * w, w1), "b1": z(n, 2 * h, 2 * w, w1),
                           "c2": z(n, 4 * h, 4 * w, w2), "g2": z(n, 4 * h, 4 * w, w2), "h2": z(n, 4 * h, 4 * w, D)}
         return cache[key]
 
@@ -878,22 +888,24 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 ops.rnet_pack(dpv_log[b].contiguous(), q_cl[0], feat_planar=False, out=x[b:b + 1])
             else:
                 ops.rnet_pack(dpv_log[b].contiguous(), quarter[0].contiguous(), feat_planar=True, out=x[b:b + 1])
-        def conv_w(x, name, out):   # quarter-resolution layers: Winograd kernel when the widths allow it (0.16 vs 0.29 ms each)
+        def conv_w(x, name, out):
+            """A conv2d_leakyRelu layer: on the Winograd kernel's R-Net form (4 instead of 9 multiplies per output and input
+            channel, even after padding 96 / 67 outputs to 128), the direct kernel as the A/B (NRGBD_RNET_WINO=0)."""
             w = pk.get(name + "_w")
-            if w is not None and out.shape[-1] == w[2]:
-                return ops.conv_wino_rnet(x, w[0], w[2], bias=w[1], lrelu=True, out=out)
+            if w is not None:
+                return ops.conv_wino_rnet(x, w[0], w[2], bias=w[1], lrelu=True, out=out, cout_valid=w[3])
             return conv(x, pk[name], out)
         x = conv_w(conv_w(x, "conv0", buf["a0"]), "conv0_1", buf["b0"])
         # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..D-1 of the concat buffer; features behind
         c1 = buf["c1"]
         conv(x, pk["t0"]["all"], c1, mode=3)
-        c1[..., D:].copy_(half.permute(0, 2, 3, 1))
-        x = conv(conv(c1, pk["conv1"], buf["a1"]), pk["conv1_1"], buf["b1"])
+        c1[..., D:D + half.shape[1]].copy_(half.permute(0, 2, 3, 1))
+        x = conv_w(conv_w(c1, "conv1", buf["a1"]), "conv1_1", buf["b1"])
         # full resolution: D + 3 channels in 16-aligned pixels (padding channels zero, with zero weights)
         c2 = buf["c2"]
         conv(x, pk["t1"]["all"], c2, mode=3)
         c2[..., D:D + 3].copy_(full.permute(0, 2, 3, 1))
-        x = conv(conv(c2, pk["conv2"], buf["g2"]), pk["conv2_1"], buf["h2"])
+        x = conv_w(conv_w(c2, "conv2", buf["g2"]), "conv2_1", buf["h2"])
         wp, bias, wdt, _, _ = pk["conv2_2"][0]
         return ops.conv2d_rnet(x, wp, wdt, bias=bias, lrelu=False, mode=2)
 

@@ -677,18 +677,21 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, run
     return ss
 
 
-def conv_wino_rnet(x, w_wino, cout, bias=None, lrelu=True, out=None):
-    """R-Net conv2d_leakyRelu block in the Winograd domain: x [N,H,W,Cin] -> leaky_relu(conv3x3(x) + bias) [N,H,W,cout]."""
+def conv_wino_rnet(x, w_wino, cout, bias=None, lrelu=True, out=None, ycoff=0, cout_valid=None):
+    """R-Net conv2d_leakyRelu block in the Winograd domain: x [N,H,W,Cin] -> leaky_relu(conv3x3(x) + bias).
+    `cout` = columns of the packed weights (% 64); `out` [N,H,W,ldy] may be wider than the layer (a concat buffer): output
+    column c < cout_valid of a pixel lands at out[..., ycoff + c], the rest of the pixel is left alone."""
     x = _need(x, "x")
     N, H, W, Cin = x.shape
+    valid = int(cout if cout_valid is None else cout_valid)
     if out is None:
-        out = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
-    elif tuple(out.shape) != (N, H, W, cout) or not out.is_contiguous():
-        raise ValueError("conv_wino_rnet: out must be a contiguous [N,H,W,cout] tensor")
+        out = torch.empty((N, H, W, valid), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape[:3]) != (N, H, W) or not out.is_contiguous() or out.shape[3] < ycoff + valid:
+        raise ValueError("conv_wino_rnet: out must be a contiguous [N,H,W,>= ycoff + cout_valid] tensor")
     with torch.cuda.device(x.device):
-        rc = _lib.load().nrgbd_conv_wino_rnet_f32(_p(x), _p(w_wino), _p(bias), int(bool(lrelu)), _p(out), N, H, W, Cin, int(cout),
-                                                   _stream(x))
-    _lib.check(rc, "nrgbd_conv_wino_rnet_f32")
+        rc = _lib.load().nrgbd_conv_wino_rnet_ex_f32(_p(x), _p(w_wino), _p(bias), int(bool(lrelu)), _p(out), N, H, W, Cin, int(cout),
+                                                      int(out.shape[3]), int(ycoff), valid, _stream(x))
+    _lib.check(rc, "nrgbd_conv_wino_rnet_ex_f32")
     return out
 
 
