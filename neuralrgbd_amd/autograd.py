@@ -64,7 +64,7 @@ class DepthWarp(torch.autograd.Function):
 
 class Conv3dCL(torch.autograd.Function):
     """3x3x3 convolution (stride 1, padding 1, no bias, 64 outputs) on channels-last activations, both directions on
-    the fp32 matrix cores: forward = csrc/wino_pc.hip (64 -> 64 layers, Winograd domain) / csrc/conv3d.hip; data gradient = the
+    the fp32 matrix cores: forward = csrc/wino_dw.hip / wino_pc.hip (64 -> 64 layers, Winograd domain) / csrc/conv3d.hip; data gradient = the
     same kernel on the output gradient with transposed + flipped weights; weight gradient = csrc/conv3d_wgrad.hip.
 
     x [D,H,W,Cin] (Cin in {16, 64}), w [64,Cin,3,3,3] -> y [D,H,W,64].
@@ -75,6 +75,8 @@ class Conv3dCL(torch.autograd.Function):
         """y = conv(x, w) (transposed: with w's data-gradient weights): the Winograd-domain kernel (wino_pc.hip) for the 64 -> 64
         layers, the direct kernel otherwise."""
         if w.shape[0] == 64 and w.shape[1] == 64:
+            if ops.conv_wino_dw_supported(x.shape[0], x.shape[1], x.shape[2], 64, 64):   # Winograd along depth too (wino_dw.hip)
+                return ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w, transposed), 64, want_stats=False)[0]
             return ops.conv_wino(x, ops.conv_wino_pack(w, transposed), 64, 3, want_stats=False)[0]
         if transposed:
             cin = w.shape[1]

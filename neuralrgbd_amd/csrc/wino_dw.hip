@@ -564,7 +564,7 @@ extern "C" int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_r
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cin > kDwMaxCin || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
     if (N & 1) return NRGBD_E_SHAPE;                                  // pairs of output slices
     if (H % kPcTH || W % kPcTW) return NRGBD_E_SHAPE;                 // whole 8x16 tiles only (every grid of the path; others: nrgbd_conv_wino_f32)
-    if ((long)N * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;   // 32-bit BYTE offsets in the loader
+    if ((long)H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;       // 32-bit BYTE offsets inside a slice (the slice is a 64-bit base)
     const int rows = nrgbd_conv_wino_tiles(N, H, W, 1);              // statistics rows: one per (8x16 tile, slice) as wino_pc
     const long nt = (long)(rows / 2) * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;

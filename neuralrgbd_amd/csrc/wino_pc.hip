@@ -628,7 +628,8 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
     if ((kd != 1 && kd != 3) || (dilation != 1 && dilation != 2) || (kd == 3 && dilation != 1)) return NRGBD_E_ARG;
     if ((Cin / kCB) * kd < 2) return NRGBD_E_SHAPE;      // two stages are always in flight (two register sets)
-    if ((long)N * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;   // 32-bit BYTE offsets in the loader
+    // 32-bit BYTE offsets in the loader: inside one slice when kd = 3 (the slice is a 64-bit base), inside the tensor otherwise
+    if ((long)(kd == 3 ? 1 : N) * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;
     const int rows = nrgbd_conv_wino_tiles(N, H, W, dilation);
     const long nt = (long)rows * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;

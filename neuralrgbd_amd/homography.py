@@ -72,6 +72,13 @@ def clear_cache():
     _const_cache.clear()
 
 
+def cache_snapshot():
+    """Strong references to every cached device constant (K, ray tables, d_candi).  A captured hipGraph bakes their raw
+    pointers in and never touches the LRU on replay: the graph's owner keeps this list so that eviction (a long run builds a
+    new intrinsics dict per trajectory) cannot hand the memory a live graph reads back to the allocator."""
+    return list(_const_cache.values())
+
+
 def homography_terms(K, R, t):
     """term1 = K t_v and the left factor K R_v of term2 (homography.py:315-317), batched: [V,3], [V,3,3]."""
     return ops.homography_terms(K, R, t)

@@ -337,7 +337,8 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         # (320 -> 128) at config B, and 2.4-3x at the 64x96 grid where 16x16 tiles under-fill the chip.  NRGBD_CNN_CONV=direct
         # keeps conv2d.hip for A/B.
         wino = (mfma and d in (1, 2) and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
-                and os.environ.get("NRGBD_CNN_CONV", "wino") != "direct")
+                and os.environ.get("NRGBD_CNN_CONV", "wino") != "direct"
+                and ops.conv_wino_supported(a.z.shape[0], a.z.shape[1], a.z.shape[2], conv.in_channels, conv.out_channels, 1))
         if wino:
             z, st, mat = ops.conv_wino(a.z, _packed_wino(self, conv), conv.out_channels, 1, d, x_ss=a.ss, x_relu=a.relu,
                                        res=a.r, res_ss=a.r_ss, res_relu=a.r_relu, materialize=materialize,
@@ -614,7 +615,8 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
             elif wino and conv.in_channels == 64 and mode == "wino1":
                 y, st, mat = ops.conv3d_wino(x, self._packed_wino(conv), x_ss=x_ss, x_relu=x_relu, res=res,
                                              materialize=materialize, want_stats=need_stats(bn))
-            elif wino and (conv.in_channels == 64 or (conv.in_channels == 16 and res is None and mode != "wino64")):
+            elif wino and (conv.in_channels == 64 or (conv.in_channels == 16 and res is None and mode != "wino64")) \
+                    and ops.conv_wino_supported(D, H, W, conv.in_channels, 64, 3):
                 # 64 -> 64 (12 stages per tile) and the first layer 16 -> 64 (3 stages: the odd-stage-count instantiation)
                 y, st, mat = ops.conv_wino(x, _packed_wino(self, conv), 64, 3, x_ss=x_ss, x_relu=x_relu, res=res,
                                            materialize=materialize, want_stats=need_stats(bn))

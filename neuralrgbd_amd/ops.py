@@ -397,6 +397,14 @@ def conv_wino_pack_reference(w):
     return U.to(torch.float32).reshape(-1)
 
 
+def conv_wino_supported(N, H, W, Cin, Cout, kd):
+    """Shapes nrgbd_conv_wino_f32 accepts (the callers fall back to the direct kernels otherwise): channel multiples, at least
+    two stages, an even stage count except for the 16-channel 3-D first layer, 32-bit byte offsets in the loader."""
+    stages = (Cin // 16) * kd
+    span = (1 if kd == 3 else N) * H * W * Cin
+    return Cin % 16 == 0 and Cout % 64 == 0 and stages >= 2 and (stages % 2 == 0 or (kd == 3 and Cin == 16)) and span < (1 << 30)
+
+
 def conv_wino_tiles(N, H, W, dilation=1):
     return int(_lib.load().nrgbd_conv_wino_tiles(N, H, W, dilation))
 

@@ -62,6 +62,7 @@ class DepthStream:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             st["out"] = self._frame(st["ref"], st["src"], st["poses"], st["inv"], st["bv"])
+        st["consts"] = warp_homo.cache_snapshot()      # K / rays / d_candi the graph reads: kept alive with the graph
         self._graph, self._static = g, st
 
     # ------------------------------------------------------------------ public step

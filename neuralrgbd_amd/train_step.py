@@ -147,6 +147,7 @@ class TrainGraph:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 st["out"] = self._iteration(st)      # gradients are allocated in the graph's pool and rewritten per replay
+            st["consts"] = warp_homo.cache_snapshot()   # K / rays / d_candi the graph reads: kept alive with the graph
             self._graph, self._st = g, st
             # capture does not execute: fall through to the first replay with the same inputs
         st = self._st

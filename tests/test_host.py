@@ -169,3 +169,27 @@ def test_stride2_conv_as_window_conv_on_space_to_depth_host_logic():
         got = F.conv2d(F.pad(s2d, (1, 0, 1, 0)), w2)
         assert got.shape == want.shape
         assert (got - want).abs().max().item() < 1e-12
+
+
+def test_graph_owners_pin_the_device_constants_they_captured():
+    """homography's LRU of device constants (K, rays, d_candi) is bounded; a captured hipGraph reads those tensors by
+    raw pointer and never refreshes the LRU, so the graph owner must hold them (cache_snapshot) — checked on the CPU side: the
+    snapshot returns the very objects the cache holds, and they survive eviction."""
+    import collections
+    from neuralrgbd_amd import homography as H
+    saved = H._const_cache
+    try:
+        H._const_cache = collections.OrderedDict()
+        marker = object()
+        H._cache_put(("d", b"x", "cpu"), marker)
+        snap = H.cache_snapshot()
+        assert snap == [marker]
+        for i in range(H._CONST_CACHE_MAX + 5):
+            H._cache_put(("d", b"y%d" % i, "cpu"), i)
+        assert ("d", b"x", "cpu") not in H._const_cache and snap[0] is marker       # evicted from the LRU, alive in the snapshot
+    finally:
+        H._const_cache = saved
+    import inspect
+    from neuralrgbd_amd import streaming, train_step
+    assert "cache_snapshot" in inspect.getsource(streaming.DepthStream._capture)
+    assert "cache_snapshot" in inspect.getsource(train_step.TrainGraph.step)
