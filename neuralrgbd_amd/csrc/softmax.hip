@@ -60,15 +60,61 @@ __global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restr
     if (conf) conf[p] = m;
 }
 
+// The same reduction with FOUR threads per pixel (part p owns candidates p, p + 4, ...: up to 32 registers for D <= 128) and a
+// workgroup of 64 pixels x 4 parts.  One thread per pixel leaves a 192x256 grid at 192 workgroups of 4 waves (less than one per
+// CU) with 128 dependent-latency loads per thread: 57 us for 37.7 MB = 0.67 TB/s (rocprofv3, round 2).  Here every thread has
+// 2 x 16 independent loads in flight and the grid is 768 workgroups.  Same arithmetic: the maximum is exact in any order and
+// the sum of exponentials is taken as (p0 + p1) + (p2 + p3) of the four partial sums, each in candidate order.
+template <int KMAX>   // candidates per part: D <= 4 * KMAX
+__global__ __launch_bounds__(256) void logsoftmax_d4_kernel(const float* __restrict__ a, const float* __restrict__ b, float scale,
+                                                            float* __restrict__ out, int D, size_t n) {
+    __shared__ float red[2][4][64];
+    const int pp = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const size_t p = (size_t)blockIdx.x * 64 + pp;
+    const bool in = p < n;
+    const size_t pc = in ? p : n - 1;
+    float col[KMAX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) {
+        const int k = part + 4 * t;
+        float v = -INFINITY;
+        if (k < D) {
+            v = scale * a[(size_t)k * n + pc];
+            if (b) v = v + b[(size_t)k * n + pc];
+        }
+        col[t] = v;
+        m = fmaxf(m, v);
+    }
+    red[0][part][pp] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0][0][pp], red[0][1][pp]), fmaxf(red[0][2][pp], red[0][3][pp]));
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t)
+        if (part + 4 * t < D) s += expf(col[t] - m);
+    red[1][part][pp] = s;
+    __syncthreads();
+    s = (red[1][0][pp] + red[1][1][pp]) + (red[1][2][pp] + red[1][3][pp]);
+    const float ls = logf(s);
+    if (in) {
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            const int k = part + 4 * t;
+            if (k < D) out[(size_t)k * n + p] = (col[t] - m) - ls;
+        }
+    }
+}
+
 int launch_logsoftmax_d(const float* a, const float* b, float scale, float* out, int D, size_t n,
                         hipStream_t s) {
-    dim3 grid(ceil_div((long)n, 256));
-    if (D <= 64)
-        hipLaunchKernelGGL(logsoftmax_d_kernel<64>, grid, dim3(256), 0, s, a, b, scale, out, D, n);
-    else if (D <= 128)
-        hipLaunchKernelGGL(logsoftmax_d_kernel<128>, grid, dim3(256), 0, s, a, b, scale, out, D, n);
-    else
-        hipLaunchKernelGGL(logsoftmax_d_kernel<0>, grid, dim3(256), 0, s, a, b, scale, out, D, n);
+    if (D <= 64) {
+        hipLaunchKernelGGL(logsoftmax_d4_kernel<16>, dim3(ceil_div((long)n, 64)), dim3(256), 0, s, a, b, scale, out, D, n);
+    } else if (D <= 128) {
+        hipLaunchKernelGGL(logsoftmax_d4_kernel<32>, dim3(ceil_div((long)n, 64)), dim3(256), 0, s, a, b, scale, out, D, n);
+    } else {
+        hipLaunchKernelGGL(logsoftmax_d_kernel<0>, dim3(ceil_div((long)n, 256)), dim3(256), 0, s, a, b, scale, out, D, n);
+    }
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }
