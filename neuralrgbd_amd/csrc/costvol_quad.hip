@@ -26,7 +26,7 @@
 // Candidates whose footprint does not fit even as a pair (nearest planes: large, fast-moving footprints) are evaluated
 // straight from L1/L2 with the same quad layout — a quad's taps are 64-byte contiguous runs, which the texture path serves at
 // 4 lanes/clk (the generation-1 gather paid 1 lane/clk) — so they need neither a patch nor a barrier.
-// ~100 VGPRs => 3 workgroups (12 waves) per CU; one workgroup owns ALL candidates of its tile (when the grid fills the chip),
+// 165 VGPRs => 3 workgroups (12 waves) per CU; one workgroup owns ALL candidates of its tile (when the grid fills the chip),
 // so log_softmax over depth is taken in the same launch (models/basic.py:299-300).
 //
 // Arithmetic per tap / channel is the same as generations 1-2 (common.hpp helpers, same operation sequence for the

@@ -398,7 +398,9 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         """Inference on the hand-written kernels: x [N,3,H,W] -> (layer1 [N,H/2,W/2,32], feat [N,H/4,W/4,F]), both
         channels-last.  Same graph as forward() (psm_submodule.py:136-167); every 3x3 stride-1 conv is one fused pass
         (conv on the fp32 matrix cores, BatchNorm statistics in its epilogue, normalise + ReLU + residual in the next
-        layer's loader).  The three stride-2 / 3-channel convs and the 1x1 convs (GEMMs) use the vendor libraries."""
+        layer's loader); the stride-2 3x3 convs run as 2x2-window convolutions on the space-to-depth image, the 1x1 convs as
+        the 1-tap form of the same kernel.  What is left of torch here: SPP average pooling, the bilinear up-sampling of its four
+        tiny maps and one concat (NRGBD_CNN_SMALL=vendor keeps MIOpen / rocBLAS for the small convs as the A/B)."""
         from . import ops
         conv, bn = self.firstconv[0]
         if x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and _small_convs_native():
