@@ -35,11 +35,16 @@
 
 namespace nrgbd {
 
-template <int KD, int DIL, bool RES, bool ODD = false, int EPI = 0>
+// MAT: the activated input is also written out (a.mat).  A template parameter because of what its stores do to the variants
+// WITHOUT them (round 3, learnt on wino_dw.hip): once loads and stores of one wave can both be pending the
+// compiler turns every s_waitcnt on a prefetched register into vmcnt(0), which also waits for the refill issued a moment
+// earlier.  For the same reason the refills are unconditional and the (scale, shift) pairs come from an LDS copy.
+template <int KD, int DIL, bool RES, bool ODD = false, int EPI = 0, bool MAT = false>
 __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Vb = lds;                           // [3][16 xi][32 tiles][16]
     float* rawb = lds + kPcNBuf * kPcV;        // [4 producer waves][4 rows][20 pixels][16]
+    float* ssl = rawb + 4 * kPcRawWave;        // [Cin][2] (scale, shift) of x, then [Cin][2] of res (identity where null)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,6 +71,13 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     if (first >= end) return;                  // uniform: no wave of this workgroup ever reaches a barrier
     const int count = (end - first + step - 1) / step;
     const unsigned plane = (unsigned)((size_t)a.H * a.W * a.Cin);
+    if constexpr (EPI == 0) {
+        for (int i = threadIdx.x; i < 2 * a.Cin; i += 512) {
+            ssl[i] = a.x_ss ? a.x_ss[i] : ((i & 1) ? 0.f : 1.f);
+            ssl[2 * a.Cin + i] = (RES && a.res_ss) ? a.res_ss[i] : ((i & 1) ? 0.f : 1.f);
+        }
+        __syncthreads();
+    }
 
     // Producers are waves 0-3: VALU issue on a SIMD is arbitrated by age, and the producers' (few) VALU instructions have to
     // get through beside the consumer's continuous MFMA stream (measured: 3.58 -> 3.38 ms per layer from this alone)
@@ -321,13 +333,13 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         auto issue = [&](bool nx, int s, Regs& r) __attribute__((always_inline)) {
             const int cb = s / KD, kd = s - cb * KD;
             r.ss[0] = r.ss[1] = r.rs[0] = r.rs[1] = f32x4{1.f, 0.f, 1.f, 0.f};
-            if (a.x_ss) {
-                r.ss[0] = *reinterpret_cast<const f32x4*>(a.x_ss + 2 * (cb * kCB + w4 * 4));
-                r.ss[1] = *reinterpret_cast<const f32x4*>(a.x_ss + 2 * (cb * kCB + w4 * 4) + 4);
-            }
-            if (RES && a.res_ss) {
-                r.rs[0] = *reinterpret_cast<const f32x4*>(a.res_ss + 2 * (cb * kCB + w4 * 4));
-                r.rs[1] = *reinterpret_cast<const f32x4*>(a.res_ss + 2 * (cb * kCB + w4 * 4) + 4);
+            if constexpr (EPI == 0) {
+                r.ss[0] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4));
+                r.ss[1] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4) + 4);
+                if constexpr (RES) {
+                    r.rs[0] = *reinterpret_cast<const f32x4*>(ssl + 2 * a.Cin + 2 * (cb * kCB + w4 * 4));
+                    r.rs[1] = *reinterpret_cast<const f32x4*>(ssl + 2 * a.Cin + 2 * (cb * kCB + w4 * 4) + 4);
+                }
             }
             const int tz = nx ? tn.n : tl.n;
             const int z = KD == 3 ? min(max(tz + kd - 1, 0), a.N - 1) : 0;   // clamped: an outside slice is zeroed when published
@@ -373,9 +385,11 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                         for (int u = 0; u < kPcNPF; ++u) *reinterpret_cast<f32x4*>(raw + wr_off[u]) = f32x4{0.f, 0.f, 0.f, 0.f};
                     } else {
                         // (scale, shift) pairs re-paired for the packed FMAs: channels (0,1) and (2,3); identity = (1, 0)
+                        asm volatile("" : "+v"(r.ss[0]), "+v"(r.ss[1]));   // re-paired HERE, not behind their loads
+                        if constexpr (RES) asm volatile("" : "+v"(r.rs[0]), "+v"(r.rs[1]));
                         const f32x2 sc01 = {r.ss[0].x, r.ss[0].z}, sh01 = {r.ss[0].y, r.ss[0].w}, sc23 = {r.ss[1].x, r.ss[1].z}, sh23 = {r.ss[1].y, r.ss[1].w};
                         const f32x2 rc01 = {r.rs[0].x, r.rs[0].z}, rh01 = {r.rs[0].y, r.rs[0].w}, rc23 = {r.rs[1].x, r.rs[1].z}, rh23 = {r.rs[1].y, r.rs[1].w};
-                        const bool wmat = a.mat && (KD != 3 || kd == 1) && tl.cg == 0;
+                        const bool wmat = MAT && (KD != 3 || kd == 1) && tl.cg == 0;
                         // Breadth-first over the 5 items — all FMAs, then all ReLUs, then all masks, then the stores — and
                         // pinned in that order: beside the consumer's MFMA stream a VALU instruction that has to wait for
                         // its predecessor's result loses the issue port to the next MFMA (32 cycles), an independent one
@@ -425,7 +439,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                                 const int u = U0 + i;
                                 const f32x4 v = __builtin_shufflevector(lo[i], hi[i], 0, 1, 2, 3);
                                 // the activated input is written once: by the wave that owns the pixel, at the centre tap
-                                if (wmat) {
+                                if (MAT && wmat) {
                                     if ((cur_own >> u) & 1u)
                                         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.mat) + ((size_t)(KD == 3 ? z : 0) * plane + (size_t)(cb * kCB)) * sizeof(float) + cur_off[u]) = v;
                                 }
@@ -445,8 +459,9 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
 #endif
                 // (2) refill the set: stage s+2 of this tile, or stage s+2-NS of the next one
                 {
+                    // UNCONDITIONAL (the last two stages of the last tile re-read this tile's first two: harmless, never used)
                     const bool nx = s + 2 >= NS;
-                    if (!nx || has_next) issue(nx, nx ? s + 2 - NS : s + 2, r);
+                    issue(nx && has_next, nx ? s + 2 - NS : s + 2, r);
                 }
 #ifdef NRGBD_DEV
                 const long q2 = wall_clock64();
@@ -625,7 +640,7 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
                                    int H, int W, int Cin, int Cout, int kd, int dilation, void* stream) {
     using namespace nrgbd;
     if (!x || !w_wino || !y) return NRGBD_E_NULL;
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cin > 2048 || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
     if ((kd != 1 && kd != 3) || (dilation != 1 && dilation != 2) || (kd == 3 && dilation != 1)) return NRGBD_E_ARG;
     if ((Cin / kCB) * kd < 2) return NRGBD_E_SHAPE;      // two stages are always in flight (two register sets)
     // 32-bit BYTE offsets in the loader: inside one slice when kd = 3 (the slice is a 64-bit base), inside the tensor otherwise
@@ -641,18 +656,20 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     if (e != hipSuccess) return (int)e;
     if (ncu <= 0) return NRGBD_E_ARG;
     const int nwg = nt < ncu ? (int)nt : ncu;   // persistent: one workgroup per CU
-    const size_t lds = (size_t)(kPcNBuf * kPcV + 4 * kPcRawWave) * sizeof(float);   // 96 KB V + 20 KB strips
+    const size_t lds = (size_t)(kPcNBuf * kPcV + 4 * kPcRawWave + 4 * Cin) * sizeof(float);   // 96 KB V + 20 KB strips + (scale, shift) tables
     hipStream_t st = (hipStream_t)stream;
 #define NRGBD_WINO_PC_LAUNCH(KD_, DIL_, RES_)                                                                       \
+    do { if (materialized) NRGBD_WINO_PC_LAUNCH_M(KD_, DIL_, RES_, true); else NRGBD_WINO_PC_LAUNCH_M(KD_, DIL_, RES_, false); } while (0)
+#define NRGBD_WINO_PC_LAUNCH_M(KD_, DIL_, RES_, MAT_)                                                               \
     do {                                                                                                            \
         /* > 64 KB of dynamic LDS needs the opt-in; idempotent and ~1 us, so simply repeated per call (re-entrant) */ \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<KD_, DIL_, RES_>),               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<KD_, DIL_, RES_, false, 0, MAT_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
         if (e != hipSuccess) return (int)e;                                                                         \
-        hipLaunchKernelGGL((conv_wino_pc_kernel<KD_, DIL_, RES_>), dim3(nwg), dim3(512), lds, st, a);               \
+        hipLaunchKernelGGL((conv_wino_pc_kernel<KD_, DIL_, RES_, false, 0, MAT_>), dim3(nwg), dim3(512), lds, st, a); \
     } while (0)
     const bool odd = (((Cin / kCB) * kd) & 1) != 0;
-    if (odd && (kd != 3 || res)) return NRGBD_E_SHAPE;   // an odd stage count is instantiated for the K-Net's first layer only
+    if (odd && (kd != 3 || res || materialized)) return NRGBD_E_SHAPE;   // an odd stage count is instantiated for the K-Net's first layer only
     if (kd == 3 && odd) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<3, 1, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -666,6 +683,7 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
         if (res) NRGBD_WINO_PC_LAUNCH(1, 2, true); else NRGBD_WINO_PC_LAUNCH(1, 2, false);
     }
 #undef NRGBD_WINO_PC_LAUNCH
+#undef NRGBD_WINO_PC_LAUNCH_M
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }
