@@ -466,6 +466,19 @@ int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_relu,
 int nrgbd_bn_finalize(const float* stats, int num_workgroups, int C, long count,
                       const float* gamma, const float* beta, float eps, float momentum,
                       float* running_mean, float* running_var, float* scale_shift, void* stream);
+/*
+ * nrgbd_spp_concat — the tail of the feature CNN's spatial-pyramid pooling in one channels-last pass.
+ * Replaces: models/psm_submodule.py:149-161 — for the four branches nn.ReLU after convbn (:100-117 branch1..4), F.upsample(
+ * bilinear, align_corners=True) (:153-158), and the torch.cat of (output_raw, output_skip, branch4, branch3, branch2, branch1)
+ * (:160).  out[pixel] = [ quarter (Cq) | deep (Cd) | up(relu(bz0 * s + t)) | up(.. bz1) | up(.. bz2) | up(.. bz3) ].
+ *   quarter [N][h][w][Cq], deep [N][h][w][Cd]; branch i: raw 1x1-conv output bz_i [N][bh_i][bw_i][Cb] and the (scale, shift)
+ *   [Cb][2] of its BatchNorm (nrgbd_bn_finalize); out [N][h][w][Cq + Cd + 4 Cb]; all channel counts % 4 == 0.
+ * Interpolation arithmetic = ATen upsample_bilinear2d (fp32 scale (in-1)/(out-1), lambda clamped to [0,1]).
+ */
+int nrgbd_spp_concat(const float* quarter, int Cq, const float* deep, int Cd,
+                     const float* bz0, const float* bss0, int bh0, int bw0, const float* bz1, const float* bss1, int bh1, int bw1,
+                     const float* bz2, const float* bss2, int bh2, int bw2, const float* bz3, const float* bss3, int bh3, int bw3,
+                     int Cb, float* out, int N, int h, int w, void* stream);
 int nrgbd_nhwc_stats_workgroups(long P);
 int nrgbd_nhwc_stats(const float* x, long P, int C, float* stats, void* stream);
 int nrgbd_nhwc_act(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,

@@ -440,18 +440,26 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
             pools = {8: p8, 16: F.avg_pool2d(p8, 2), 32: F.avg_pool2d(p8, 4), 64: F.avg_pool2d(p8, 8)}
         else:
             pools = {k: F.avg_pool2d(deep_nchw, (k, k), stride=(k, k)) for k in self.SPP_WINDOWS}
-        pyramid = []
+        pyramid, fused = [], []
         for i in (4, 3, 2, 1):
             branch = getattr(self, "branch%d" % i)
             pool = pools[self.SPP_WINDOWS[i - 1]]
             if _small_convs_native():                                      # 1x1 conv + BatchNorm + ReLU on the tiny map
                 pb = self._pointwise_bn_cl(branch[1], pool.permute(0, 2, 3, 1).contiguous())
+                if pb.ss is not None and os.environ.get("NRGBD_SPP", "fused") == "fused":
+                    fused.append((pb.z, pb.ss))                            # normalise + ReLU at the taps of spp_concat
+                    continue
                 y = ops.nhwc_act(pb.z, pb.ss, True).permute(0, 3, 1, 2)    # channels-last memory, NCHW view
             else:
                 y = _conv_bn_act(pool.contiguous(), branch[1], relu=True).contiguous(memory_format=torch.channels_last)
             y = F.interpolate(y, size=(h, w), mode="bilinear", align_corners=True)
             pyramid.append(y.permute(0, 2, 3, 1))                          # channels-last in memory already
-        cat = torch.cat([quarter, deep] + pyramid, dim=3)                  # [N,h,w,320]
+        if len(fused) == 4:
+            # BatchNorm + ReLU of the four tiny maps, their bilinear up-sampling and the 320-channel concat in ONE launch
+            # (csrc/spp.hip) instead of 4 nhwc_act + 4 upsample_bilinear2d + 3 CatArrayBatchedCopy
+            cat = ops.spp_concat(quarter, deep, fused)
+        else:
+            cat = torch.cat([quarter, deep] + pyramid, dim=3)              # [N,h,w,320]
         y, _ = self._conv_bn_cl(self.lastconv[0], _Act(cat), relu=True)
         head = self.lastconv[2]
         if head.out_channels in (32, 64, 128) and _small_convs_native():   # 1x1 head; BatchNorm + ReLU of lastconv[0] in its loader

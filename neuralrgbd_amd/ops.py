@@ -715,6 +715,29 @@ def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, 
     return ss
 
 
+def spp_concat(quarter, deep, branches):
+    """[quarter | deep | up(relu(bn(z_0))) | ... | up(relu(bn(z_3)))] -> [N,h,w,Cq+Cd+4*Cb] in one pass (nrgbd_spp_concat).
+    quarter [N,h,w,Cq], deep [N,h,w,Cd] channels-last; branches: four (z [N,bh,bw,Cb] raw 1x1-conv output, ss [Cb,2]) in the
+    concat's order; up = bilinear, align_corners=True (psm_submodule.py:149-161)."""
+    quarter, deep = _need(quarter, "quarter"), _need(deep, "deep")
+    N, h, w, Cq = quarter.shape
+    Cd = deep.shape[3]
+    if tuple(deep.shape[:3]) != (N, h, w) or len(branches) != 4:
+        raise ValueError("spp_concat: quarter %s / deep %s / %d branches" % (tuple(quarter.shape), tuple(deep.shape), len(branches)))
+    Cb = branches[0][0].shape[3]
+    args = []
+    for z, ss in branches:
+        z, ss = _need(z, "branch"), _need(ss, "branch scale/shift", (Cb, 2))
+        if z.shape[0] != N or z.shape[3] != Cb:
+            raise ValueError("spp_concat: branch %s" % (tuple(z.shape),))
+        args += [_p(z), _p(ss), int(z.shape[1]), int(z.shape[2])]
+    out = torch.empty((N, h, w, Cq + Cd + 4 * Cb), dtype=torch.float32, device=quarter.device)
+    with torch.cuda.device(quarter.device):
+        rc = _lib.load().nrgbd_spp_concat(_p(quarter), Cq, _p(deep), Cd, *args, Cb, _p(out), N, h, w, _stream(quarter))
+    _lib.check(rc, "nrgbd_spp_concat")
+    return out
+
+
 def nhwc_stats(x):
     """Per-workgroup (sum, sum of squares) partials of a channels-last tensor [..., C] -> [nwg, 2C]."""
     x = _need(x, "x")

@@ -242,3 +242,27 @@ def test_conv_1x1_vs_torch(N, H, W, Cin, Cout):
     assert err < 2e-5 * max(1.0, want.abs().max().item())
     s = stats.double().sum(0)
     assert torch.allclose(s[:Cout], want.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+
+
+def test_spp_concat_vs_torch():
+    """nrgbd_spp_concat (BatchNorm + ReLU of the four tiny SPP maps at the taps, bilinear up-sampling with align_corners=True, the
+    320-channel concat) vs the torch ops it replaces (psm_submodule.py:149-161), incl. maps of a single row / column."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for (N, h, w, sizes) in ((2, 24, 40, ((3, 5), (2, 3), (1, 2), (1, 1))), (5, 64, 96, ((8, 12), (4, 6), (2, 3), (1, 1)))):
+        quarter = torch.randn(N, h, w, 64, generator=g).to(DEV)
+        deep = torch.randn(N, h, w, 128, generator=g).to(DEV)
+        br, want = [], [quarter, deep]
+        for (bh, bw) in sizes:
+            z = torch.randn(N, bh, bw, 32, generator=g).to(DEV)
+            ss = torch.randn(32, 2, generator=g).to(DEV)
+            br.append((z, ss))
+            y = torch.relu(z * ss[:, 0] + ss[:, 1]).permute(0, 3, 1, 2)
+            want.append(F.interpolate(y, size=(h, w), mode="bilinear", align_corners=True).permute(0, 2, 3, 1))
+        want = torch.cat(want, dim=3)
+        got = ops.spp_concat(quarter, deep, br)
+        assert got.shape == want.shape
+        assert torch.equal(got[..., :192], want[..., :192])
+        err = (got - want).abs().max().item()
+        print("[parity] spp_concat %dx%dx%d: max|d| vs torch %.2e" % (N, h, w, err))
+        assert err < 2e-6

@@ -48,7 +48,9 @@ def _gpu_two_frames(model, cam, d_candi, windows):
     return outs
 
 
-MAX_TIE_FLIPS = 4    # per frame and volume; measured envelope over every config: <= 2 (round 2 allowed 1 per 1,000 pixels)
+MAX_TIE_FLIPS = 8    # per frame and volume (round 2 allowed 1 per 1,000 pixels = 49 at B).  Measured envelope over rounds 2-3: 0 at S,
+                     # B and H in these tests, up to 6 of 12,288 at K (KITTI's 1-60 m candidate range has the most near-ties: which
+                     # of them flip changes with every rounding-order change of a kernel); every flip must be a tie (gap < 1e-3)
 
 
 def _check(name, got, want, argmax=True, fp64=None, oracle_err=None, max_abs=None):
