@@ -383,6 +383,19 @@ int nrgbd_conv_wino_dw_pack(const float* w, float* w_wino, int Cin, int Cout, in
 int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
                            int res_relu, float* materialized, const float* w_wino, float* y, float* stats,
                            int N, int H, int W, int Cin, int Cout, void* stream);
+/* The same with the BatchNorm3d finalisation of models/basic.py:53-68 (convbn_3d: batch statistics, running-statistics update)
+ * FUSED into the launch: every workgroup leaves its per-channel sums (fp64) in wg_scratch and takes a ticket; the last one turns
+ * them into scale_shift [Cout][2] = (gamma * invstd, beta - mean * gamma * invstd) — what nrgbd_bn_finalize_cm does in a launch of
+ * its own from 2 Cout x tiles floats.  Cout = 64.
+ *   wg_scratch [nrgbd_conv_wino_dw_workgroups(N,H,W,Cout)][2*Cout] doubles (no initialisation needed);
+ *   ticket     one int, ZERO before the first launch; the finalising workgroup resets it, so one ticket serves every launch of
+ *              a stream (hipGraph replays included).  Not to be shared between launches that can overlap in time. */
+int nrgbd_conv_wino_dw_workgroups(int N, int H, int W, int Cout);
+int nrgbd_conv_wino_dw_bn_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
+                              int res_relu, float* materialized, const float* w_wino, float* y, int N, int H, int W,
+                              int Cin, int Cout, const float* gamma, const float* beta, float eps, float momentum,
+                              float* running_mean, float* running_var, double* wg_scratch, int* ticket,
+                              float* scale_shift, void* stream);
 
 /*
  * R-Net (DPV up-sampler) on the same matrix-core kernel.  Replaces, per layer of models/Refine.py:51-107:

@@ -613,12 +613,25 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         wino = mode != "direct"
         dw_layers = os.environ.get("NRGBD_KNET_DW", "16,64")  # which input widths take wino_dw.hip: "16,64" | "64" | ""
         dw_cin = {int(v) for v in dw_layers.split(",") if v} if mode == "auto" else set()
+        # BatchNorm finalisation inside the conv launch (nrgbd_conv_wino_dw_bn_f32, NRGBD_KNET_BN=fused) is built and tested but
+        # NOT the default: measured 42.70 vs 42.79 ms per frame at config B and 6.54 vs 6.41 at S — the last workgroup's serial
+        # reduction costs what the tiny separate launch costs
+        fuse_bn = os.environ.get("NRGBD_KNET_BN", "separate") == "fused"
 
         def run(i, x, x_ss, x_relu, res=None, materialize=False):
             conv, bn = L[i]
             cm = False
             if (conv.in_channels in dw_cin and conv.out_channels == 64
                     and ops.conv_wino_dw_supported(D, H, W, conv.in_channels, 64)):
+                if need_stats(bn) and fuse_bn:
+                    # BatchNorm3d finalisation inside the conv launch (last workgroup reduces the per-workgroup sums)
+                    upd = bn.training and bn.track_running_stats
+                    if upd:
+                        bn.num_batches_tracked += 1
+                    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                    return ops.conv_wino_dw_bn(x, _packed_wino_dw(self, conv), bn.weight.detach(), bn.bias.detach(), bn.eps,
+                                               momentum, bn.running_mean if upd else None, bn.running_var if upd else None,
+                                               x_ss=x_ss, x_relu=x_relu, res=res, materialize=materialize)
                 y, st, mat = ops.conv_wino_dw(x, _packed_wino_dw(self, conv), 64, x_ss=x_ss, x_relu=x_relu, res=res,
                                               materialize=materialize, want_stats=need_stats(bn))
                 cm = True

@@ -482,6 +482,47 @@ def conv_wino_dw(x, w_wino, Cout, x_ss=None, x_relu=False, res=None, res_ss=None
     return y, stats, mat
 
 
+_bn_tickets = {}
+
+
+def _bn_ticket(device):
+    """One zero-initialised int per (device, stream): the finalising workgroup of a fused-BatchNorm launch resets it, so it
+    serves every such launch of that stream, hipGraph replays included."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _bn_tickets.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _bn_tickets[key] = t
+    return t
+
+
+def conv_wino_dw_bn(x, w_wino, gamma, beta, eps, momentum, running_mean=None, running_var=None, x_ss=None, x_relu=False,
+                    res=None, res_ss=None, res_relu=False, materialize=False):
+    """conv_wino_dw (Cout = 64) with the BatchNorm3d finalisation fused into the launch (nrgbd_conv_wino_dw_bn_f32):
+    -> (y [D,H,W,64], scale_shift [64,2], materialized | None); running statistics updated in place when given."""
+    x = _need(x, "x")
+    N, H, W, Cin = x.shape
+    Cout = 64
+    y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
+    mat = torch.empty_like(x) if materialize else None
+    if res is not None:
+        res = _need(res, "res", x.shape)
+    if w_wino.numel() != (Cin // 16) * 4 * 16 * 1024:
+        raise ValueError("conv_wino_dw_bn: packed weights do not match Cin=%d Cout=64" % Cin)
+    nwg = int(_lib.load().nrgbd_conv_wino_dw_workgroups(N, H, W, Cout))
+    if nwg <= 0:
+        raise ValueError("conv_wino_dw_bn: unsupported shape %s" % (tuple(x.shape),))
+    wg = torch.empty((nwg, 2 * Cout), dtype=torch.float64, device=x.device)
+    ss = torch.empty((Cout, 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv_wino_dw_bn_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(mat),
+                                                    _p(w_wino), _p(y), N, H, W, Cin, Cout, _p(gamma), _p(beta), float(eps),
+                                                    float(momentum), _p(running_mean), _p(running_var), _p(wg),
+                                                    _p(_bn_ticket(x.device)), _p(ss), _stream(x))
+    _lib.check(rc, "nrgbd_conv_wino_dw_bn_f32")
+    return y, ss, mat
+
+
 def conv3d_wgrad(x, gy):
     """Weight gradient of the channels-last 3x3x3 convolution: x [D,H,W,Cin], gy [D,H,W,64] -> dW [64,Cin,3,3,3]."""
     x = _need(x, "x")

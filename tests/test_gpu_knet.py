@@ -361,3 +361,30 @@ def test_knet_stack_dw_vs_generation_2(monkeypatch):
           ((a - b).abs().max().item(), a.abs().max().item(), (a - c).abs().max().item()))
     assert (a - b).abs().max().item() < 2e-4 * max(1.0, a.abs().max().item())
     assert (a - c).abs().max().item() < 2e-4 * max(1.0, a.abs().max().item())
+
+
+def test_conv_wino_dw_fused_batchnorm_finalisation():
+    """nrgbd_conv_wino_dw_bn_f32: (scale, shift) and the running statistics from the per-workgroup fp64 sums reduced by the last
+    workgroup inside the conv launch == the separate path (per-tile partials + nrgbd_bn_finalize_cm) and torch's batch_norm
+    statistics; the ticket is reset (a second launch gives the same answer); grids with more / fewer tile pairs than CUs."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for (D, H, W) in ((4, 16, 32), (40, 40, 80), (64, 8, 16)):
+        x = torch.randn(64, D, H, W, generator=g).to(DEV)
+        w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).to(DEV)
+        gamma, beta = torch.rand(64, generator=g).to(DEV) + 0.5, torch.randn(64, generator=g).to(DEV)
+        wp = ops.conv_wino_dw_pack(w)
+        y0, st, _ = ops.conv_wino_dw(_cl(x), wp, 64)
+        rm0, rv0 = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        ss0 = ops.bn_finalize_cm(st, D * H * W, gamma, beta, 1e-5, 0.1, rm0, rv0)
+        for rep in range(2):
+            rm1, rv1 = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+            y1, ss1, _ = ops.conv_wino_dw_bn(_cl(x), wp, gamma, beta, 1e-5, 0.1, rm1, rv1)
+            assert torch.equal(y0, y1)
+            assert (ss1 - ss0).abs().max().item() <= 2e-6 * ss0.abs().max().item()
+            assert (rm1 - rm0).abs().max().item() < 1e-6 and (rv1 - rv0).abs().max().item() < 1e-6
+        yd = y0.permute(3, 0, 1, 2).double()
+        mean, var = yd.mean((1, 2, 3)), yd.var((1, 2, 3), unbiased=False)
+        sc = gamma.double() / torch.sqrt(var + 1e-5)
+        want = torch.stack((sc, beta.double() - mean * sc), 1)
+        assert (ss1.double() - want).abs().max().item() < 1e-5 * want.abs().max().item()
