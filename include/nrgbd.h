@@ -131,14 +131,20 @@ int nrgbd_costvol_fwd_gen(const float* ref_nhwc, const float* src_nhwc,
  * Replaces: what autograd records for warping/homography.py:293-331 (grid_sample backward scatter-add,
  * broadcast subtract, channel sum).  Same geometry arguments as the forward.
  *   g_cost [D][h][w]  gradient of the loss w.r.t. out_cost
- *   g_ref  [h][w][Cp], g_src [V][h][w][Cp]   overwritten (zeroed by the call, then accumulated)
+ *   g_ref  [h][w][Cp], g_src [V][h][w][Cp]   overwritten
+ *   workspace         device scratch of at least nrgbd_costvol_bwd_workspace() bytes, 16-byte aligned (per-slice
+ *                     partial sums of the LDS scatter kernel); may be NULL when that size is 0 (grids whose
+ *                     16*h*w bytes exceed the LDS budget use global atomics instead).
+ * NRGBD_E_NULL / NRGBD_E_SHAPE when a needed workspace is missing / too small.
  */
+int nrgbd_costvol_bwd_workspace(int V, int Cp, int D, int h, int w, size_t* bytes);
 int nrgbd_costvol_bwd(const float* ref_nhwc, const float* src_nhwc,
                       const float* KR, const float* Kt, const float* rays,
                       const float* d_candi, float cx, float cy, float sigma,
                       int dist, int align_corners, const float* g_cost,
                       float* g_ref, float* g_src,
-                      int V, int C, int Cp, int D, int h, int w, void* stream);
+                      int V, int C, int Cp, int D, int h, int w,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * nrgbd_warp_volume — plane-sweep warp of low-channel maps with the samples kept, plus

@@ -14,6 +14,7 @@ _P = _c.c_void_p
 _F = _c.c_float
 _I = _c.c_int
 _L = _c.c_long
+_Z = _c.c_size_t
 
 # name -> (restype, argtypes); one entry per function of include/nrgbd.h
 SIGNATURES = {
@@ -26,8 +27,9 @@ SIGNATURES = {
                                _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_costvol_fwd_gen": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P,
                                    _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_costvol_bwd_workspace": (_I, [_I, _I, _I, _I, _I, _P]),
     "nrgbd_costvol_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P, _P,
-                               _I, _I, _I, _I, _I, _I, _P]),
+                               _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "nrgbd_warp_volume": (_I, [_P, _L, _L, _L, _L, _P, _L, _L, _L, _P, _P, _P, _P, _F, _F, _I,
                                _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_dpv_resample": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _I, _I, _P]),

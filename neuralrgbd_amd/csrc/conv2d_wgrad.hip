@@ -11,6 +11,10 @@
 // A = dY (global, 64-byte rows), B = X at the 9 tap offsets (LDS).  Wave (a, b) of the 16 owns the 16 x 16 sub-block
 // (co 16a.., ci 16b..) of every tap: 9 x v_mfma_f32_16x16x4_f32 accumulators.  Partials [workgroup][9][64][64] are reduced by a
 // second small kernel (no atomics: bitwise reproducible).
+// Round 3: the tile of dY is staged in LDS as well (all 1,024 threads, 16-byte coalesced loads) — the first version read a
+// lane's dY element straight from global memory inside every 4-pixel step, one exposed memory latency per 9 MFMAs — and a
+// workgroup owns ONE pixel tile (the 64x96 training grid has 240 of them per image batch: the first version's "at least four
+// tiles per workgroup" left 196 of 256 CUs idle to keep the partials small; the reduction now reads them 16 bytes per thread).
 #include "common.hpp"
 
 namespace nrgbd {
@@ -30,7 +34,8 @@ struct Wgrad2dArgs {
 template <int DIL>
 __global__ __launch_bounds__(1024) void conv2d_wgrad_kernel(const Wgrad2dArgs a) {
     constexpr int HH = kGH + 2 * DIL, HW = kGW + 2 * DIL, HALO = HH * HW;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [HALO][kGSV]
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // X halo [HALO][kGSV], then the dY tile [kGH*kGW][kGSV]
+    float* ldg = lds + HALO * kGSV;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int cog = blockIdx.y / a.ncig, cig = blockIdx.y - cog * a.ncig;
     const int cin0 = cig * 64, nci = min(64, a.Cin - cin0) >> 4;   // 16-channel sub-blocks of this block that exist
@@ -62,16 +67,24 @@ __global__ __launch_bounds__(1024) void conv2d_wgrad_kernel(const Wgrad2dArgs a)
                 v = *reinterpret_cast<const f32x4g*>(a.x + (((size_t)n * a.H + gy_) * a.W + gx) * a.Cin + cin0 + c4 * 4);
             *reinterpret_cast<f32x4g*>(lds + hv * kGSV + c4 * 4) = v;
         }
+        // ---- and the tile of dY (this block's output channels), zero outside the image ----
+        const int o4n = nco * 4;
+        for (int idx = tid; idx < kGH * kGW * o4n; idx += 1024) {
+            const int pv = idx / o4n, c4 = idx - pv * o4n;
+            const int vy = pv / kGW, vx = pv - vy * kGW;
+            const int gy_ = y0 + vy, gx = x0 + vx;
+            f32x4g v = {0.f, 0.f, 0.f, 0.f};
+            if (gy_ < a.H && gx < a.W)
+                v = *reinterpret_cast<const f32x4g*>(a.gy + (((size_t)n * a.H + gy_) * a.W + gx) * a.Cout + cog * 64 + c4 * 4);
+            *reinterpret_cast<f32x4g*>(ldg + pv * kGSV + c4 * 4) = v;
+        }
         __syncthreads();
         if (!wave_on) continue;
         // ---- 32 steps of 4 consecutive pixels (along x) ----
 #pragma unroll 1
         for (int step = 0; step < (kGH * kGW) / 4; ++step) {
             const int vy = step / (kGW / 4), vx = (step - vy * (kGW / 4)) * 4 + k4;   // this lane's pixel (k = lane >> 4)
-            const int gy_ = y0 + vy, gx = x0 + vx;
-            float av = 0.f;   // A[i = co][k = pixel]
-            if (gy_ < a.H && gx < a.W)
-                av = a.gy[(((size_t)n * a.H + gy_) * a.W + gx) * a.Cout + cog * 64 + cob * 16 + i16];
+            const float av = ldg[(vy * kGW + vx) * kGSV + cob * 16 + i16];   // A[i = co][k = pixel]
             const float* bbase = lds + (vy * HW + vx) * kGSV + cib * 16 + i16;  // B[k = pixel][j = ci], tap (0,0)
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -94,34 +107,49 @@ __global__ __launch_bounds__(1024) void conv2d_wgrad_kernel(const Wgrad2dArgs a)
     }
 }
 
-// dW[co][ci][tap] (torch layout [Cout][Cin][3][3]) = sum over the block's workgroups of partial[block][wg][tap][co % 64][ci % 64]
+// dW[co][ci][tap] (torch layout [Cout][Cin][3][3]) = sum over the block's workgroups of partial[block][wg][tap][co % 64][ci % 64].
+// Workgroup = 32 outputs (tap, co, 4 consecutive ci: 16-byte loads, coalesced along ci) x 8 interleaved slices of the
+// workgroup list; the slices are added through LDS in index order, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                                   int nwg, int Cin, int Cout, int ncig) {
-    const long n = (long)9 * Cin * Cout;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    const int tap = (int)(idx % 9);
-    const int ci = (int)((idx / 9) % Cin), co = (int)(idx / (9 * (long)Cin));
+    __shared__ f32x4g part[8][32];
+    const int cin4 = Cin >> 2;
+    const long n = (long)9 * cin4 * Cout;
+    const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long idx = (long)blockIdx.x * 32 + lane;
+    const bool live = idx < n;
+    const long id = live ? idx : 0;
+    const int c4 = (int)(id % cin4);
+    const int co = (int)((id / cin4) % Cout), tap = (int)(id / ((long)cin4 * Cout));
+    const int ci = c4 * 4;
     const int blk = (co >> 6) * ncig + (ci >> 6);
     const float* p = partial + (size_t)blk * nwg * (9 * 64 * 64) + ((size_t)tap * 64 + (co & 63)) * 64 + (ci & 63);
-    float s = 0.f;
-    for (int g = 0; g < nwg; ++g) s += p[(size_t)g * (9 * 64 * 64)];
-    dw[idx] = s;   // idx = (co * Cin + ci) * 9 + tap
+    f32x4g s4 = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+#pragma unroll 4
+        for (int g = sl; g < nwg; g += 8) s4 = s4 + *reinterpret_cast<const f32x4g*>(p + (size_t)g * (9 * 64 * 64));
+    }
+    part[sl][lane] = s4;
+    __syncthreads();
+    if (sl == 0 && live) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s4 = s4 + part[q][lane];
+        float* o = dw + ((size_t)co * Cin + ci) * 9 + tap;
+        o[0] = s4.x; o[9] = s4.y; o[18] = s4.z; o[27] = s4.w;
+    }
 }
 
 }  // namespace nrgbd
 
-// workgroups per 64 x 64 weight block: enough to fill the chip on large problems, but never fewer than 4 pixel tiles per
-// workgroup — every workgroup writes a 147 KB partial that the reduction has to read back (at the 64x96 training grid 256
-// single-tile workgroups made the reduction as expensive as the gradient itself)
+// workgroups per 64 x 64 weight block (each writes a 147 KB partial that the reduction reads back)
 extern "C" int nrgbd_conv2d_wgrad_workgroups(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || Cout % 16) return NRGBD_E_SHAPE;
     const int blocks = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     const long ntiles = (long)N * ((H + nrgbd::kGH - 1) / nrgbd::kGH) * ((W + nrgbd::kGW - 1) / nrgbd::kGW);
-    long per = 256 / blocks;
-    if (per < 1) per = 1;
-    if (per > (ntiles + 3) / 4) per = (ntiles + 3) / 4;
-    return (int)(per > 0 ? per : 1);
+    // one pixel tile per workgroup up to 1,024 workgroups per weight block (37 MB of partials per block at most), beyond that
+    // the workgroups walk the tile list
+    (void)blocks;
+    return (int)(ntiles < 1024 ? ntiles : 1024);
 }
 
 extern "C" int nrgbd_conv2d_wgrad_f32(const float* x, const float* gy, float* partial, float* dw, int N, int H, int W, int Cin,
@@ -133,7 +161,7 @@ extern "C" int nrgbd_conv2d_wgrad_f32(const float* x, const float* gy, float* pa
     const int ncig = (Cin + 63) / 64, blocks = ((Cout + 63) / 64) * ncig;
     const int nwg = nrgbd_conv2d_wgrad_workgroups(N, H, W, Cin, Cout);
     Wgrad2dArgs a{x, gy, partial, N, H, W, Cin, Cout, ncig};
-    const size_t lds = (size_t)(kGH + 2 * dilation) * (kGW + 2 * dilation) * kGSV * sizeof(float);   // 57.6 / 76.8 KB
+    const size_t lds = (size_t)((kGH + 2 * dilation) * (kGW + 2 * dilation) + kGH * kGW) * kGSV * sizeof(float);   // 98.6 / 117.8 KB
     hipError_t e;
     if (dilation == 1) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -144,8 +172,8 @@ extern "C" int nrgbd_conv2d_wgrad_f32(const float* x, const float* gy, float* pa
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(conv2d_wgrad_kernel<2>, dim3(nwg, blocks), dim3(1024), lds, (hipStream_t)stream, a);
     }
-    const long n = (long)9 * Cin * Cout;
-    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, dw,
+    const long n = (long)9 * (Cin / 4) * Cout;
+    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial, dw,
                        nwg, Cin, Cout, ncig);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;

@@ -95,16 +95,33 @@ __global__ __launch_bounds__(1024, 4) void conv3d_wgrad_kernel(const WgradArgs a
     }
 }
 
-// dW[co][ci][tap] (torch layout [64][Cin][27]) = sum over workgroups of partial[wg][tap][co][ci]
+// dW[co][ci][tap] (torch layout [64][Cin][27]) = sum over workgroups of partial[wg][tap][co][ci].  Workgroup = 32 outputs
+// (4 consecutive ci each, 16-byte loads) x 8 interleaved slices of the partial list, combined through LDS in index order.
 __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                                   int nwg, int Cin) {
-    const int n = 27 * 64 * Cin;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    float s = 0.f;
-    for (int g = 0; g < nwg; ++g) s += partial[(size_t)g * n + idx];
-    const int ci = idx % Cin, co = (idx / Cin) % 64, tap = idx / (Cin * 64);
-    dw[((size_t)co * Cin + ci) * 27 + tap] = s;
+    __shared__ float4 part[8][32];
+    const int n = 27 * 64 * Cin, n4 = n >> 2;
+    const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int idx4 = blockIdx.x * 32 + lane;
+    const bool live = idx4 < n4;
+    const int idx = live ? idx4 * 4 : 0;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+#pragma unroll 4
+        for (int g = sl; g < nwg; g += 8) {
+            const float4 q = *reinterpret_cast<const float4*>(partial + (size_t)g * n + idx);
+            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
+    }
+    part[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && live) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { s.x += part[q][lane].x; s.y += part[q][lane].y; s.z += part[q][lane].z; s.w += part[q][lane].w; }
+        const int ci = idx % Cin, co = (idx / Cin) % 64, tap = idx / (Cin * 64);
+        float* o = dw + ((size_t)co * Cin + ci) * 27 + tap;
+        o[0] = s.x; o[27] = s.y; o[54] = s.z; o[81] = s.w;
+    }
 }
 
 }  // namespace nrgbd
@@ -124,7 +141,7 @@ extern "C" int nrgbd_conv3d_wgrad_f32(const float* x, const float* gy, float* pa
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(conv3d_wgrad_kernel, dim3(nwg), dim3(1024), lds, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(ceil_div(27 * 64 * Cin, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(ceil_div(27 * 64 * Cin / 4, 32)), dim3(256), 0, (hipStream_t)stream,
                        partial, dw, nwg, Cin);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;

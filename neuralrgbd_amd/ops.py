@@ -141,10 +141,14 @@ def costvol_bwd(ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, cx, cy, sigma, C, g_c
     g_cost = _need(g_cost, "g_cost", (D, h, w))
     g_ref, g_src = torch.empty_like(ref_nhwc), torch.empty_like(src_nhwc)
     with torch.cuda.device(src_nhwc.device):
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(_lib.load().nrgbd_costvol_bwd_workspace(V, Cp, D, h, w, ctypes.byref(nbytes)), "nrgbd_costvol_bwd_workspace")
+        work = torch.empty(nbytes.value, dtype=torch.uint8, device=src_nhwc.device) if nbytes.value else None
         rc = _lib.load().nrgbd_costvol_bwd(_p(ref_nhwc), _p(src_nhwc), _p(_need(KR, "KR").reshape(V, 9)), _p(_need(Kt, "Kt", (V, 3))),
                                            _p(_need(rays, "rays", (3, h * w))), _p(d_candi), float(cx), float(cy), float(sigma),
                                            DIST[dist], int(bool(align_corners)), _p(g_cost), _p(g_ref), _p(g_src),
-                                           V, int(C), Cp, D, h, w, _stream(src_nhwc))
+                                           V, int(C), Cp, D, h, w, _p(work) if work is not None else None, nbytes.value,
+                                           _stream(src_nhwc))
     _lib.check(rc, "nrgbd_costvol_bwd")
     return g_ref, g_src
 

@@ -29,7 +29,10 @@ def _torch_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, sigma, dis
     return cost
 
 
-@pytest.mark.parametrize("h,w,D,V,C,dist", [(12, 20, 6, 2, 7, "L2"), (16, 24, 8, 4, 67, "L2"), (10, 14, 4, 3, 5, "L1")])
+# 64x96 is the training grid (LDS scatter kernel, one depth slice per ~CU share); 96x128 exceeds the LDS plane budget
+# (16*h*w bytes > 144 KB) and takes the global-atomic kernel
+@pytest.mark.parametrize("h,w,D,V,C,dist", [(12, 20, 6, 2, 7, "L2"), (16, 24, 8, 4, 67, "L2"), (10, 14, 4, 3, 5, "L1"),
+                                            (64, 96, 16, 2, 67, "L2"), (96, 128, 4, 1, 6, "L2")])
 def test_costvol_backward_vs_torch_autograd(h, w, D, V, C, dist):
     from neuralrgbd_amd.autograd import PlaneSweepCost
     from neuralrgbd_amd import ops
@@ -60,6 +63,27 @@ def test_costvol_backward_vs_torch_autograd(h, w, D, V, C, dist):
     err = (f2.grad - f1.grad).abs().max().item()
     print("[parity] costvol backward %s C=%d: max|d grad|=%.2e (|grad|max %.2f)" % (dist, C, err, scale))
     assert err < 2e-4 * max(1.0, scale)
+
+
+def test_costvol_backward_workspace_contract():
+    import ctypes
+    from neuralrgbd_amd import _lib
+    lib = _lib.load()
+    n = ctypes.c_size_t(7)
+    assert lib.nrgbd_costvol_bwd_workspace(4, 68, 64, 64, 96, ctypes.byref(n)) == 0
+    words, hw = 17, 64 * 96
+    assert n.value % (2 * 4 * words * hw * 16) == 0 and 1 <= n.value // (2 * 4 * words * hw * 16) <= 16   # whole depth slices
+    assert lib.nrgbd_costvol_bwd_workspace(1, 8, 4, 96, 128, ctypes.byref(n)) == 0 and n.value == 0          # over the LDS budget
+    assert lib.nrgbd_costvol_bwd_workspace(4, 68, 64, 64, 96, None) < 0
+    # a grid that needs the workspace refuses to run without it (nothing is substituted)
+    t = torch.zeros(2, 8, 8, 8, device=DEV)
+    z = torch.zeros(64, device=DEV)
+    args = [t[1].data_ptr(), t[:1].data_ptr(), z.data_ptr(), z.data_ptr(), torch.zeros(3, 64, device=DEV).data_ptr(), z.data_ptr(),
+            4.0, 4.0, 1.0, 0, 0, torch.zeros(4, 8, 8, device=DEV).data_ptr(), torch.empty_like(t[1]).data_ptr(),
+            torch.empty_like(t[:1]).data_ptr(), 1, 8, 8, 4, 8, 8]
+    assert lib.nrgbd_costvol_bwd(*args, None, 0, None) == -1
+    small = torch.empty(64, dtype=torch.uint8, device=DEV)
+    assert lib.nrgbd_costvol_bwd(*args, small.data_ptr(), 64, None) == -2
 
 
 def test_one_training_iteration_updates_weights_and_predicts():
