@@ -243,15 +243,17 @@ def train_main(args):
     world, rank, local = init_world(args.gpus, "nccl")
     import neuralrgbd_amd
     from neuralrgbd_amd import camera, distributed as nd, ops, synth
-    from neuralrgbd_amd.train_step import train
+    from neuralrgbd_amd.train_step import TrainGraph, train
     H, W, D = 256, 384, 64
     cam = camera.scannet_intrinsics(W // 4, H // 4)
     d_candi = np.linspace(0.1, 5, D)
     model = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
     model.load_state_dict(synth.seeded_state_dict(model, 0))
     model = model.to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-5, betas=(.9, .999))      # local_train_scanNet.sh
+    use_graph = world == 1 and not args.no_graph      # single-GPU: the iteration replayed as one hipGraph (train_step.TrainGraph)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-5, betas=(.9, .999), capturable=use_graph)      # local_train_scanNet.sh
     reducer = nd.GradAllReduce(model) if world > 1 else None
+    tg = TrainGraph(model, opt, 2, d_candi, cam, warmup=0) if use_graph else None
     rng = np.random.RandomState(rank)
     wins = []
     for it in range(4):
@@ -264,12 +266,19 @@ def train_main(args):
     ops.conv_wino_dw = knet_timer.wrap(ops.conv_wino_dw)
     state = {"pred": None, "loss": None}
 
-    def step(i):
+    def step(i, eager=False):
         ref, src, p = wins[i % len(wins)]
+        if tg is not None and not eager:
+            srcs = torch.cat([s_["img"] for s_ in src[0]], dim=0).unsqueeze(0)
+            loss, pred = tg.step(ref[0]["img"], srcs, p, ref[0]["dmap"], ref[0]["dmap_imgsize_digit"], state["pred"])
+            state["pred"], state["loss"] = pred.clone(), loss      # the graph's outputs are static buffers
+            return
         _, state["pred"], state["loss"], _, _ = train(world, model, opt, 2, d_candi, ref, src, p, state["pred"], [cam],
                                                       grad_reducer=reducer)
+    for i in range(2):      # first frame + one update frame launched from Python: filter state, optimizer state, caches, vendor find
+        step(i, eager=True)
     for i in range(max(args.warmup, 2)):
-        step(i)
+        step(i + 2)
     dt = timed_steps(step, args.steps, world, dev)
     assert bool(torch.isfinite(state["loss"])), "training loss went non-finite"
     if rank == 0:
@@ -278,6 +287,7 @@ def train_main(args):
                 "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "ScanNet training window 384x256 image, grid 96x64x64cand, Adam lr 1e-5", "mode": "train",
+                           "launch": "hipGraph replay" if tg is not None else "eager",
                            "parallelism": "data-parallel x%d, one bucketed gradient all-reduce per step (%.2f MB fp32)" %
                                           (world, 4e-6 * sum(p.numel() for p in set(model.parameters()))),
                            "loss": float(state["loss"])}}

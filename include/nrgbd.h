@@ -147,6 +147,26 @@ int nrgbd_costvol_bwd(const float* ref_nhwc, const float* src_nhwc,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * nrgbd_bn_cl_fwd / nrgbd_bn_cl_bwd — train-mode BatchNorm (batch statistics, biased variance) with its ReLU and residual add,
+ * forward and backward, on channels-last activations viewed as x [rows][C] (training path, BASELINE config 4).
+ * Replaces what autograd records for models/psm_submodule.py:10-16,31-50 (convbn / BasicBlock: nn.BatchNorm2d, ReLU, `out += x`)
+ * and models/basic.py:53-68,71-94 (convbn_3d / KV_NET_BASIC: nn.BatchNorm3d, ReLU, residual adds) under
+ * train_utils/train_KVNet.py:152 (loss.backward()).
+ *   y = act(x*scale + shift) + res        res may be NULL; relu 0/1
+ *   coef [4][C]   scale = gamma*invstd, shift = beta - mean*scale, mean, invstd   (forward writes, backward reads)
+ *   running_mean / running_var: both NULL, or updated in place with `momentum` (unbiased variance), as nn.BatchNorm does
+ *   backward: gx [rows][C], g_gamma [C], g_beta [C]; the gradient of `res` is gy itself; coef2 [2][C] is scratch
+ *   partial: scratch of nrgbd_bn_cl_workgroups(rows, C) x 2*C floats (per-workgroup partial sums, added in index order in double)
+ * C % 4 == 0 and 256 % (C/4) == 0 (NRGBD_E_SHAPE otherwise).
+ */
+int nrgbd_bn_cl_workgroups(long rows, int C);
+int nrgbd_bn_cl_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, int relu, float* y, float* coef, float* partial,
+                    long rows, int C, void* stream);
+int nrgbd_bn_cl_bwd(const float* x, const float* gy, const float* coef, int relu, float* gx, float* g_gamma,
+                    float* g_beta, float* coef2, float* partial, long rows, int C, void* stream);
+
+/*
  * nrgbd_warp_volume — plane-sweep warp of low-channel maps with the samples kept, plus
  * the K-Net input-volume assembly.
  * Replaces: warping/homography.py:234-280 warp_img_feats_v3 / :183-232 warp_img_feats_mgpu

@@ -30,6 +30,9 @@ SIGNATURES = {
     "nrgbd_costvol_bwd_workspace": (_I, [_I, _I, _I, _I, _I, _P]),
     "nrgbd_costvol_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P, _P,
                                _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "nrgbd_bn_cl_workgroups": (_I, [_L, _I]),
+    "nrgbd_bn_cl_fwd": (_I, [_P, _P, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P, _L, _I, _P]),
+    "nrgbd_bn_cl_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _P]),
     "nrgbd_warp_volume": (_I, [_P, _L, _L, _L, _L, _P, _L, _L, _L, _P, _P, _P, _P, _F, _F, _I,
                                _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_dpv_resample": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P, _I, _I, _I, _P]),

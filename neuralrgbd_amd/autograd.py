@@ -105,6 +105,52 @@ class Conv3dCL(torch.autograd.Function):
         return gx, gw
 
 
+class BatchNormActCL(torch.autograd.Function):
+    """y = act(batch_norm(x)) + residual on a channels-last tensor x [..., C] (batch statistics over every leading axis), forward
+    and backward on csrc/bn_train.hip — nn.BatchNorm2d / nn.BatchNorm3d + ReLU + residual add of models/psm_submodule.py:10-16,31-50
+    and models/basic.py:53-68,71-94 in training.  The running statistics (if any) are updated by the forward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, eps, relu, momentum, running_mean, running_var):
+        C = x.shape[-1]
+        x2 = x.contiguous().view(-1, C)
+        r2 = None if residual is None else residual.contiguous().view(-1, C)
+        y, coef = ops.bn_cl_fwd(x2, weight, bias, eps, relu, r2, momentum, running_mean, running_var)
+        ctx.save_for_backward(x2, coef)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, coef = ctx.saved_tensors
+        gy2 = gy.contiguous().view(x2.shape)
+        gx, gg, gb = ops.bn_cl_bwd(x2, gy2, coef, ctx.relu)
+        return gx.view(gy.shape), gg, gb, (gy if ctx.has_res else None), None, None, None, None, None
+
+
+def batch_norm_act_cl(x_cl, bn, relu, residual=None):
+    """Train-mode nn.BatchNorm{2,3}d `bn` (+ ReLU, + residual) applied to the channels-last tensor x_cl [..., C] under autograd.
+    NRGBD_TRAIN_BN=vendor keeps torch's batch_norm / relu / add (A/B); shapes bn_train.hip has no form for take that path too."""
+    import os
+    import torch.nn.functional as F
+    C = x_cl.shape[-1]
+    use_batch = bn.training or not bn.track_running_stats
+    upd = bn.training and bn.track_running_stats
+    if upd:
+        bn.num_batches_tracked += 1
+    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    if (use_batch and x_cl.is_cuda and x_cl.dtype == torch.float32 and bn.affine and ops.bn_cl_supported(x_cl.numel() // C, C)
+            and os.environ.get("NRGBD_TRAIN_BN", "native") == "native"):
+        return BatchNormActCL.apply(x_cl, bn.weight, bn.bias, residual, bn.eps, relu, m,
+                                    bn.running_mean if upd else None, bn.running_var if upd else None)
+    y = F.batch_norm(x_cl.reshape(-1, C), bn.running_mean if bn.track_running_stats else None,
+                     bn.running_var if bn.track_running_stats else None, bn.weight, bn.bias, use_batch, m, bn.eps).view_as(x_cl)
+    if relu:
+        y = torch.relu(y)
+    return y if residual is None else y + residual
+
+
 class Conv2dCL(torch.autograd.Function):
     """3x3 convolution (stride 1, padding = dilation, no bias) of the feature CNN / R-Net under autograd, all three directions
     on the hand-written matrix-core kernels (models/psm_submodule.py:10-16, models/m_submodule.py:18-27 in training,

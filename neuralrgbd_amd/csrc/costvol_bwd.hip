@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBwdThreads) void costvol_bwd_lds_kernel(const Cost
             for (int tpi = 0; tpi < 4; ++tpi)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (acc[tpi][e] != 0.f) atomicAdd(gl + e * hw + o[tpi], acc[tpi][e]);
+                    if (acc[tpi][e] != 0.f && !(a.abl & 1)) atomicAdd(gl + e * hw + ((a.abl & 4) ? min(p + tpi, hw - 1) : o[tpi]), acc[tpi][e]);
         };
         for (int k = k_begin; k < k_end; ++k) {
             const float gk = a.g_cost[(size_t)k * hw + p] / inv_sigma_den;
@@ -164,10 +164,13 @@ __global__ __launch_bounds__(kBwdThreads) void costvol_bwd_lds_kernel(const Cost
                     for (int e = 0; e < 4; ++e) acc[tpi][e] = 0.f;
             }
             if (gk == 0.f) continue;
-            const float4 A = *reinterpret_cast<const float4*>(sv + (size_t)o[0] * a.Cp);
-            const float4 B = *reinterpret_cast<const float4*>(sv + (size_t)o[1] * a.Cp);
-            const float4 Cc = *reinterpret_cast<const float4*>(sv + (size_t)o[2] * a.Cp);
-            const float4 Dd = *reinterpret_cast<const float4*>(sv + (size_t)o[3] * a.Cp);
+            float4 A = r, B = r, Cc = r, Dd = r;
+            if (!(a.abl & 2)) {
+                A = *reinterpret_cast<const float4*>(sv + (size_t)o[0] * a.Cp);
+                B = *reinterpret_cast<const float4*>(sv + (size_t)o[1] * a.Cp);
+                Cc = *reinterpret_cast<const float4*>(sv + (size_t)o[2] * a.Cp);
+                Dd = *reinterpret_cast<const float4*>(sv + (size_t)o[3] * a.Cp);
+            }
             const float df[4] = {lerp4(A.x, B.x, Cc.x, Dd.x, b) - r.x, lerp4(A.y, B.y, Cc.y, Dd.y, b) - r.y,
                                  lerp4(A.z, B.z, Cc.z, Dd.z, b) - r.z, lerp4(A.w, B.w, Cc.w, Dd.w, b) - r.w};
             const float wt[4] = {b.nw, b.ne, b.sw, b.se};
@@ -268,7 +271,7 @@ extern "C" int nrgbd_costvol_bwd(const float* ref_nhwc, const float* src_nhwc, c
         float* part_src = static_cast<float*>(workspace);
         float* part_ref = part_src + half;
         CostvolBwdArgs a{ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, g_cost, g_ref, g_src, cx, cy, sigma,
-                         dist, align_corners, V, C, Cp, D, h, w, lds_kc, 0};
+                         dist, align_corners, V, C, Cp, D, h, w, lds_kc, dev_env_int("NRGBD_BWD_ABL")};
         const size_t lds = hw * 16;
         hipError_t e = hipSuccess;
         if (lds > 64 * 1024)

@@ -186,8 +186,13 @@ def _conv_bn_act(x, seq, relu, residual=None):
     """
     conv, bn = seq[0], seq[1]
     if torch.is_grad_enabled():
-        from .autograd import conv2d_module
+        from .autograd import conv2d_module, batch_norm_act_cl
         y = conv2d_module(conv, x)           # training: forward / data gradient / weight gradient on the hand-written kernels
+        cl = torch.channels_last
+        if y.is_cuda and y.is_contiguous(memory_format=cl) and (residual is None or residual.is_contiguous(memory_format=cl)):
+            # BatchNorm2d + ReLU + add in both directions on csrc/bn_train.hip, on the NHWC view of the channels-last map
+            r = None if residual is None else residual.permute(0, 2, 3, 1)
+            return batch_norm_act_cl(y.permute(0, 2, 3, 1), bn, relu, r).permute(0, 3, 1, 2)
     else:
         y = conv(x)
     use_batch = bn.training or not bn.track_running_stats
@@ -470,6 +475,10 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         return half, feat
 
     def forward(self, x):
+        if x.is_cuda and torch.is_grad_enabled():
+            # training: the whole trunk in channels-last memory, the layout of the hand-written conv / BatchNorm kernels (the vendor
+            # convolutions left in the graph keep the format of their input)
+            x = x.contiguous(memory_format=torch.channels_last)
         stem = x
         for i in (0, 2, 4):
             stem = _conv_bn_act(stem, self.firstconv[i], relu=True)
@@ -664,29 +673,19 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         """Training path: same graph on channels-last activations with the convolutions (forward, data gradient and
         weight gradient) on the hand-written matrix-core kernels (autograd.Conv3dCL); BatchNorm3d / ReLU / adds are
         ordinary torch autograd ops applied in place of the layout (no NCDHW round trips).  vol [D,H,W,Cin] -> [D,H,W]."""
-        from .autograd import Conv3dCL
+        from .autograd import Conv3dCL, batch_norm_act_cl
         L = self._layers()
 
-        def bn_cl(x_cl, bn):
-            """BatchNorm3d on a channels-last tensor without any layout change: [D,H,W,C] viewed as (N = voxels, C)
-            is exactly the (N, C) form of batch_norm — same statistics, same running-stat update."""
-            if bn.training and bn.track_running_stats:
-                bn.num_batches_tracked += 1
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            use_batch = bn.training or not bn.track_running_stats
-            y = F.batch_norm(x_cl.reshape(-1, x_cl.shape[-1]), bn.running_mean if bn.track_running_stats else None,
-                             bn.running_var if bn.track_running_stats else None, bn.weight, bn.bias, use_batch, m, bn.eps)
-            return y.view_as(x_cl)
-
-        def cbr(x_cl, i, relu):
+        def cbr(x_cl, i, relu, res=None):
+            """conv -> BatchNorm3d -> [ReLU] -> [+ res].  [D,H,W,C] viewed as (voxels, C) is exactly the (N, C) form of batch_norm:
+            same statistics, same running-statistics update; csrc/bn_train.hip in both directions."""
             conv, bn = L[i]
-            y = bn_cl(Conv3dCL.apply(x_cl, conv.weight), bn)
-            return torch.relu(y) if relu else y
+            return batch_norm_act_cl(Conv3dCL.apply(x_cl, conv.weight), bn, relu, res)
 
         x = cbr(vol, 0, True)
         x = cbr(x, 1, True)
         for i in (2, 4, 6, 8):
-            x = cbr(cbr(x, i, True), i + 1, False) + x
+            x = cbr(cbr(x, i, True), i + 1, False, x)
         y = cbr(x, 10, True)
         # classify.2 = Conv3d(64, 1): zero-padded to 64 outputs so that forward, data gradient and weight gradient
         # all run on the matrix-core kernels (the vendor weight-gradient of this layer alone costs 58 ms at the

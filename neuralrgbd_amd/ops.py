@@ -748,6 +748,52 @@ def conv_wino_rnet(x, w_wino, cout, bias=None, lrelu=True, out=None, ycoff=0, co
     return out
 
 
+def bn_cl_supported(rows, C):
+    """Shapes of the channels-last train-mode BatchNorm kernels (bn_train.hip): 16-byte channel quads that tile a 256-lane workgroup."""
+    return rows > 0 and 4 <= C <= 1024 and C % 4 == 0 and 256 % (C // 4) == 0
+
+
+def bn_cl_fwd(x, gamma, beta, eps, relu, residual=None, momentum=0.0, running_mean=None, running_var=None):
+    """y = act(batchnorm(x)) + residual with batch statistics over the rows of x [rows, C] (contiguous, channels last).
+    Returns (y, coef [4,C] = scale, shift, mean, invstd); updates the running statistics in place when given."""
+    x = _need(x, "x")
+    rows, C = x.shape
+    if residual is not None:
+        residual = _need(residual, "residual", (rows, C))
+    y = torch.empty_like(x)
+    coef = torch.empty((4, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        lib = _lib.load()
+        G = lib.nrgbd_bn_cl_workgroups(rows, C)
+        _lib.check(min(G, 0), "nrgbd_bn_cl_workgroups")
+        partial = torch.empty((G, 2 * C), dtype=torch.float32, device=x.device)
+        rc = lib.nrgbd_bn_cl_fwd(_p(x), _p(residual), _p(_need(gamma, "gamma", (C,))), _p(_need(beta, "beta", (C,))), float(eps),
+                                 float(momentum), _p(running_mean), _p(running_var), int(bool(relu)), _p(y), _p(coef), _p(partial),
+                                 rows, C, _stream(x))
+    _lib.check(rc, "nrgbd_bn_cl_fwd")
+    return y, coef
+
+
+def bn_cl_bwd(x, gy, coef, relu):
+    """Backward of bn_cl_fwd w.r.t. (x, gamma, beta): gx [rows, C], g_gamma [C], g_beta [C] (the residual's gradient is gy)."""
+    x = _need(x, "x")
+    rows, C = x.shape
+    gy = _need(gy, "gy", (rows, C))
+    coef = _need(coef, "coef", (4, C))
+    gx = torch.empty_like(x)
+    gg = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    coef2 = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        lib = _lib.load()
+        G = lib.nrgbd_bn_cl_workgroups(rows, C)
+        _lib.check(min(G, 0), "nrgbd_bn_cl_workgroups")
+        partial = torch.empty((G, 2 * C), dtype=torch.float32, device=x.device)
+        rc = lib.nrgbd_bn_cl_bwd(_p(x), _p(gy), _p(coef), int(bool(relu)), _p(gx), _p(gg[0]), _p(gg[1]), _p(coef2), _p(partial),
+                                 rows, C, _stream(x))
+    _lib.check(rc, "nrgbd_bn_cl_bwd")
+    return gx, gg[0], gg[1]
+
+
 def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
     """Column-major per-tile partials [2C, rows] (conv_wino) -> scale_shift [C,2]; updates the running statistics in place."""
     stats = _need(stats, "stats")

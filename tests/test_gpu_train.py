@@ -356,3 +356,38 @@ def test_feature_cnn_training_path_native_vs_vendor_convs(monkeypatch):
     # moves one layer's gradient by ~1e-2 of its scale (see test_knet_training_path_vs_fp64_autograd); the convolutions
     # themselves agree with float64 to 1e-6 (test_conv2d_autograd_function_vs_fp64)
     assert worst < 5e-2
+
+
+@pytest.mark.parametrize("rows,C,relu,res", [(1000, 64, True, False), (37, 32, False, True), (4099, 128, True, True), (513, 16, True, False),
+                                              (64 * 96 * 4, 64, False, True)])
+def test_batchnorm_act_channels_last_vs_fp64_autograd(rows, C, relu, res):
+    """csrc/bn_train.hip (statistics, normalise + ReLU + residual, and the whole backward) vs torch batch_norm in fp64."""
+    from neuralrgbd_amd.autograd import BatchNormActCL
+    g = torch.Generator(device="cpu").manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.7).to(DEV)
+    r = torch.randn(rows, C, generator=g).to(DEV) if res else None
+    w, b = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    gy = torch.randn(rows, C, generator=g).to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+
+    xs = [t.clone().requires_grad_(True) for t in (x, w, b)] + ([r.clone().requires_grad_(True)] if res else [None])
+    y = BatchNormActCL.apply(xs[0], xs[1], xs[2], xs[3], 1e-5, relu, 0.1, rm, rv)
+    y.backward(gy)
+
+    xd = [t.double().clone().requires_grad_(True) for t in (x, w, b)] + ([r.double().clone().requires_grad_(True)] if res else [None])
+    rmd, rvd = torch.zeros(C, device=DEV, dtype=torch.float64), torch.ones(C, device=DEV, dtype=torch.float64)
+    yd = F.batch_norm(xd[0], rmd, rvd, xd[1], xd[2], True, 0.1, 1e-5)
+    if relu:
+        yd = torch.relu(yd)
+    if res:
+        yd = yd + xd[3]
+    yd.backward(gy.double())
+    assert (y.double() - yd).abs().max().item() < 2e-5
+    assert (rm.double() - rmd).abs().max().item() < 1e-6 and (rv.double() - rvd).abs().max().item() < 1e-5
+    for got, want, name in zip(xs, xd, ("x", "gamma", "beta", "residual")):
+        if got is None:
+            continue
+        scale = max(1.0, want.grad.abs().max().item())
+        err = (got.grad.double() - want.grad).abs().max().item()
+        print("[parity] bn_cl rows=%d C=%d d%s: %.2e (|grad|max %.2f)" % (rows, C, name, err, scale))
+        assert err < 2e-5 * scale, name
