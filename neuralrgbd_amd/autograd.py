@@ -201,17 +201,17 @@ class Conv2dCL(torch.autograd.Function):
 
 
 def conv2d_module(conv, x):
-    """nn.Conv2d forward for the module (autograd) paths.  NRGBD_TRAIN_CONV=native routes every 3x3 stride-1 convolution with a
-    kernel in all three directions (CUDA, fp32, padding = dilation) through Conv2dCL; the default stays the vendor library:
-    at the 64x96 training grid the hand-written path is correct to 1e-6 but not faster — 54.1 vs 48.0 ms per iteration
-    launched from Python, 53.1 vs 51.4 ms replayed as a hipGraph (two extra launches per layer and direction for the weight
-    transforms, and weight-gradient partials whose reduction costs as much as the gradient on grids this small)."""
+    """nn.Conv2d forward for the module (autograd) paths: every 3x3 stride-1 convolution with a kernel in all three directions
+    (CUDA, fp32, padding = dilation) goes through Conv2dCL.  NRGBD_TRAIN_CONV=vendor keeps the vendor library for A/B: at the
+    64x96 training grid, round 3, the iteration replayed as a hipGraph takes 38.7 ms on the hand-written kernels and 41.4 ms on
+    the vendor convolutions (round 2: 53.1 vs 51.4 ms — since then the weight-gradient kernel stages its dY tile in LDS and its
+    partials are reduced by 8 slices per workgroup)."""
     import os
     d = conv.dilation[0]
     if (x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (d, d) and conv.dilation == (d, d) and conv.groups == 1
             and Conv2dCL.eligible(conv.in_channels, conv.out_channels, d)
-            and os.environ.get("NRGBD_TRAIN_CONV", "vendor") == "native"):
+            and os.environ.get("NRGBD_TRAIN_CONV", "native") == "native"):
         y = Conv2dCL.apply(x, conv.weight, d)
         return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
     return conv(x)

@@ -53,3 +53,70 @@ def test_rccl_single_rank_gradient_allreduce_and_max_over_ranks():
             assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-7)
     finally:
         dist.destroy_process_group()
+
+
+def _train_replica(rank, world, port, q):
+    """One data-parallel replica of the REAL training step (train_step.train: forward under autograd on the HIP kernels, 4 NLL
+    terms, backward, bucketed gradient all-reduce from backward hooks, Adam, PREDICT) — both replicas share the box's single GPU,
+    so the process group is gloo on device tensors; what is exercised is everything but the RCCL transport."""
+    import hashlib
+    import os
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    import neuralrgbd_amd
+    from neuralrgbd_amd import camera, distributed as nd, synth
+    from neuralrgbd_amd.train_step import train
+    try:
+        nd.init_from_env("gloo")
+        H, W, D = 256, 256, 8            # the smallest image whose 1/4 grid holds the 64x64 SPP window
+        cam = camera.scannet_intrinsics(W // 4, H // 4)
+        d_candi = np.linspace(0.1, 5, D)
+        model = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+        model.load_state_dict(synth.seeded_state_dict(model, 0))
+        model = model.to(DEV)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(.9, .999))
+        reducer = nd.GradAllReduce(model, bucket_mb=2.0)
+        rng = np.random.RandomState(10 + rank)
+        pred, losses, hooks = None, [], []
+        for it in range(3):                         # frame 0 has no predicted volume (3 loss terms use the K-Net only later)
+            r, s, p = synth.noise_window(1000 * rank + it, H, W)          # different windows on each replica
+            ref = [{"img": r.to(DEV), "dmap": torch.from_numpy(rng.randint(0, D, (1, H // 4, W // 4))).to(DEV),
+                    "dmap_imgsize_digit": torch.from_numpy(rng.randint(0, D, (1, H, W))).to(DEV)}]
+            src = [[{"img": s[0, v:v + 1].to(DEV)} for v in range(4)]]
+            _, pred, loss, _, _ = train(world, model, opt, 2, d_candi, ref, src, p.to(DEV), pred, [cam], grad_reducer=reducer)
+            losses.append(float(loss))
+            hooks.append(reducer.launched_in_backward)
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for _, prm in sorted(model.named_parameters()):
+            h.update(prm.detach().cpu().numpy().tobytes())
+        q.put((rank, {"hash": h.hexdigest(), "losses": losses, "hooks": hooks, "n_buckets": len(reducer.buckets)}))
+        dist.barrier()
+    except Exception as e:          # report instead of hanging the parent
+        q.put((rank, {"error": repr(e)}))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_replicas_of_the_real_training_step_stay_bit_identical():
+    """the real train() on two ranks with different windows -> every parameter bit-identical after 3 steps
+    (first frame + two update frames), collectives started from backward hooks, different losses per rank."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_replica, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    for r in range(world):
+        assert "error" not in res[r], res[r]
+    a, b = res[0], res[1]
+    print("[dist] replicas: losses %s vs %s, buckets %d, launched in backward %s" % (a["losses"], b["losses"], a["n_buckets"], a["hooks"]))
+    assert a["hash"] == b["hash"]
+    assert a["losses"] != b["losses"]
+    assert a["n_buckets"] >= 3 and max(a["hooks"]) >= 2
