@@ -150,6 +150,28 @@ def cpu_baseline(cfg, cam, d_candi, sd, window, bv_pred, sigma):
                       "(%.1f s) + 2 timed (%.1f, %.1f s), median reported" % (cfg, times[0], times[1], times[2])}, out
 
 
+def cpu_baseline_train(model, cam, d_candi, wins, sigma):
+    """--mode train: the same training window through oracle/train_oracle.py (the CPU restatement of the reference's train()
+    under torch autograd, pinned to tests/golden/train_small.npz) on the host cores: one first-frame iteration to create the
+    filter state and the Adam moments, then one timed update-branch iteration (4 NLL terms, backward, Adam, PREDICT)."""
+    from oracle import cpu_oracle, train_oracle
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    cpu_oracle.set_threads(cores)
+    leaves = train_oracle.leaf_state({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    opt = torch.optim.Adam(train_oracle.parameters(leaves), lr=1e-5, betas=(.9, .999))
+    pred, times, loss = None, [], None
+    for ref, src, p in wins[:2]:
+        srcs = torch.cat([s_["img"] for s_ in src[0]], dim=0).unsqueeze(0).cpu()
+        t0 = time.time()
+        loss, pred = train_oracle.train_iteration(leaves, opt, ref[0]["img"].cpu(), srcs, p.cpu(), ref[0]["dmap"].cpu(),
+                                                  ref[0]["dmap_imgsize_digit"].cpu(), cam, d_candi, sigma, pred)
+        times.append(time.time() - t0)
+    return {"value": 1.0 / times[1], "unit": "windows/s", "cores": cores, "kind": "port", "loss": float(loss),
+            "sample": "one update-branch training iteration of the same window shape through oracle/train_oracle.py (%.1f s), after "
+                      "one first-frame iteration (%.1f s, untimed)" % (times[1], times[0])}
+
+
 def parity_block(cfg, gpu, oracle_out):
     """GPU frame vs the oracle's frame on the same window and the same filter state: max / mean |d| and arg-max
     depth-index mismatches of BV_cur, DPV, BV_predict and the refined DPV (BASELINE.json gates: L1 < 1e-4, arg-max exact)."""
@@ -302,6 +324,8 @@ def train_main(args):
                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                 "flops": flops, "direct_conv_flops": 2.0 * a0.shape[0] * a0.shape[1] * a0.shape[2] * 64 * 64 * 27,
                                 "traffic": None, "kernel_ms": c_ms}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_train(model, cam, d_candi, wins, 10.0)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

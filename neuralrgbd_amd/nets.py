@@ -188,10 +188,11 @@ def _conv_bn_act(x, seq, relu, residual=None):
     if torch.is_grad_enabled():
         from .autograd import conv2d_module, batch_norm_act_cl
         y = conv2d_module(conv, x)           # training: forward / data gradient / weight gradient on the hand-written kernels
-        cl = torch.channels_last
-        if y.is_cuda and y.is_contiguous(memory_format=cl) and (residual is None or residual.is_contiguous(memory_format=cl)):
-            # BatchNorm2d + ReLU + add in both directions on csrc/bn_train.hip, on the NHWC view of the channels-last map
-            r = None if residual is None else residual.permute(0, 2, 3, 1)
+        if y.is_cuda:
+            # BatchNorm2d + ReLU + add in both directions on csrc/bn_train.hip, on the NHWC view of the channels-last map (a
+            # vendor convolution that answered in NCHW — some tiny SPP shapes — is converted first: a no-op otherwise)
+            y = y.contiguous(memory_format=torch.channels_last)
+            r = None if residual is None else residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
             return batch_norm_act_cl(y.permute(0, 2, 3, 1), bn, relu, r).permute(0, 3, 1, 2)
     else:
         y = conv(x)

@@ -1,11 +1,12 @@
 """The CPU oracle against the golden vectors generated from the unmodified reference
 (oracle/gen_golden.py).  CPU only; this is what pins the oracle (prompt §3)."""
 import math
+import os
 
 import numpy as np
 import torch
 
-from conftest import report
+from conftest import GOLDEN, report
 from neuralrgbd_amd import camera, synth
 from oracle import cpu_oracle as co
 from oracle import gen_golden, kvnet_oracle as ko
@@ -238,3 +239,35 @@ def test_pose_inverse_is_the_rounded_float64_inverse():
     import pytest
     with pytest.raises(np.linalg.LinAlgError):
         co.pose_inverse(np.zeros((4, 4), np.float32))
+
+
+def test_training_oracle_vs_reference_train_golden():
+    """oracle/train_oracle.py (the CPU training iteration under autograd: grid_sample cost volume, functional networks, 4 NLL
+    terms, SGD, PREDICT) against two iterations of the unmodified reference's own train() (tests/golden/train_small.npz):
+    losses, predicted filter state, and the SGD weight deltas (= lr x gradient) of six probe tensors."""
+    import neuralrgbd_amd
+    from oracle import gen_golden, train_oracle
+    t = gen_golden.TRAIN
+    g = dict(np.load(os.path.join(GOLDEN, "train_small.npz")))
+    cam = camera.scannet_intrinsics(t["W"] // 4, t["H"] // 4)
+    d_candi = np.linspace(0.1, 5, t["D"])
+    model = neuralrgbd_amd.KVNET(64, cam, d_candi, t["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    leaves = train_oracle.leaf_state(synth.seeded_state_dict(model, t["weight_seed"]))
+    opt = torch.optim.SGD(train_oracle.parameters(leaves), lr=t["lr"])
+    pred = None
+    for it, (r, s, p, dm, dmf) in enumerate(gen_golden.train_inputs()):
+        before = {k: leaves[k].detach().clone() for k in t["probes"]}
+        loss, pred = train_oracle.train_iteration(leaves, opt, r, s, p, dm, dmf, cam, d_candi, t["sigma"], pred)
+        want = float(g["loss_%d" % it])
+        e_pred = pred[0].numpy() - g["pred_%d" % it]
+        print("[oracle] train iteration %d: loss %.6f vs reference %.6f; BV_predict mean|d| %.2e" % (it, float(loss), want, np.abs(e_pred).mean()))
+        assert abs(float(loss) - want) < 2e-5 * want
+        assert np.abs(e_pred).mean() < (1e-4 if it == 0 else 2e-3)
+        for k in t["probes"]:
+            delta = (leaves[k].detach() - before[k]).numpy()
+            ref_d = g["delta_%d_%s" % (it, k)]
+            if np.abs(ref_d).max() == 0:
+                assert np.abs(delta).max() == 0
+                continue
+            rel = np.abs(delta - ref_d).max() / np.abs(ref_d).max()
+            assert rel < (2e-2 if it == 0 else 5e-2), (k, rel)

@@ -14,13 +14,17 @@ for c in B S K; do
   cp $(find $O/prof_$c -name "*kernel_stats.csv" | head -1) $O/bench_${c}_kernel_stats.csv
   rm -rf $O/prof_$c
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_T -- python bench.py --mode train --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $O/prof_T.log 2>&1
+cp $(find $O/prof_T -name "*kernel_stats.csv" | head -1) $O/bench_train_kernel_stats.csv; rm -rf $O/prof_T
+if [ -z "$SKIP_PMC" ]; then   # SKIP_PMC=1: the committed PMC files stay valid while the sampling / Winograd kernel sources are unchanged
 bash tools/pmc_traffic.sh ${1:-r3final}/traffic B S K H > /dev/null 2>&1
 cp $O/traffic/costvol_traffic.json $O/costvol_traffic.json; rm -rf $O/traffic/*/fetch $O/traffic/*/write
 bash tools/pmc_wino.sh ${1:-r3final}/pmc_wino B > /dev/null 2>&1
 cp $O/pmc_wino/summary.txt $O/pmc_wino_summary.txt; rm -rf $O/pmc_wino/pmc?
+fi
 cat $O/pytest.txt $O/smoke.txt | tail -8
 cut -c1-420 $O/bench_B.json
 for c in S K H train H_300frames; do cut -c95-210 $O/bench_$c.json; done
 python -c "
 import json; d=json.load(open('$O/bench_B.json')); print(json.dumps(d.get('parity'))[:900]); print(json.dumps(d.get('roofline'))[:600]); print(json.dumps(d.get('roofline_mfma'))[:500]); print(json.dumps(d.get('cpu_baseline'))[:300])"
-cat $O/costvol_traffic.json | head -30
+[ -z "$SKIP_PMC" ] && cat $O/costvol_traffic.json | head -30
