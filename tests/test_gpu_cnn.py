@@ -135,9 +135,12 @@ def test_rnet_fused_tail_vs_torch_modules(h, w):
         feats_cl = [f.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) for f in feats[:2]] + [feats[2]]
         got2 = net(dpv, feats_cl)       # channels-last feature views, as the matrix-core D-Net hands them over
     err = (got - want).abs().max().item()
-    print("[parity] R-Net fused tail %dx%d max|d log p|=%.3e" % (h, w, err))
-    assert got.shape == want.shape and err < 1e-4
-    assert (got2 - got).abs().max().item() < 1e-4
+    scale = want.abs().max().item()     # He-initialised convs + bilinear transposed convs: the logits of this random net reach ~1e4
+    print("[parity] R-Net fused tail %dx%d max|d log p|=%.3e (|log p| max %.1f)" % (h, w, err, scale))
+    # the module graph under autograd runs the hand-written training kernels (autograd.Conv2dCL), the inference path its own
+    # kernels: two fp32 evaluations of the same graph, compared relative to the size of the logits (3e-6 = a few dozen ulps)
+    assert got.shape == want.shape and err < 1e-4 + 3e-6 * scale
+    assert (got2 - got).abs().max().item() < 1e-4 + 3e-6 * scale
     x = torch.randn(2, 5, 6, 10, device=DEV)
     b = torch.randn(5, device=DEV)
     ref = F.leaky_relu(x + b.view(1, -1, 1, 1), 0.01)
