@@ -30,17 +30,26 @@ struct WgradArgs {
     int D, H, W, Cin;
 };
 
-__global__ __launch_bounds__(1024, 4) void conv3d_wgrad_kernel(const WgradArgs a) {
+// Round 3: 8 waves of 256 registers instead of 16 of 128.  Wave (p, b) owns the ci block b of BOTH co blocks 2p, 2p+1 of every
+// tap (216 accumulator registers): a B operand read from LDS feeds two MFMAs, there is room to keep several LDS reads in flight
+// (the 128-register version spilled and waited for every single ds_read before its MFMA), and the dY elements of step s + 1 are
+// requested — unconditionally, from a clamped address, so that the compiler can count them — before the 54 MFMAs of step s issue.
+constexpr int kWThreads = 512;
+__device__ float g_wgrad_zeros[64];   // what lanes whose voxel lies outside the volume load instead of dY (never written)
+
+__global__ __launch_bounds__(kWThreads) void conv3d_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [kWHalo][kWSV]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nci = a.Cin >> 4;                       // ci blocks (1 or 4)
-    const int cob = wv & 3, cib = wv >> 2;            // this wave's (co, ci) block
+    const int cib = wv & 3, cop = wv >> 2;            // this wave's ci block and pair of co blocks
     const bool wave_on = cib < nci;
     const int i16 = lane & 15, k4 = lane >> 4;        // MFMA row/col (0..15) and k (0..3)
 
-    f32x4w acc[27];
+    f32x4w acc[2][27];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) acc[t] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc[g][t] = f32x4w{0.f, 0.f, 0.f, 0.f};
 
     const int tiles_x = (a.W + kWW - 1) / kWW, tiles_y = (a.H + kWH - 1) / kWH, tiles_z = (a.D + kWD - 1) / kWD;
     const int ntiles = tiles_x * tiles_y * tiles_z;
@@ -52,7 +61,7 @@ __global__ __launch_bounds__(1024, 4) void conv3d_wgrad_kernel(const WgradArgs a
         __syncthreads();  // previous tile's readers are done
         // ---- stage the halo tile of X, all Cin channels, zero outside the volume ----
         const int c4n = a.Cin >> 2;
-        for (int idx = tid; idx < kWHalo * c4n; idx += 1024) {
+        for (int idx = tid; idx < kWHalo * c4n; idx += kWThreads) {
             const int hv = idx / c4n, c4 = idx - hv * c4n;
             const int hz = hv / (kWHH * kWHW), rem = hv - hz * (kWHH * kWHW);
             const int hy = rem / kWHW, hx = rem - hy * kWHW;
@@ -65,33 +74,55 @@ __global__ __launch_bounds__(1024, 4) void conv3d_wgrad_kernel(const WgradArgs a
         __syncthreads();
         if (!wave_on) continue;
         // ---- 32 steps of 4 consecutive voxels (along x) ----
-#pragma unroll 1
-        for (int step = 0; step < (kWD * kWH * kWW) / 4; ++step) {
+        // A[i = co][k = voxel] of a step for the wave's two co blocks: an unconditional load (lanes outside the volume read zeros)
+        auto load_a = [&](int step, float (&av)[2]) {
             const int vz = step / (kWH * kWW / 4), r2 = step - vz * (kWH * kWW / 4);
             const int vy = r2 / (kWW / 4), vx = (r2 - vy * (kWW / 4)) * 4 + k4;   // this lane's voxel (k = lane>>4)
             const int gz = z0 + vz, gy_ = y0 + vy, gx = x0 + vx;
-            float av = 0.f;   // A[i = co][k = voxel]
-            if (gz < a.D && gy_ < a.H && gx < a.W)
-                av = a.gy[(((size_t)gz * a.H + gy_) * a.W + gx) * 64 + cob * 16 + i16];
+            const bool ok = gz < a.D && gy_ < a.H && gx < a.W;
+            const float* p = a.gy + (((size_t)gz * a.H + gy_) * a.W + gx) * 64 + cop * 32 + i16;
+            p = ok ? p : g_wgrad_zeros + i16;          // the select is on the address: nothing depends on the loaded value but the MFMAs
+            av[0] = p[0]; av[1] = p[16];
+        };
+        auto step_mfma = [&](int step, const float (&av)[2]) {
+            const int vz = step / (kWH * kWW / 4), r2 = step - vz * (kWH * kWW / 4);
+            const int vy = r2 / (kWW / 4), vx = (r2 - vy * (kWW / 4)) * 4 + k4;
             const float* bbase = lds + ((vz * kWHH + vy) * kWHW + vx) * kWSV + cib * 16 + i16;  // B[k = voxel][j = ci], tap (0,0,0)
 #pragma unroll
             for (int tap = 0; tap < 27; ++tap) {
                 const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
                 const float bv = bbase[((kd * kWHH + kh) * kWHW + kw) * kWSV];
-                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[tap], 0, 0, 0);
+                acc[0][tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv, acc[0][tap], 0, 0, 0);
+                acc[1][tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv, acc[1][tap], 0, 0, 0);
             }
+        };
+        constexpr int NSTEP = (kWD * kWH * kWW) / 4;
+        float a0[2], a1[2];
+        load_a(0, a0);
+#pragma unroll 1
+        for (int step = 0; step < NSTEP; step += 2) {      // two steps per trip: the operand registers alternate, nothing is moved
+            load_a(step + 1, a1);
+            __builtin_amdgcn_sched_barrier(0);             // the requests leave BEFORE the MFMAs of this step (the scheduler sinks them otherwise)
+            step_mfma(step, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(min(step + 2, NSTEP - 1), a0);
+            __builtin_amdgcn_sched_barrier(0);
+            step_mfma(step + 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (wave_on) {
         // C/D layout of 16x16x4: col = lane & 15 (j = ci), row = (lane >> 4) * 4 + reg (i = co)
         float* out = a.partial + (size_t)blockIdx.x * 27 * 64 * a.Cin;
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = cob * 16 + k4 * 4 + r, ci = cib * 16 + i16;
-                out[((size_t)tap * 64 + co) * a.Cin + ci] = acc[tap][r];
-            }
+            for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = (2 * cop + g) * 16 + k4 * 4 + r, ci = cib * 16 + i16;
+                    out[((size_t)tap * 64 + co) * a.Cin + ci] = acc[g][tap][r];
+                }
     }
 }
 
@@ -140,7 +171,7 @@ extern "C" int nrgbd_conv3d_wgrad_f32(const float* x, const float* gy, float* pa
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(conv3d_wgrad_kernel, dim3(nwg), dim3(1024), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3d_wgrad_kernel, dim3(nwg), dim3(kWThreads), lds, (hipStream_t)stream, a);
     hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(ceil_div(27 * 64 * Cin / 4, 32)), dim3(256), 0, (hipStream_t)stream,
                        partial, dw, nwg, Cin);
     NRGBD_CHECK_LAUNCH();
