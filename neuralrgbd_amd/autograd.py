@@ -142,6 +142,8 @@ def batch_norm_act_cl(x_cl, bn, relu, residual=None):
     m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
     if (use_batch and x_cl.is_cuda and x_cl.dtype == torch.float32 and bn.affine and ops.bn_cl_supported(x_cl.numel() // C, C)
             and os.environ.get("NRGBD_TRAIN_BN", "native") == "native"):
+        if x_cl.numel() // C <= 1:      # nn.BatchNorm's own refusal (torch/nn/functional.py::_verify_batch_size)
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x_cl.shape),))
         return BatchNormActCL.apply(x_cl, bn.weight, bn.bias, residual, bn.eps, relu, m,
                                     bn.running_mean if upd else None, bn.running_var if upd else None)
     y = F.batch_norm(x_cl.reshape(-1, C), bn.running_mean if bn.track_running_stats else None,

@@ -32,7 +32,7 @@ def _torch_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, sigma, dis
 # 64x96 is the training grid (LDS scatter kernel, one depth slice per ~CU share); 96x128 exceeds the LDS plane budget
 # (16*h*w bytes > 144 KB) and takes the global-atomic kernel
 @pytest.mark.parametrize("h,w,D,V,C,dist", [(12, 20, 6, 2, 7, "L2"), (16, 24, 8, 4, 67, "L2"), (10, 14, 4, 3, 5, "L1"),
-                                            (64, 96, 16, 2, 67, "L2"), (96, 128, 4, 1, 6, "L2")])
+                                            (64, 96, 16, 2, 67, "L2"), (96, 128, 4, 1, 6, "L2"), (9, 11, 2, 5, 3, "L1"), (8, 8, 1, 1, 4, "L2")])
 def test_costvol_backward_vs_torch_autograd(h, w, D, V, C, dist):
     from neuralrgbd_amd.autograd import PlaneSweepCost
     from neuralrgbd_amd import ops
@@ -359,7 +359,7 @@ def test_feature_cnn_training_path_native_vs_vendor_convs(monkeypatch):
 
 
 @pytest.mark.parametrize("rows,C,relu,res", [(1000, 64, True, False), (37, 32, False, True), (4099, 128, True, True), (513, 16, True, False),
-                                              (64 * 96 * 4, 64, False, True)])
+                                              (64 * 96 * 4, 64, False, True), (3, 4, True, True), (70, 1024, True, False), (2, 8, False, False)])
 def test_batchnorm_act_channels_last_vs_fp64_autograd(rows, C, relu, res):
     """csrc/bn_train.hip (statistics, normalise + ReLU + residual, and the whole backward) vs torch batch_norm in fp64."""
     from neuralrgbd_amd.autograd import BatchNormActCL
@@ -391,3 +391,37 @@ def test_batchnorm_act_channels_last_vs_fp64_autograd(rows, C, relu, res):
         err = (got.grad.double() - want.grad).abs().max().item()
         print("[parity] bn_cl rows=%d C=%d d%s: %.2e (|grad|max %.2f)" % (rows, C, name, err, scale))
         assert err < 2e-5 * scale, name
+
+
+def test_batch_norm_module_glue_native_vs_vendor(monkeypatch):
+    """autograd.batch_norm_act_cl on nn.BatchNorm3d / nn.BatchNorm2d modules: the HIP path (NRGBD_TRAIN_BN unset) and torch's batch_norm
+    (NRGBD_TRAIN_BN=vendor) give the same output, gradients, running statistics and batch counter; widths bn_train.hip has no form for
+    (C = 48: its 12 channel quads do not tile a 256-lane workgroup) and eval-mode norms take the torch path by themselves."""
+    from neuralrgbd_amd import ops
+    from neuralrgbd_amd.autograd import batch_norm_act_cl
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for C, track in ((64, True), (32, False), (48, True)):
+        res = {}
+        for mode in ("native", "vendor"):
+            monkeypatch.setenv("NRGBD_TRAIN_BN", mode)
+            bn = torch.nn.BatchNorm3d(C, track_running_stats=track).to(DEV)
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+            x = torch.randn(6, 5, 7, C, generator=torch.Generator().manual_seed(C)).to(DEV).requires_grad_(True)
+            r = torch.randn(6, 5, 7, C, generator=torch.Generator().manual_seed(C + 1)).to(DEV).requires_grad_(True)
+            y = batch_norm_act_cl(x, bn, True, r)
+            (y * torch.arange(y.numel(), device=DEV).reshape(y.shape).remainder(7).float()).sum().backward()
+            res[mode] = (y.detach(), x.grad, r.grad, bn.weight.grad, bn.bias.grad,
+                         bn.running_mean.clone() if track else None, int(bn.num_batches_tracked) if track else None)
+        assert ops.bn_cl_supported(6 * 5 * 7, C) == (C != 48)
+        for a, b in zip(res["native"][:5], res["vendor"][:5]):
+            assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
+        if track:
+            assert (res["native"][5] - res["vendor"][5]).abs().max().item() < 1e-6 and res["native"][6] == res["vendor"][6] == 1
+    monkeypatch.delenv("NRGBD_TRAIN_BN")
+    with pytest.raises(ValueError):                                  # torch's own error for a single value per channel in training
+        batch_norm_act_cl(torch.randn(1, 1, 1, 32, device=DEV), torch.nn.BatchNorm3d(32).to(DEV), False)
+    bn = torch.nn.BatchNorm2d(32).to(DEV).eval()                     # running statistics in use: torch's own path
+    x = torch.randn(2, 5, 6, 32, device=DEV, requires_grad=True)
+    y = batch_norm_act_cl(x, bn, False)
+    assert torch.allclose(y, bn(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1), atol=1e-6) and int(bn.num_batches_tracked) == 0
