@@ -84,6 +84,50 @@ def pmc_traffic(cfg):
     return rec.get("traffic_bytes"), "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch on this bench's windows (tools/pmc_traffic.sh -> profiles/%s, kernel sources %s)" % (os.path.basename(TRAFFIC_FILE), doc.get("kernel_source_sha16"))
 
 
+def live_pmc_traffic(cfg, timeout_s=240):
+    """HBM-side bytes per launch of the fused sampling kernel, MEASURED IN THIS RUN: this script is re-run as a child under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domain beside them: MI355X_MICROARCH.md,
+    HBM section) with eager launches on the same windows (3 frames), and the per-dispatch counters of the sampling kernel are
+    averaged; FETCH_SIZE is doubled as the guide prescribes for gfx950.  Returns (bytes | None, note): None when rocprofv3 is
+    not there / fails / times out — the caller then falls back to the committed measurement (pmc_traffic)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    root = tempfile.mkdtemp(prefix="nrgbd_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(root, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--config", cfg, "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline",
+                   "--no-live-traffic"]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            except (OSError, subprocess.SubprocessError) as e:
+                return None, "rocprofv3 --pmc %s failed (%s)" % (counter, type(e).__name__)
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if "costvol_quad" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, "no %s rows for the sampling kernel in the rocprofv3 output" % counter
+            vals[counter] = (sum(got) / len(got), len(got))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    f, w = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+    return int(2 * f[0] * 1024 + w[0] * 1024), ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in two child passes of this "
+                                                "script (eager launches, same windows), mean over %d / %d dispatches of the sampling kernel; "
+                                                "FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB" % (f[1], w[1], f[0], w[0]))
+
+
 def costvol_bytes(V, C, D, h, w):
     """Algorithmic bytes of the fused warp + cost-volume kernel."""
     return 4 * ((V + 1) * C * h * w + D * h * w)
@@ -339,6 +383,8 @@ def main():
     ap.add_argument("--config", default="B", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC file instead of two rocprofv3 "
+                    "--pmc child passes of this script (about a minute; N = 1 only)")
     ap.add_argument("--streams", type=int, default=1, help="independent video streams per GPU, each on its own HIP stream "
                     "(a step is then one frame of EVERY stream; the extra streams fill the tails of each other's kernels)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU self-test of the N>1 harness
@@ -411,6 +457,12 @@ def main():
         k_ms = timer.measure(n_k)
         algo = costvol_bytes(V, 67, D, h, w)
         achieved = algo / (k_ms * 1e-3) / 1e9
+        traffic, traffic_note = (None, "")
+        if world == 1 and not args.no_live_traffic and not args.no_graph and S == 1:
+            traffic, traffic_note = live_pmc_traffic(args.config)      # measured now, by two rocprofv3 --pmc child passes
+        if traffic is None:
+            t2, n2 = pmc_traffic(args.config)                          # the committed measurement (refused if the kernel changed)
+            traffic, traffic_note = t2, (n2 if not traffic_note else "%s; live measurement unavailable: %s" % (n2, traffic_note))
         line = {
             "metric": "depth frames/sec @256x192x64cand, 5-view window; warp-kernel HBM GB/s vs peak",
             "value": args.steps * S * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -424,7 +476,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes": algo, "kernel_ms": k_ms, "launches_timed": n_k,
                          "timing": "HIP events around back-to-back launches of the frame's own costvol call (log-softmax launch included), right after the timed region",
-                         "traffic": pmc_traffic(args.config)[0], "traffic_source": pmc_traffic(args.config)[1]},
+                         "traffic": traffic, "traffic_source": traffic_note},
         }
         if knet_timer.last is not None:   # secondary roofline: the matrix-core kernel that takes most of the frame
             c_ms = knet_timer.measure(5)

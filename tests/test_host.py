@@ -3,6 +3,7 @@ host mirror keeps the reference's contracts, and the product path refuses to run
 import ctypes
 import json
 import os
+import sys
 import re
 
 import numpy as np
@@ -213,3 +214,35 @@ def test_bench_refuses_a_traffic_measurement_taken_on_other_kernel_sources(tmp_p
     assert val is None and "refused" in why
     monkeypatch.setattr(bench, "TRAFFIC_FILE", str(tmp_path / "missing.json"))
     assert bench.pmc_traffic("B")[0] is None
+
+
+def test_live_traffic_measurement_parses_the_counter_files_and_fails_soft(tmp_path, monkeypatch):
+    """bench.live_pmc_traffic: two rocprofv3 --pmc child passes -> FETCH_SIZE x2 + WRITE_SIZE per dispatch of the sampling kernel;
+    a missing profiler, a failing child or an output without the kernel give (None, reason) and the caller falls back to the file."""
+    import subprocess
+    import bench
+    calls = []
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        assert "--pmc" in cmd and "--no-live-traffic" in cmd and "--no-graph" in cmd      # the child cannot recurse
+        counter, out = cmd[cmd.index("--pmc") + 1], cmd[cmd.index("-d") + 1]
+        os.makedirs(os.path.join(out, "host", "1"), exist_ok=True)
+        with open(os.path.join(out, "host", "1", "p_counter_collection.csv"), "w") as f:
+            f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            for v in (100.0, 300.0):
+                f.write('"void nrgbd::costvol_quad<0, 3, false, 188, 3, false>(nrgbd::CostvolArgs)",%s,%f\n' % (counter, v))
+            f.write('"other_kernel",%s,999999\n' % counter)
+        return subprocess.CompletedProcess(cmd, 0)
+
+    import shutil
+    monkeypatch.setattr(shutil, "which", lambda name: sys.executable)       # any existing file stands in for the profiler
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    val, note = bench.live_pmc_traffic("B")
+    assert val == int(2 * 200 * 1024 + 200 * 1024) and "measured in this run" in note and len(calls) == 2
+
+    def failing(cmd, **kw):
+        raise subprocess.CalledProcessError(1, cmd)
+    monkeypatch.setattr(subprocess, "run", failing)
+    val, note = bench.live_pmc_traffic("B")
+    assert val is None and "failed" in note
