@@ -98,6 +98,8 @@ def live_pmc_traffic(cfg, timeout_s=240):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if "HSA_TOOLS_LIB" in os.environ or any(k.startswith(("ROCP_", "ROCPROFILER_")) for k in os.environ):
+        return None, "this process is itself running under a profiler"     # no nested rocprofv3
     vals = {}
     root = tempfile.mkdtemp(prefix="nrgbd_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
