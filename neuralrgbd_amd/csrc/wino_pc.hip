@@ -93,13 +93,15 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
 
         PcTile tl = pc_decode<KD, DIL>(first, a);
         const f32x4* wt = wbase + (size_t)tl.cg * wgroup;
-        f32x4 Bn[kPcNB], An[2][2];
+        f32x4 Bn[kPcNB], An[4][2];             // A operands run TWO transform points ahead (one point = 256 MFMA cycles < a loaded LDS's latency)
 #pragma unroll
         for (int b = 0; b < kPcBD; ++b) Bn[b] = wt[b * 256];
         __syncthreads();                       // producers finish stage 0
         __syncthreads();                       // ... and stage 1
         An[0][0] = *reinterpret_cast<const f32x4*>(Vb + a0);
         An[0][1] = *reinterpret_cast<const f32x4*>(Vb + a1);
+        An[1][0] = *reinterpret_cast<const f32x4*>(Vb + a0 + kPcTiles * kCB);
+        An[1][1] = *reinterpret_cast<const f32x4*>(Vb + a1 + kPcTiles * kCB);
         int buf = 0;
 #ifdef NRGBD_DEV
         long t_mfma = 0, t_bar = 0, t_epi = 0;
@@ -124,13 +126,13 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int xi = 0; xi < 16; ++xi) {
-                        const int cur = xi & 1, nxt = cur ^ 1;
-                        if (xi + 1 < 16) {
-                            An[nxt][0] = *reinterpret_cast<const f32x4*>(Vc + a0 + (xi + 1) * (kPcTiles * kCB));
-                            An[nxt][1] = *reinterpret_cast<const f32x4*>(Vc + a1 + (xi + 1) * (kPcTiles * kCB));
-                        } else {   // first operand of the next stage: its buffer was completed two barriers ago
-                            An[nxt][0] = *reinterpret_cast<const f32x4*>(Vn + a0);
-                            An[nxt][1] = *reinterpret_cast<const f32x4*>(Vn + a1);
+                        const int cur = xi & 3, nxt = (xi + 2) & 3;
+                        if (xi + 2 < 16) {
+                            An[nxt][0] = *reinterpret_cast<const f32x4*>(Vc + a0 + (xi + 2) * (kPcTiles * kCB));
+                            An[nxt][1] = *reinterpret_cast<const f32x4*>(Vc + a1 + (xi + 2) * (kPcTiles * kCB));
+                        } else {   // the first two operands of the next stage: its buffer was completed two barriers ago
+                            An[nxt][0] = *reinterpret_cast<const f32x4*>(Vn + a0 + (xi + 2 - 16) * (kPcTiles * kCB));
+                            An[nxt][1] = *reinterpret_cast<const f32x4*>(Vn + a1 + (xi + 2 - 16) * (kPcTiles * kCB));
                         }
                         Bn[(xi + kPcBD) % kPcNB] = xi + kPcBD < 16 ? wcur[(xi + kPcBD) * 256] : wnx[(xi + kPcBD - 16) * 256];
 #pragma unroll
