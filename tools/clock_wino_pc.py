@@ -4,7 +4,7 @@ tile, median over workgroups: consumer MFMA time, consumer barrier wait, epilogu
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["NRGBD_WINO_ABL"] = "64"
+os.environ["NRGBD_WINO_ABL"] = str(64 | int(os.environ.get("EXTRA_ABL", "0")))
 from neuralrgbd_amd import _lib
 _lib.LIB_PATH = _lib.LIB_PATH.replace("libnrgbd_hip.so", "libnrgbd_hip_dev.so")
 from neuralrgbd_amd import ops
