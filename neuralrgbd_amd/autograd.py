@@ -81,9 +81,14 @@ class Conv3dCL(torch.autograd.Function):
         if transposed:
             cin = w.shape[1]
             wt = w.transpose(0, 1).flip(2, 3, 4)                      # [Cin, 64, 3,3,3]: correlation with the flipped kernel
-            if cin < 64:                                              # the kernel produces 64 outputs: pad, then slice
+            if cin < 64:                                              # the kernels produce 64 outputs: pad, then slice
                 wt = torch.cat((wt, wt.new_zeros(64 - cin, 64, 3, 3, 3)), dim=0)
-            gx = ops.conv3d(x, ops.conv3d_pack_weights(wt.contiguous()), want_stats=False)[0]
+            if ops.conv_wino_dw_supported(x.shape[0], x.shape[1], x.shape[2], 64, 64):
+                # data gradient of the first layer (16 -> 64): a 64 -> 64(16 real) layer in the Winograd domain, 0.31 instead of
+                # 0.64 ms on the direct kernel at the training grid
+                gx = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(wt.contiguous()), 64, want_stats=False)[0]
+            else:
+                gx = ops.conv3d(x, ops.conv3d_pack_weights(wt.contiguous()), want_stats=False)[0]
             return gx[..., :cin].contiguous() if cin < 64 else gx
         return ops.conv3d(x, ops.conv3d_pack_weights(w.contiguous()), want_stats=False)[0]
 
