@@ -386,7 +386,9 @@ int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, const float
                                 int N, int H, int W, int Cin, int Cout, int ldy, int ycoff, int cout_valid, void* stream);
 /* w [Cout][Cin][kd][3][3] (torch layout) -> w_wino [Cout*Cin*kd*16] floats in the order described above (on the device).
  * transposed = 1: the DATA-GRADIENT weights of w [Cin][Cout][kd][3][3] (roles of the channel axes swapped, every tap flipped),
- * i.e. what the same kernel needs to turn dL/dy into dL/dx — without materialising w.transpose(0,1).flip(...) first. */
+ * i.e. what the same kernel needs to turn dL/dy into dL/dx — without materialising w.transpose(0,1).flip(...) first.
+ * transposed = 2: BOTH streams of the layer w [Cout][Cin][kd][3][3] in one launch (training re-packs them every iteration):
+ * the forward stream at w_wino, the data-gradient stream right behind it (w_wino holds 2 * Cout*Cin*kd*16 floats; Cin % 64 too). */
 int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int Cout, int kd, int transposed, void* stream);
 int nrgbd_bn_finalize_cm(const float* stats, int rows, int C, long count, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream);

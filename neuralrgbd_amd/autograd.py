@@ -71,13 +71,13 @@ class Conv3dCL(torch.autograd.Function):
     """
 
     @staticmethod
-    def _conv(x, w, transposed=False):
-        """y = conv(x, w) (transposed: with w's data-gradient weights): the Winograd-domain kernel (wino_pc.hip) for the 64 -> 64
-        layers, the direct kernel otherwise."""
+    def _conv(x, w, transposed=False, packed=None):
+        """y = conv(x, w) (transposed: with w's data-gradient weights): the Winograd-domain kernels (wino_dw.hip / wino_pc.hip) for
+        the 64 -> 64 layers, the direct kernel otherwise.  packed: the weight stream of this call if the caller already has it."""
         if w.shape[0] == 64 and w.shape[1] == 64:
             if ops.conv_wino_dw_supported(x.shape[0], x.shape[1], x.shape[2], 64, 64):   # Winograd along depth too (wino_dw.hip)
-                return ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w, transposed), 64, want_stats=False)[0]
-            return ops.conv_wino(x, ops.conv_wino_pack(w, transposed), 64, 3, want_stats=False)[0]
+                return ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w, transposed) if packed is None else packed, 64, want_stats=False)[0]
+            return ops.conv_wino(x, ops.conv_wino_pack(w, transposed) if packed is None else packed, 64, 3, want_stats=False)[0]
         if transposed:
             cin = w.shape[1]
             wt = w.transpose(0, 1).flip(2, 3, 4)                      # [Cin, 64, 3,3,3]: correlation with the flipped kernel
@@ -94,19 +94,24 @@ class Conv3dCL(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w):
-        y = Conv3dCL._conv(x.contiguous(), w)
-        ctx.save_for_backward(x, w)
+        x = x.contiguous()
+        fwd = bwd = None
+        if w.shape[0] == 64 and w.shape[1] == 64 and ctx.needs_input_grad[0]:
+            # both weight streams (forward + data gradient) in one launch: the weights changed since the last iteration anyway
+            fwd, bwd = ops.conv_wino_pack_both(w, dw=ops.conv_wino_dw_supported(x.shape[0], x.shape[1], x.shape[2], 64, 64))
+        y = Conv3dCL._conv(x, w, packed=fwd)
+        ctx.save_for_backward(x, w, bwd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, bwd = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[1]:
             gw = ops.conv3d_wgrad(x.contiguous(), gy)
         if ctx.needs_input_grad[0]:
-            gx = Conv3dCL._conv(gy, w, transposed=True)
+            gx = Conv3dCL._conv(gy, w, transposed=True, packed=bwd)
         return gx, gw
 
 
@@ -179,10 +184,10 @@ class Conv2dCL(torch.autograd.Function):
         return fwd(cin, cout) and fwd(cout, cin) and cin % 16 == 0 and cout % 16 == 0
 
     @staticmethod
-    def _conv(x_cl, w, dil, transposed=False):
+    def _conv(x_cl, w, dil, transposed=False, packed=None):
         cout, cin = (w.shape[1], w.shape[0]) if transposed else w.shape[:2]
         if cin % 32 == 0 and cout % 64 == 0:
-            return ops.conv_wino(x_cl, ops.conv_wino_pack(w, transposed), cout, 1, dil, want_stats=False)[0]
+            return ops.conv_wino(x_cl, ops.conv_wino_pack(w, transposed) if packed is None else packed, cout, 1, dil, want_stats=False)[0]
         if transposed:
             w = w.transpose(0, 1).flip(2, 3)                          # [Cin, Cout, 3, 3]: correlation with the flipped kernel
         return ops.conv2d(x_cl, ops.conv_pack_weights(w.contiguous()), cout, dil, want_stats=False)[0]
@@ -190,20 +195,24 @@ class Conv2dCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, dil):
         x_cl = x.permute(0, 2, 3, 1).contiguous()                 # free when x is channels_last
-        y = Conv2dCL._conv(x_cl, w, dil)
-        ctx.save_for_backward(x_cl, w)
+        cout, cin = w.shape[:2]
+        fwd = bwd = None
+        if cin % 64 == 0 and cout % 64 == 0 and ctx.needs_input_grad[0]:
+            fwd, bwd = ops.conv_wino_pack_both(w)                 # both directions run on wino_pc.hip: one packing launch for the two streams
+        y = Conv2dCL._conv(x_cl, w, dil, packed=fwd)
+        ctx.save_for_backward(x_cl, w, bwd)
         ctx.dil = dil
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
-        x_cl, w = ctx.saved_tensors
+        x_cl, w, bwd = ctx.saved_tensors
         gy_cl = gy.permute(0, 2, 3, 1).contiguous()
         gx = gw = None
         if ctx.needs_input_grad[1]:
             gw = ops.conv2d_wgrad(x_cl, gy_cl, ctx.dil)
         if ctx.needs_input_grad[0]:
-            gx = Conv2dCL._conv(gy_cl, w, ctx.dil, transposed=True).permute(0, 3, 1, 2)
+            gx = Conv2dCL._conv(gy_cl, w, ctx.dil, transposed=True, packed=bwd).permute(0, 3, 1, 2)
         return gx, gw, None
 
 

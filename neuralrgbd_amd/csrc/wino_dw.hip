@@ -572,6 +572,10 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
 __global__ __launch_bounds__(256) void conv_wino_dw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
                                                                 int transposed) {
     const long total = (long)Cout * Cin * 4 * 16;
+    if (transposed == 2) {     // both streams in one launch (grid.y = 2): forward at wp, data gradient behind it (see conv_wino_pack_kernel)
+        transposed = blockIdx.y;
+        if (transposed) { const int c = Cin; Cin = Cout; Cout = c; wp += total; }
+    }
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     long t = idx;
@@ -608,9 +612,11 @@ extern "C" int nrgbd_conv_wino_dw_pack(const float* w, float* w_wino, int Cin, i
     using namespace nrgbd;
     if (!w || !w_wino) return NRGBD_E_NULL;
     if (Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
+    if (transposed < 0 || transposed > 2) return NRGBD_E_ARG;
+    if (transposed == 2 && Cin % 64) return NRGBD_E_SHAPE;
     const long total = (long)Cout * Cin * 4 * 16;
-    hipLaunchKernelGGL(conv_wino_dw_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_wino,
-                       Cin, Cout, transposed);
+    hipLaunchKernelGGL(conv_wino_dw_pack_kernel, dim3((unsigned)((total + 255) / 256), transposed == 2 ? 2 : 1), dim3(256), 0, (hipStream_t)stream,
+                       w, w_wino, Cin, Cout, transposed);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

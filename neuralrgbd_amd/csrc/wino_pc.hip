@@ -577,9 +577,15 @@ __global__ __launch_bounds__(1024) void bn_finalize_cm_kernel(const float* __res
 
 // w [Cout][Cin][KD][3][3] -> U = G g G^T (float64, rounded once) in the kernel's B-operand order
 // [cg][stage = cb*KD + kd][xi][wave][lane = kq*16 + j][e], co = cg*64 + 16*wave + j, ci = cb*16 + 4*kq + e
+// transposed == 2 (grid.y = 2): BOTH streams of a layer [Cout][Cin] in one launch — y = 0 the forward one at wp, y = 1 the data-gradient
+// one (roles of Cin / Cout swapped, taps flipped) right behind it (training packs both every iteration: the weights just changed)
 __global__ __launch_bounds__(256) void conv_wino_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int KD,
                                                              int transposed) {
     const long total = (long)Cout * Cin * KD * 16;
+    if (transposed == 2) {
+        transposed = blockIdx.y;
+        if (transposed) { const int c = Cin; Cin = Cout; Cout = c; wp += total; }
+    }
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     long t = idx;
@@ -611,9 +617,11 @@ extern "C" int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int 
     using namespace nrgbd;
     if (!w || !w_wino) return NRGBD_E_NULL;
     if (Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64 || (kd != 1 && kd != 3)) return NRGBD_E_SHAPE;
+    if (transposed < 0 || transposed > 2) return NRGBD_E_ARG;
+    if (transposed == 2 && Cin % 64) return NRGBD_E_SHAPE;           // both streams: each channel count is a Cout once
     const long total = (long)Cout * Cin * kd * 16;
-    hipLaunchKernelGGL(conv_wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_wino,
-                       Cin, Cout, kd, transposed);
+    hipLaunchKernelGGL(conv_wino_pack_kernel, dim3((unsigned)((total + 255) / 256), transposed == 2 ? 2 : 1), dim3(256), 0, (hipStream_t)stream,
+                       w, w_wino, Cin, Cout, kd, transposed);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

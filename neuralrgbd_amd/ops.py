@@ -378,15 +378,24 @@ def conv_wino_pack(w, transposed=False):
         w = w[:, :, None]
     if w.dim() != 5 or tuple(w.shape[3:]) != (3, 3) or w.shape[2] not in (1, 3):
         raise ValueError("conv_wino_pack expects [Cout, Cin, (3,) 3, 3], got %s" % (tuple(w.shape),))
-    Cout, Cin, KD = (w.shape[1], w.shape[0], w.shape[2]) if transposed else w.shape[:3]
-    if Cout % 64 or Cin % 16:
+    Cout, Cin, KD = (w.shape[1], w.shape[0], w.shape[2]) if transposed is True or transposed == 1 else w.shape[:3]
+    if Cout % 64 or Cin % 16 or (transposed == 2 and Cin % 64):
         raise ValueError("conv_wino_pack: Cout %% 64 and Cin %% 16 required, got Cout=%d Cin=%d" % (Cout, Cin))
-    wp = torch.empty(Cout * Cin * KD * 16, dtype=torch.float32, device=w.device)
+    # transposed = 2: both streams in one launch -> a buffer of twice the size, forward half first (training: ops.conv_wino_pack_both)
+    wp = torch.empty(Cout * Cin * KD * 16 * (2 if transposed == 2 else 1), dtype=torch.float32, device=w.device)
     wc = w.detach().contiguous()
     with torch.cuda.device(w.device):
         rc = _lib.load().nrgbd_conv_wino_pack(_p(wc), _p(wp), Cin, Cout, KD, int(transposed), _stream(w))
     _lib.check(rc, "nrgbd_conv_wino_pack")
     return wp
+
+
+def conv_wino_pack_both(w, dw=False):
+    """(forward stream, data-gradient stream) of a layer's weight in ONE launch (training re-packs both every iteration).
+    dw: the streams of wino_dw.hip (Winograd along depth too) instead of wino_pc.hip's."""
+    both = (conv_wino_dw_pack if dw else conv_wino_pack)(w, transposed=2)
+    n = both.numel() // 2
+    return both[:n], both[n:]
 
 
 def conv_wino_pack_reference(w):
@@ -440,10 +449,10 @@ def conv_wino_dw_pack(w, transposed=False):
     w = _need(w, "w")
     if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
         raise ValueError("conv_wino_dw_pack expects [Cout, Cin, 3, 3, 3], got %s" % (tuple(w.shape),))
-    Cout, Cin = (w.shape[1], w.shape[0]) if transposed else w.shape[:2]
-    if Cout % 64 or Cin % 16:
+    Cout, Cin = (w.shape[1], w.shape[0]) if transposed is True or transposed == 1 else w.shape[:2]
+    if Cout % 64 or Cin % 16 or (transposed == 2 and Cin % 64):
         raise ValueError("conv_wino_dw_pack: Cout %% 64 and Cin %% 16 required, got Cout=%d Cin=%d" % (Cout, Cin))
-    wp = torch.empty(Cout * Cin * 4 * 16, dtype=torch.float32, device=w.device)
+    wp = torch.empty(Cout * Cin * 4 * 16 * (2 if transposed == 2 else 1), dtype=torch.float32, device=w.device)
     wc = w.detach().contiguous()
     with torch.cuda.device(w.device):
         rc = _lib.load().nrgbd_conv_wino_dw_pack(_p(wc), _p(wp), Cin, Cout, int(transposed), _stream(w))

@@ -388,3 +388,18 @@ def test_conv_wino_dw_fused_batchnorm_finalisation():
         sc = gamma.double() / torch.sqrt(var + 1e-5)
         want = torch.stack((sc, beta.double() - mean * sc), 1)
         assert (ss1.double() - want).abs().max().item() < 1e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (128, 64, 3, 3), (128, 320 - 64, 3, 3), (64, 64, 3, 3, 3)])
+def test_both_weight_streams_in_one_launch(shape):
+    """transposed = 2 of the packing kernels (training): forward and data-gradient streams of a layer written by ONE launch are the
+    streams the two single launches write (wino_pc.hip, and wino_dw.hip for 3-D weights)."""
+    from neuralrgbd_amd import ops
+    w = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape))).to(DEV)
+    f, b = ops.conv_wino_pack_both(w)
+    assert torch.equal(f, ops.conv_wino_pack(w)) and torch.equal(b, ops.conv_wino_pack(w, True))
+    if w.dim() == 5:
+        f, b = ops.conv_wino_pack_both(w, dw=True)
+        assert torch.equal(f, ops.conv_wino_dw_pack(w)) and torch.equal(b, ops.conv_wino_dw_pack(w, True))
+    with pytest.raises(ValueError):
+        ops.conv_wino_pack(torch.zeros(64, 32, 3, 3, device=DEV), transposed=2)      # 32 inputs cannot be a 64-column output group
