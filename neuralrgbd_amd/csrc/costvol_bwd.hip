@@ -24,7 +24,7 @@ struct CostvolBwdArgs {
     float* g_ref; float* g_src;
     float cx, cy, sigma;
     int dist, align, V, C, Cp, D, h, w, kchunks;
-    int abl;   // developer builds: 1 = no atomics (results invalid), 2 = no tap loads
+    int abl;   // developer builds only (NRGBD_BWD_ABL): 1 = no atomics, 2 = no tap loads, 4 = conflict-free LDS addresses (results invalid)
 };
 
 // grid (ceil(hw/64), kchunks, Cp/4), block 64: one lane = one pixel x one slice of consecutive depth candidates x
@@ -33,6 +33,11 @@ struct CostvolBwdArgs {
 // are accumulated in registers while the cell stays the same and flushed with atomics only when it changes
 // (4-8x fewer atomics than one per (pixel, candidate, view, channel); the kernel is atomic-bound).
 __global__ __launch_bounds__(64) void costvol_bwd_kernel(const CostvolBwdArgs a) {
+#ifdef NRGBD_DEV
+    const int abl = a.abl;
+#else
+    constexpr int abl = 0;
+#endif
     const size_t hw = (size_t)a.h * a.w;
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (p >= hw) return;
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(64) void costvol_bwd_kernel(const CostvolBwdArgs a)
             for (int tpi = 0; tpi < 4; ++tpi)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (acc[tpi][e] != 0.f && !(a.abl & 1)) atomicAdd(gs + o[tpi] + e, acc[tpi][e]);
+                    if (acc[tpi][e] != 0.f && !(abl & 1)) atomicAdd(gs + o[tpi] + e, acc[tpi][e]);
         };
         for (int k = k_begin; k < k_end; ++k) {
             const float gk = a.g_cost[(size_t)k * hw + p] / a.sigma;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(64) void costvol_bwd_kernel(const CostvolBwdArgs a)
             }
             if (gk == 0.f) continue;
             float4 A = r, B = r, Cc = r, Dd = r;
-            if (!(a.abl & 2)) {
+            if (!(abl & 2)) {
                 A = *reinterpret_cast<const float4*>(sv + o[0]); B = *reinterpret_cast<const float4*>(sv + o[1]);
                 Cc = *reinterpret_cast<const float4*>(sv + o[2]); Dd = *reinterpret_cast<const float4*>(sv + o[3]);
             }
@@ -117,6 +122,11 @@ constexpr size_t kBwdLdsMax = 144 * 1024;   // of the 160 KB of a CU
 //   part_ref [kchunks][V][Cp/4][h*w][4]   partial g_ref of this slice and view
 __global__ __launch_bounds__(kBwdThreads) void costvol_bwd_lds_kernel(const CostvolBwdArgs a, float* __restrict__ part_src,
                                                                       float* __restrict__ part_ref) {
+#ifdef NRGBD_DEV
+    const int abl = a.abl;
+#else
+    constexpr int abl = 0;
+#endif
     extern __shared__ float gl[];
     const int hw = a.h * a.w, words = a.Cp >> 2;
     const int kc = blockIdx.x, i = blockIdx.y, v = blockIdx.z, tid = threadIdx.x;
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(kBwdThreads) void costvol_bwd_lds_kernel(const Cost
             for (int tpi = 0; tpi < 4; ++tpi)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (acc[tpi][e] != 0.f && !(a.abl & 1)) atomicAdd(gl + e * hw + ((a.abl & 4) ? min(p + tpi, hw - 1) : o[tpi]), acc[tpi][e]);
+                    if (acc[tpi][e] != 0.f && !(abl & 1)) atomicAdd(gl + e * hw + ((abl & 4) ? min(p + tpi, hw - 1) : o[tpi]), acc[tpi][e]);
         };
         for (int k = k_begin; k < k_end; ++k) {
             const float gk = a.g_cost[(size_t)k * hw + p] / inv_sigma_den;
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(kBwdThreads) void costvol_bwd_lds_kernel(const Cost
             }
             if (gk == 0.f) continue;
             float4 A = r, B = r, Cc = r, Dd = r;
-            if (!(a.abl & 2)) {
+            if (!(abl & 2)) {
                 A = *reinterpret_cast<const float4*>(sv + (size_t)o[0] * a.Cp);
                 B = *reinterpret_cast<const float4*>(sv + (size_t)o[1] * a.Cp);
                 Cc = *reinterpret_cast<const float4*>(sv + (size_t)o[2] * a.Cp);
