@@ -486,6 +486,57 @@ __global__ __launch_bounds__(256) void space_to_depth2_kernel(const float* __res
     y[idx] = v;
 }
 
+// The two forms the path uses, 16 bytes per access (round 3; the element-wise kernel above stays for any other shape):
+//   channels-last input with C % 4 == 0 (the 32-channel half-resolution map of layer2's first block): one lane = one 16-byte word
+//   of the output pixel, read from one phase pixel of the input
+__global__ __launch_bounds__(256) void space_to_depth2_cl4_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H,
+                                                                  int W, int Cp) {
+    const int Ho = H >> 1, Wo = W >> 1, q4 = Cp >> 2;
+    const long total = (long)N * Ho * Wo * q4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cp = (int)(idx % q4) * 4;
+    long t = idx / q4;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cp < 4 * C) {
+        const int ph = cp / C, c = cp - ph * C;
+        v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + 2 * yo + (ph >> 1)) * W + 2 * xo + (ph & 1)) * C + c);
+    }
+    *reinterpret_cast<float4*>(y + idx * 4) = v;
+}
+
+//   planar RGB image (C = 3, Cp = 16: the stem's first convolution): one lane = one output pixel = six 8-byte loads (a plane row's
+//   two phase columns are adjacent) and four 16-byte stores
+__global__ __launch_bounds__(256) void space_to_depth2_rgb_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int xo = (int)(idx % Wo);
+    long t = idx / Wo;
+    const int yo = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float2 v[3][2];   // [c][py] = (px 0, px 1)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+            v[c][py] = *reinterpret_cast<const float2*>(x + (((size_t)n * 3 + c) * H + 2 * yo + py) * W + 2 * xo);
+    // output channel (py*2 + px)*3 + c
+    float o[16];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[(py * 2 + 0) * 3 + c] = v[c][py].x; o[(py * 2 + 1) * 3 + c] = v[c][py].y; }
+    o[12] = o[13] = o[14] = o[15] = 0.f;
+    float4* dst = reinterpret_cast<float4*>(y + idx * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+}
+
 }  // namespace nrgbd
 
 extern "C" int nrgbd_space_to_depth2(const float* x, int nchw, float* y, int N, int C, int H, int W, int Cp, void* stream) {
@@ -493,8 +544,16 @@ extern "C" int nrgbd_space_to_depth2(const float* x, int nchw, float* y, int N, 
     if (!x || !y) return NRGBD_E_NULL;
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cp < 4 * C) return NRGBD_E_SHAPE;
     const long total = (long)N * (H / 2) * (W / 2) * Cp;
-    hipLaunchKernelGGL(space_to_depth2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, nchw,
-                       y, N, C, H, W, Cp);
+    const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    if (!nchw && (C & 3) == 0 && (Cp & 3) == 0 && aligned)
+        hipLaunchKernelGGL(space_to_depth2_cl4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, C,
+                           H, W, Cp);
+    else if (nchw && C == 3 && Cp == 16 && aligned)        // W even: a plane row's phase pair is 8-byte aligned
+        hipLaunchKernelGGL(space_to_depth2_rgb_kernel, dim3((unsigned)((total / 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, N,
+                           H, W);
+    else
+        hipLaunchKernelGGL(space_to_depth2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, nchw,
+                           y, N, C, H, W, Cp);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -229,6 +229,23 @@ def test_conv_stride2_via_space_to_depth_vs_torch(N, H, W, C, Cout, nchw):
     assert torch.allclose(s[Cout:], (want ** 2).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("N,C,H,W,nchw,cp", [(2, 3, 32, 48, True, None), (5, 3, 18, 34, True, None), (2, 32, 20, 28, False, None),
+                                             (1, 8, 6, 10, False, 48), (2, 6, 8, 12, False, None), (2, 5, 8, 12, True, None), (1, 3, 8, 12, True, 32)])
+def test_space_to_depth2_every_form(N, C, H, W, nchw, cp):
+    """nrgbd_space_to_depth2: the 16-byte forms (planar RGB -> 16 channels, channels-last with C % 4 == 0) and the element-wise kernel
+    every other shape takes all give y[n,yo,xo,(py*2+px)*C + c] = x[n,c,2yo+py,2xo+px], zero in the padding channels (pure data movement:
+    compared with torch.equal)."""
+    from neuralrgbd_amd import ops
+    x = torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(C * H)).to(DEV)
+    got = ops.space_to_depth2(x if nchw else _cl(x), nchw=nchw, cp=cp)
+    Cp = got.shape[-1]
+    want = torch.zeros(N, H // 2, W // 2, Cp, device=DEV)
+    for py in range(2):
+        for px in range(2):
+            want[..., (py * 2 + px) * C:(py * 2 + px + 1) * C] = x[:, :, py::2, px::2].permute(0, 2, 3, 1)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(5, 24, 32, 128, 32), (2, 3, 4, 128, 32), (2, 33, 47, 64, 128), (1, 40, 56, 32, 64), (1, 20, 20, 128, 64)])
 def test_conv_1x1_vs_torch(N, H, W, Cin, Cout):
     """1x1 convolutions of the trunk (shortcuts, SPP branches, head) on the matrix-core kernel, with the loader prologue."""
