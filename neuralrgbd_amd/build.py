@@ -53,7 +53,8 @@ def build_dev(verbose=False):
     """Developer variant libnrgbd_hip_dev.so (-DNRGBD_DEV: ablation bits and tile-order switches honoured, read from the
     environment).  Used only by tools/ for kernel analysis; never loaded by the package."""
     lib = os.path.join(CSRC, "libnrgbd_hip_dev.so")
-    cmd = [HIPCC] + FLAGS + ["-DNRGBD_DEV", "-I", INCLUDE] + sources() + ["-o", lib]
+    extra = os.environ.get("NRGBD_DEV_DEFINES", "").split()      # e.g. NRGBD_DEV_DEFINES="-DNRGBD_DW_NT=1" for a one-off experiment
+    cmd = [HIPCC] + FLAGS + ["-DNRGBD_DEV"] + extra + ["-I", INCLUDE] + sources() + ["-o", lib]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
