@@ -11,6 +11,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int RB, int ABL>   // ABL bits: 1 = no stage barrier, 2 = no weight loads (ring filled once), 4 = no LDS reads, 8 = no sched_barrier pin,
+                             // 64 = the weight line from LDS (ds_read_b128) instead of global memory,
                              // 16 = the weight line as four 4-byte loads (lane-contiguous layout), one per MFMA gap; 32 = as two 8-byte loads
 __global__ __launch_bounds__(RB == 2 ? 256 : 512) void probe(const f32x4* __restrict__ w, float* __restrict__ out, int stages, long long* clk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -42,7 +43,8 @@ __global__ __launch_bounds__(RB == 2 ? 256 : 512) void probe(const f32x4* __rest
 #pragma unroll
             for (int r = 0; r < RB; ++r) if (!(ABL & 4)) An[nxt][r] = *reinterpret_cast<const f32x4*>(a0 + ((xi + 2) & 15) * 512 + r * 256);
             const size_t wpt = (size_t)(((s * 16 + xi + 7) & 63)) * 4096;
-            if (!(ABL & (2 | 16 | 32))) Bn[(xi + 7) & 7] = wl[wpt];
+            if (!(ABL & (2 | 16 | 32 | 64))) Bn[(xi + 7) & 7] = wl[wpt];
+            if (ABL & 64) Bn[(xi + 7) & 7] = *reinterpret_cast<const f32x4*>(lds + 16384 + ((xi + 7) & 7) * 1024 + (wave & 3) * 256 + lane * 4);   // weight line from an LDS ring
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -98,6 +100,8 @@ int main() {
     run(&probe<2, 8>, 256, "1 wave/SIMD, scheduler free (no sched_barrier)");
     run(&probe<2, 7>, 256, "1 wave/SIMD, MFMAs only");
     run(&probe<2, 15>, 256, "1 wave/SIMD, MFMAs only, scheduler free");
+    run(&probe<2, 64>, 256, "1 wave/SIMD, weight line read from LDS");
+    run(&probe<1, 64>, 512, "2 waves/SIMD, weight line read from LDS");
     run(&probe<2, 16>, 256, "1 wave/SIMD, weight line = 4 x 4-byte loads in the gaps");
     run(&probe<2, 32>, 256, "1 wave/SIMD, weight line = 2 x 8-byte loads in the gaps");
     run(&probe<1, 0>, 512, "2 waves/SIMD, half the tiles each");
