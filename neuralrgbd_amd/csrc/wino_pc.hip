@@ -134,7 +134,6 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                             An[nxt][0] = *reinterpret_cast<const f32x4*>(Vn + a0 + (xi + 2 - 16) * (kPcTiles * kCB));
                             An[nxt][1] = *reinterpret_cast<const f32x4*>(Vn + a1 + (xi + 2 - 16) * (kPcTiles * kCB));
                         }
-                        Bn[(xi + kPcBD) % kPcNB] = xi + kPcBD < 16 ? wcur[(xi + kPcBD) * 256] : wnx[(xi + kPcBD - 16) * 256];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[cur][0][e], Bn[xi % kPcNB][e],
@@ -143,6 +142,10 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                                                                               FIRST && e == 0 ? zero4 : acc[xi][1], 0, 0, 0);
                             // pin the order: the two row blocks alternate (no back-to-back dependent MFMAs) and the operand
                             // streams keep their distances
+                            // the weight line of the point 7 ahead is requested HERE, in the second MFMA gap of the point, not at its top beside the two
+                            // LDS reads: a vector-memory instruction costs the wave ~50 issue cycles, and three memory instructions in one gap let the
+                            // matrix pipe run dry (tools/probes/mfma_stream_probe.hip: 78.5 -> 85.4 % busy)
+                            if (e == 1) Bn[(xi + kPcBD) % kPcNB] = xi + kPcBD < 16 ? wcur[(xi + kPcBD) * 256] : wnx[(xi + kPcBD - 16) * 256];
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }

@@ -11,6 +11,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int RB, int ABL>   // ABL bits: 1 = no stage barrier, 2 = no weight loads (ring filled once), 4 = no LDS reads, 8 = no sched_barrier pin,
+                             // 128 = the 16-byte weight load issued in the third MFMA gap of the point instead of at its top,
                              // 64 = the weight line from LDS (ds_read_b128) instead of global memory,
                              // 16 = the weight line as four 4-byte loads (lane-contiguous layout), one per MFMA gap; 32 = as two 8-byte loads
 __global__ __launch_bounds__(RB == 2 ? 256 : 512) void probe(const f32x4* __restrict__ w, float* __restrict__ out, int stages, long long* clk) {
@@ -43,13 +44,14 @@ __global__ __launch_bounds__(RB == 2 ? 256 : 512) void probe(const f32x4* __rest
 #pragma unroll
             for (int r = 0; r < RB; ++r) if (!(ABL & 4)) An[nxt][r] = *reinterpret_cast<const f32x4*>(a0 + ((xi + 2) & 15) * 512 + r * 256);
             const size_t wpt = (size_t)(((s * 16 + xi + 7) & 63)) * 4096;
-            if (!(ABL & (2 | 16 | 32 | 64))) Bn[(xi + 7) & 7] = wl[wpt];
+            if (!(ABL & (2 | 16 | 32 | 64 | 128))) Bn[(xi + 7) & 7] = wl[wpt];
             if (ABL & 64) Bn[(xi + 7) & 7] = *reinterpret_cast<const f32x4*>(lds + 16384 + ((xi + 7) & 7) * 1024 + (wave & 3) * 256 + lane * 4);   // weight line from an LDS ring
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
                     acc[xi][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[cur][r][e], Bn[xi & 7][e], acc[xi][r], 0, 0, 0);
+                if ((ABL & 128) && e == 1) Bn[(xi + 7) & 7] = wl[wpt];      // the weight load two MFMA pairs after the LDS reads, not beside them
                 if (ABL & 16) Bn[(xi + 7) & 7][e] = wf[wpt * 4 + e * 64];                     // 256 contiguous bytes per wave instruction
                 if ((ABL & 32) && (e & 1) == 0) {
                     const float2 v = *reinterpret_cast<const float2*>(wf + wpt * 4 + e * 64);  // 512 contiguous bytes per wave instruction
@@ -100,6 +102,7 @@ int main() {
     run(&probe<2, 8>, 256, "1 wave/SIMD, scheduler free (no sched_barrier)");
     run(&probe<2, 7>, 256, "1 wave/SIMD, MFMAs only");
     run(&probe<2, 15>, 256, "1 wave/SIMD, MFMAs only, scheduler free");
+    run(&probe<2, 128>, 256, "1 wave/SIMD, weight load moved into a later MFMA gap");
     run(&probe<2, 64>, 256, "1 wave/SIMD, weight line read from LDS");
     run(&probe<1, 64>, 512, "2 waves/SIMD, weight line read from LDS");
     run(&probe<2, 16>, 256, "1 wave/SIMD, weight line = 4 x 4-byte loads in the gaps");
