@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                             // the weight line of the point 7 ahead is requested HERE, in the second MFMA gap of the point, not at its top beside the two
                             // LDS reads: a vector-memory instruction costs the wave ~50 issue cycles, and three memory instructions in one gap let the
                             // matrix pipe run dry (tools/probes/mfma_stream_probe.hip: 78.5 -> 85.4 % busy)
-                            if (e == 1) Bn[(xi + kPcBD) % kPcNB] = xi + kPcBD < 16 ? wcur[(xi + kPcBD) * 256] : wnx[(xi + kPcBD - 16) * 256];
+                            if (e == NRGBD_WPOS) Bn[(xi + kPcBD) % kPcNB] = xi + kPcBD < 16 ? wcur[(xi + kPcBD) * 256] : wnx[(xi + kPcBD - 16) * 256];
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }

@@ -16,6 +16,9 @@ constexpr int kPcV = 16 * kPcTiles * kCB;       // floats of one V buffer [16 xi
 constexpr int kPcNBuf = 3;
 constexpr int kPcItems = 4 * 18 * 4;            // (row, column, 16-byte word) items of a strip
 constexpr int kPcNPF = (kPcItems + 63) / 64;    // per producer lane and stage (5)
+#ifndef NRGBD_WPOS
+#define NRGBD_WPOS 1   // MFMA gap (0..3) of a transform point in which the consumers request the weight line 7 points ahead
+#endif
 constexpr int kPcBD = 7, kPcNB = 8;             // weight ring: distance / slots
 
 // BatchNorm finalisation fused into the convolution (wino_dw.hip): the last workgroup to finish turns the per-workgroup fp64

@@ -30,7 +30,7 @@ def main():
     args = ap.parse_args()
     if args.dev:
         from neuralrgbd_amd import _lib
-        _lib.LIB_PATH = _lib.LIB_PATH.replace("libnrgbd_hip.so", "libnrgbd_hip_dev.so")
+        _lib.LIB_PATH = os.environ.get("NRGBD_DEV_LIB") or _lib.LIB_PATH.replace("libnrgbd_hip.so", "libnrgbd_hip_dev.so")   # NRGBD_DEV_LIB: a one-off experimental build
     from neuralrgbd_amd import ops
     D, H, W = GRIDS[args.config]
     g = torch.Generator().manual_seed(0)
