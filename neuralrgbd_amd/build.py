@@ -61,6 +61,27 @@ def build_dev(verbose=False):
     return lib
 
 
+def build_variant(name, defines, only=("wino_dw.hip",), verbose=False):
+    """Experimental A/B library libnrgbd_exp_<name>.so: the product objects with `only` recompiled under extra -D defines.
+    Git-ignored; loaded by tools/ through _lib.LIB_PATH, never by the package."""
+    build()
+    lib = os.path.join(CSRC, "libnrgbd_exp_%s.so" % name)
+    objs = []
+    for src in sources():
+        base = os.path.basename(src)
+        if base in only:
+            obj = os.path.join(OBJ, "%s.%s.o" % (base[:-4], name))
+            cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + list(defines) + ["-c", "-I", INCLUDE, src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        else:
+            obj = os.path.join(OBJ, base[:-4] + ".o")
+        objs.append(obj)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    return lib
+
+
 def build(force=False, verbose=False):
     """Per-file objects (compiled in parallel, re-used when unchanged) linked into libnrgbd_hip.so."""
     if not force and not stale():

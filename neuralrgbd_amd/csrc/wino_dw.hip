@@ -61,6 +61,16 @@ __device__ __forceinline__ DwTile dw_decode(int t, const WinoPcArgs& a) {
     return r;
 }
 
+// Channel block of the i-th stage of phase t: odd phases sweep the blocks backwards (ncb-1 .. 0).  Phases 1 and 2 read the same
+// two slices, phase 0 / 1 and 2 / 3 share one: with every phase sweeping forwards a unit's re-read came Cin/16 stages after its
+// first read, and the 32 workgroups of an XCD stream 1.5 MB (3 MB with a residual operand) per stage through their 4 MB L2 beside
+// the 1 MB weight stream — every re-read missed (profiles/r3_pmc_wino.txt: the residual variant fetched ALL its reads).  Turning
+// round at the phase boundary puts the most recently read units first.
+#ifndef NRGBD_DW_SERP
+#define NRGBD_DW_SERP 1
+#endif
+__device__ __forceinline__ int dw_cb(int t, int i, int ncb) { return (NRGBD_DW_SERP && (t & 1)) ? ncb - 1 - i : i; }
+
 // slices combined by stage phase t: V_t = d[zA] + sign * d[zB]
 __device__ __forceinline__ int dw_zA(int t) { return t == 0 ? -1 : (t == 2 ? 1 : 0); }   // relative to z0: -1, 0, 1, 0
 __device__ __forceinline__ int dw_zB(int t) { return t == 2 ? 0 : (t == 3 ? 2 : 1); }    //                  1, 1, 0, 2
@@ -198,12 +208,13 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
             auto phase = [&](auto t_tag) __attribute__((always_inline)) {
                 constexpr int T = decltype(t_tag)::value;
                 for (int cb = 0; cb < ncb; ++cb) {
-                    const int s = T * ncb + cb;
+                    const int s = T * ncb + dw_cb(T, cb, ncb);          // cb: position in the phase's sweep
                     const float* Vc = Vb + buf * kPcV;
                     const int nbuf = buf ^ 1;
                     const float* Vn = Vb + nbuf * kPcV;
                     const f32x4* wcur = wt + (size_t)s * (16 * 256);
-                    const f32x4* wnx = s + 1 < NS ? wcur + 16 * 256 : wt_next;
+                    const f32x4* wnx = cb + 1 < ncb ? wt + (size_t)(T * ncb + dw_cb(T, cb + 1, ncb)) * (16 * 256)
+                                       : (T < 3 ? wt + (size_t)((T + 1) * ncb + dw_cb(T + 1, 0, ncb)) * (16 * 256) : wt_next);
                     auto body = [&](auto first_tag) __attribute__((always_inline)) {
                         constexpr bool FIRST = decltype(first_tag)::value;
                         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -500,7 +511,8 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                 const bool zinA = zA >= 0, zinB = zB < a.N;       // zA <= z0 + 1 < N and zB >= z0 >= 0 always hold
                 const bool wmat = MAT && t == 1 && tl.cg == 0;    // phase 1 publishes slices z0 (unit A) and z0 + 1 (unit B)
                 const bool nx = s + 1 >= NS;
-                const int cbn = cb + 1 == ncb ? 0 : cb + 1, tnx = nx ? 0 : (cb + 1 == ncb ? t + 1 : t);   // (t, cb) of stage s + 1
+                const int cbn = cb + 1 == ncb ? 0 : cb + 1, tnx = nx ? 0 : (cb + 1 == ncb ? t + 1 : t);   // (t, position) of stage s + 1
+                const int cbe = dw_cb(t, cb, ncb), cbne = dw_cb(tnx, cbn, ncb);                            // their channel blocks
                 if constexpr (MAT) {
                     // With materialise stores in the queue the compiler cannot count it (loads and stores of one wave pending =
                     // "may complete out of order" = every wait becomes vmcnt(0)), and the wait for set B would also wait for the
@@ -520,18 +532,18 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
 #pragma unroll
                     for (int u = 0; u < kPcNPF; ++u) *reinterpret_cast<f32x4*>(raw + wr_off[u]) = f32x4{0.f, 0.f, 0.f, 0.f};
                 } else {
-                    if (interior) publish(std::false_type{}, std::true_type{}, setA, zA, cb, wmat, 1.f);
-                    else publish(std::false_type{}, std::false_type{}, setA, zA, cb, wmat, 1.f);
+                    if (interior) publish(std::false_type{}, std::true_type{}, setA, zA, cbe, wmat, 1.f);
+                    else publish(std::false_type{}, std::false_type{}, setA, zA, cbe, wmat, 1.f);
                 }
                 // refills are UNCONDITIONAL (the last stage of the last tile re-reads this tile's stage 0: harmless, never used);
                 // a set is refilled right after it was published (longest time to land)
-                if (!(abl & (2 | 32))) issue(nx && has_next, tnx, cbn, false, setA);
+                if (!(abl & (2 | 32))) issue(nx && has_next, tnx, cbne, false, setA);
                 // (2) unit B combined into the strip: V_t = d[zA] + sign d[zB], sign = +1 in phase 1 only
                 if (zinB && !(abl & (2 | 16))) {
-                    if (interior) publish(std::true_type{}, std::true_type{}, setB, zB, cb, wmat, t == 1 ? 1.f : -1.f);
-                    else publish(std::true_type{}, std::false_type{}, setB, zB, cb, wmat, t == 1 ? 1.f : -1.f);
+                    if (interior) publish(std::true_type{}, std::true_type{}, setB, zB, cbe, wmat, t == 1 ? 1.f : -1.f);
+                    else publish(std::true_type{}, std::false_type{}, setB, zB, cbe, wmat, t == 1 ? 1.f : -1.f);
                 }
-                if (!(abl & (2 | 32))) issue(nx && has_next, tnx, cbn, true, setB);
+                if (!(abl & (2 | 32))) issue(nx && has_next, tnx, cbne, true, setB);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // (3) plane transform B^T d B of this lane's (tile, word): rows (2 of the 4 xi_y), then columns
                 if (!(abl & (2 | 4))) {

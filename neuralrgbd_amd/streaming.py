@@ -56,12 +56,12 @@ class DepthStream:
         return r_kv, dpv, nxt
 
     def _capture(self, ref, src, poses, pose_next):
-        st = {"ref": ref.clone(), "src": src.clone(), "poses": poses.clone(), "inv": pose_next.clone(),
+        st = {"ref": ref.clone(), "src": src.clone(), "poses": poses.clone(), "pose_next": pose_next.clone(),
               "bv": self.bv_predict.clone()}
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            st["out"] = self._frame(st["ref"], st["src"], st["poses"], st["inv"], st["bv"])
+            st["out"] = self._frame(st["ref"], st["src"], st["poses"], st["pose_next"], st["bv"])
         st["consts"] = warp_homo.cache_snapshot()      # K / rays / d_candi the graph reads: kept alive with the graph
         self._graph, self._static = g, st
 
@@ -71,14 +71,16 @@ class DepthStream:
         Returns (refined DPV [1,D,H,W], DPV [1,D,h,w]); the predicted state for the next frame is kept inside.
         With the hipGraph active and copy_outputs=False the returned tensors are only valid until the next step()."""
         pose = src_cam_poses[0, self.t_win_r] if cam_pose_next is None else cam_pose_next
-        pose_next_inv = pose.to(dtype=torch.float32).contiguous()   # inverted inside the frame (nrgbd_pose_inverse)
+        # the pose of the next reference frame, NOT inverted: the inversion happens inside the frame (nrgbd_pose_inverse); a host
+        # tensor is accepted as before (ADVICE r3)
+        pose_next = pose.to(device=self.device, dtype=torch.float32).contiguous()
         if self.bv_predict is None:                      # first window of the stream: D-Net only
-            r, dpv, nxt = self._frame(ref_frame, src_frames, src_cam_poses, pose_next_inv, None)
+            r, dpv, nxt = self._frame(ref_frame, src_frames, src_cam_poses, pose_next, None)
             self.bv_predict = nxt
             return r, dpv
         if self.use_graph and self._graph is None and self.graph_error is None and self._eager_updates >= 1:
             try:
-                self._capture(ref_frame, src_frames, src_cam_poses, pose_next_inv)
+                self._capture(ref_frame, src_frames, src_cam_poses, pose_next)
             except Exception as e:  # keep running eagerly, but say so
                 self.graph_error = repr(e)
                 self._graph = None
@@ -86,14 +88,14 @@ class DepthStream:
         if self._graph is not None:
             st = self._static
             st["ref"].copy_(ref_frame); st["src"].copy_(src_frames); st["poses"].copy_(src_cam_poses)
-            st["inv"].copy_(pose_next_inv); st["bv"].copy_(self.bv_predict)
+            st["pose_next"].copy_(pose_next); st["bv"].copy_(self.bv_predict)
             self._graph.replay()
             r, dpv, nxt = st["out"]
             self.bv_predict = nxt        # static output buffer: copied into st["bv"] at the next step
             if self.copy_outputs:
                 return r.clone(), dpv.clone()
             return r, dpv                # valid until the next step() (see copy_outputs)
-        r, dpv, nxt = self._frame(ref_frame, src_frames, src_cam_poses, pose_next_inv, self.bv_predict)
+        r, dpv, nxt = self._frame(ref_frame, src_frames, src_cam_poses, pose_next, self.bv_predict)
         self._eager_updates += 1
         self.bv_predict = nxt
         return r, dpv

@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="B")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default="", help="substring filter on the variant names (e.g. 'wino-dw')")
     ap.add_argument("--cnn", action="store_true", help="also time the feature CNN's 2-D layer shapes")
     ap.add_argument("--dev", action="store_true", help="load libnrgbd_hip_dev.so (python -m neuralrgbd_amd.build --dev): "
                     "NRGBD_WINO_ABL=1|2 (producers only / consumers only) is honoured there")
@@ -49,6 +50,8 @@ def main():
                      ("direct res+mat", lambda: ops.conv3d(x, wd, x_ss=ss, res=r, materialize=True)),
                      ("wino   res+mat", lambda: ops.conv3d_wino(x, ww, x_ss=ss, res=r, materialize=True)),
                      ("wino-pc res+mat", lambda: ops.conv_wino(x, ww, 64, 3, x_ss=ss, res=r, materialize=True))):
+        if args.only and args.only not in name:
+            continue
         ms = timeit(fn, args.iters)
         print("%-16s %8.3f ms   %6.1f TFLOP/s nominal (27-tap flops)" % (name, ms, flops / ms / 1e9))
     if args.dev and (int(os.environ.get("NRGBD_WINO_ABL", "0")) & 64):
@@ -62,6 +65,8 @@ def main():
         r2 = st.reshape(-1)[4096:4096 + 256 * 4].reshape(256, 4).double().cpu() / per
         print("publish split: wait-vmcnt %.0f  valu+ds_write %.0f  issue-loads %.0f" % tuple(r2.median(0).values.tolist()[:3]))
         print("in-kernel wall_clock64 (10 ns ticks) per stage, median over workgroups: " + "  ".join("%s %.0f" % (n, v) for n, v in zip(names, vals.median(0).values.tolist())))
+    if args.only:
+        return
     y1 = ops.conv3d(x, wd, x_ss=ss, x_relu=True)[0]
     y2 = ops.conv3d_wino(x, ww, x_ss=ss, x_relu=True)[0]
     print("max|wino - direct| = %.3e (|y|max %.2f)" % ((y1 - y2).abs().max().item(), y1.abs().max().item()))
