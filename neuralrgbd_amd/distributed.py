@@ -70,6 +70,15 @@ class GradAllReduce:
 
     Use:  reducer.prepare(); loss.backward(); reducer(); optimizer.step()
     (`prepare` re-attaches the views — optimizers' zero_grad(set_to_none=True) drops them — and zeroes the buffers.)
+
+    Gradient accumulation (BASELINE config 4: global batch 32 = 8 GPUs x 4 sequential N = 1 windows):
+        reducer.prepare(accum_steps=4); four times { loss.backward() }; reducer(); optimizer.step()
+    the four backward passes add into the same buckets, a bucket's collective starts (from the LAST pass's hooks) once all
+    4 x len(bucket) gradients have landed, and `__call__` divides by 4 * world: the mean over all 32 windows.  With one rank
+    the division by accum_steps still happens (no collective).
+
+    `hold = True` keeps the hooks from launching anything (train_step.TrainGraph: forward + backward are captured into a
+    hipGraph, whose replays run no hooks; every bucket is then launched from `__call__`, in index order as always).
     """
 
     def __init__(self, module, bucket_mb=6.0, overlap=True):
@@ -99,6 +108,8 @@ class GradAllReduce:
         self._pending = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self.overlap = overlap
+        self.hold = False
+        self._accum = 1
         self.launched_in_backward = 0              # buckets whose collective started from a hook in the last step
         if overlap and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
             for p in self.params:
@@ -112,13 +123,16 @@ class GradAllReduce:
     def _active(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
-    def prepare(self):
-        """Before backward: zero the messages and make every .grad a view into its bucket."""
+    def prepare(self, accum_steps=1):
+        """Before the (first) backward: zero the messages and make every .grad a view into its bucket."""
+        if accum_steps < 1:
+            raise ValueError("accum_steps must be >= 1")
+        self._accum = int(accum_steps)
         for flat in self.flat:
             flat.zero_()
         for p in self.params:
             p.grad = self._views[p]
-        self._pending = [len(b) for b in self.buckets]
+        self._pending = [len(b) * self._accum for b in self.buckets]
         self._work = [None] * len(self.buckets)
         self._next = 0                             # first bucket not launched yet: launches happen in index order only
         self.launched_in_backward = 0
@@ -136,7 +150,7 @@ class GradAllReduce:
             self._views[p].copy_(p.grad)
             p.grad = self._views[p]
         self._pending[bi] -= 1
-        if self.overlap and self._active():
+        if self.overlap and not self.hold and self._active():
             # in index order only: a complete bucket behind an incomplete one waits (for __call__ at the latest), so that
             # every rank issues the same sequence of collectives whatever sub-networks its step used
             while self._next < len(self.buckets) and self._pending[self._next] == 0:
@@ -147,8 +161,15 @@ class GradAllReduce:
 
     def __call__(self):
         if not self._active():
+            if self._accum > 1:                    # one rank: the mean over the accumulated windows, no collective
+                for p in self.params:
+                    if p.grad is not None and p.grad is not self._views[p]:
+                        self._views[p].copy_(p.grad)
+                        p.grad = self._views[p]
+                for flat in self.flat:
+                    flat.div_(self._accum)
             return
-        world = dist.get_world_size()
+        world = dist.get_world_size() * self._accum
         for p in self.params:                      # no hook support / a replaced grad tensor: fold it into the message
             if p.grad is not None and p.grad is not self._views[p] and self._work[self._bucket_of[p]] is None:
                 self._views[p].copy_(p.grad)

@@ -19,56 +19,85 @@ from . import ops
 from .misc import depth_val_regression, valid_dpv
 
 
-def train(nGPU, model_KV, optimizer_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, Src_CamPoses, BVs_predict,
-          Cam_Intrinsics, refine_dup=False, weight_var=.001, loss_type='NLL', mGPU=False,
-          Cam_Intrinsics_spatial_up=None, return_confmap_up=False, grad_reducer=None):
-    """Returns (r_dpv, BVs_predict_out, loss, dmap_kv_lowres, dmap_kv_highres) — the two depth maps are device
-    tensors (the reference stacks them with the ground truth into numpy arrays for TensorBoard)."""
-    if loss_type != 'NLL' or refine_dup:
-        raise NotImplementedError("only the NLL loss without depth up-sampling is on this path")
-    if len(Ref_Dats) != 1:
-        raise AssertionError("one trajectory per process (N = 1 per replica)")
-    dev = next(model_KV.parameters()).device
-    ref_frame = torch.cat(tuple(r['img'] for r in Ref_Dats), dim=0).to(dev)
-    src_frames = torch.cat(tuple(torch.cat(tuple(f['img'] for f in traj), dim=0).unsqueeze(0) for traj in Src_Dats),
-                           dim=0).to(dev)
-    poses = Src_CamPoses.to(dev)
-    if grad_reducer is not None and hasattr(grad_reducer, "prepare"):
-        grad_reducer.prepare()         # .grad = zeroed views into the all-reduce buckets (no per-step flatten / scatter)
-    else:
-        optimizer_KV.zero_grad()
-
-    valid = valid_dpv(BVs_predict) if isinstance(BVs_predict, torch.Tensor) else False
-    dmap_cur_refined, dmap_refined, d_dpv, kv_dpv = model_KV(
-        ref_frame=ref_frame, src_frames=src_frames, src_cam_poses=poses, BatchIdx=torch.zeros(1),
-        cam_intrinsics=Cam_Intrinsics, BV_predict=BVs_predict if valid else None, dpv_valid=True if valid else None)
-
-    # train_KVNet.py:103-120: NLL on the 1/4-res DPV and on its R-Net refinement, for the measurement and the update
-    depth_ref = Ref_Dats[0]['dmap'].to(dev)                        # [1,h,w] int64 bin indices, 0 = ignore
-    depth_ref_imgsize = Ref_Dats[0]['dmap_imgsize_digit'].to(dev)  # [1,H,W]
+def _nll_terms(d_dpv, dmap_cur_refined, kv_dpv, dmap_refined, depth_ref, depth_ref_imgsize, valid):
+    """train_KVNet.py:103-120: NLL on the 1/4-res DPV and on its R-Net refinement, for the measurement and (update branch)
+    for the filtered volume."""
     loss = F.nll_loss(d_dpv, depth_ref, ignore_index=0)
     loss = loss + F.nll_loss(dmap_cur_refined, depth_ref_imgsize, ignore_index=0)
     if valid:
         loss = loss + F.nll_loss(kv_dpv, depth_ref, ignore_index=0)
         loss = loss + F.nll_loss(dmap_refined, depth_ref_imgsize, ignore_index=0)
+    return loss
 
-    loss.backward()
+
+def _predict(kv, pose_next, cam, d_candi):
+    """PREDICT on the detached DPV (train_KVNet.py:155-171): fixed-order pose inverse + one resampling launch."""
+    rel_Rt = ops.pose_inverse(pose_next.to(dtype=torch.float32).contiguous())
+    return warp_homo.resample_vol_cuda(src_vol=kv, rel_extM=rel_Rt, cam_intrinsic=cam, d_candi=d_candi,
+                                       padding_value=math.log(1. / float(len(d_candi))), clamp=(-1000., 0.)).unsqueeze(0)
+
+
+def train(nGPU, model_KV, optimizer_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, Src_CamPoses, BVs_predict,
+          Cam_Intrinsics, refine_dup=False, weight_var=.001, loss_type='NLL', mGPU=False,
+          Cam_Intrinsics_spatial_up=None, return_confmap_up=False, grad_reducer=None, accum_steps=1):
+    """Returns (r_dpv, BVs_predict_out, loss, dmap_kv_lowres, dmap_kv_highres) — the two depth maps are device
+    tensors (the reference stacks them with the ground truth into numpy arrays for TensorBoard).
+
+    accum_steps = A > 1 (BASELINE config 4: global batch 32 = 8 GPUs x 4): the call takes A trajectories the way the
+    reference's batch dimension does — Ref_Dats / Src_Dats lists of length A, Src_CamPoses [A,V,4,4], BVs_predict None, a
+    tensor [A,D,h,w] or a list of A (tensor | None) — and runs them as A SEQUENTIAL N = 1 windows (KVNET asserts N = 1 per
+    forward), each with its own BV_predict: A forward/backward passes accumulate into the same gradient, ONE all-reduce,
+    division by A x world, ONE optimizer step.  Outputs are concatenated along the batch dimension; `loss` is the mean."""
+    if loss_type != 'NLL' or refine_dup:
+        raise NotImplementedError("only the NLL loss without depth up-sampling is on this path")
+    A = int(accum_steps)
+    if A < 1:
+        raise ValueError("accum_steps must be >= 1")
+    if len(Ref_Dats) != A or len(Src_Dats) != A:
+        raise AssertionError("one trajectory per accumulation step and process (N = 1 per forward): %d windows for accum_steps=%d"
+                             % (len(Ref_Dats), A))
+    dev = next(model_KV.parameters()).device
+    poses_all = Src_CamPoses.to(dev)
+    if grad_reducer is not None and hasattr(grad_reducer, "prepare"):
+        # .grad = zeroed views into the all-reduce buckets (no per-step flatten / scatter)
+        grad_reducer.prepare(A) if A > 1 else grad_reducer.prepare()
+    else:
+        optimizer_KV.zero_grad()
+
+    outs = []
+    for b in range(A):
+        ref_frame = Ref_Dats[b]['img'].to(dev)
+        src_frames = torch.cat(tuple(f['img'] for f in Src_Dats[b]), dim=0).unsqueeze(0).to(dev)
+        poses = poses_all[b:b + 1]
+        bv = BVs_predict[b] if isinstance(BVs_predict, (list, tuple)) else (
+            BVs_predict[b:b + 1] if isinstance(BVs_predict, torch.Tensor) and A > 1 else BVs_predict)
+        if isinstance(bv, torch.Tensor) and bv.dim() == 3:
+            bv = bv.unsqueeze(0)
+        cam = Cam_Intrinsics[b] if len(Cam_Intrinsics) == A else Cam_Intrinsics[0]
+        valid = valid_dpv(bv) if isinstance(bv, torch.Tensor) else False
+        dmap_cur_refined, dmap_refined, d_dpv, kv_dpv = model_KV(
+            ref_frame=ref_frame, src_frames=src_frames, src_cam_poses=poses, BatchIdx=torch.zeros(1),
+            cam_intrinsics=[cam], BV_predict=bv if valid else None, dpv_valid=True if valid else None)
+        depth_ref = Ref_Dats[b]['dmap'].to(dev)                        # [1,h,w] int64 bin indices, 0 = ignore
+        depth_ref_imgsize = Ref_Dats[b]['dmap_imgsize_digit'].to(dev)  # [1,H,W]
+        loss = _nll_terms(d_dpv, dmap_cur_refined, kv_dpv, dmap_refined, depth_ref, depth_ref_imgsize, valid)
+        loss.backward()                # accumulates: the mean over the A windows is taken once, after the all-reduce
+        with torch.no_grad():
+            kv = kv_dpv.detach()
+            outs.append((dmap_cur_refined.detach(), _predict(kv, poses[0, t_win_r], cam, d_candi), loss.detach(),
+                         depth_val_regression(kv, d_candi, BV_log=True),
+                         depth_val_regression(dmap_refined.detach(), d_candi, BV_log=True)))
+
     if grad_reducer is not None:
-        grad_reducer()                 # RCCL all-reduce (sum / world) of the 21 MB fp32 gradient: buckets whose gradients
-                                       # were complete started from backward hooks; this waits for all of them
+        grad_reducer()                 # RCCL all-reduce (sum / (A * world)) of the 21 MB fp32 gradient: buckets whose gradients
+                                       # were complete started from the last window's backward hooks; this waits for all of them
+    elif A > 1:
+        torch._foreach_div_([p.grad for p in model_KV.parameters() if p.grad is not None], float(A))
     optimizer_KV.step()
-
-    # PREDICT on the detached DPV (train_KVNet.py:155-171)
-    with torch.no_grad():
-        kv = kv_dpv.detach()
-        rel_Rt = ops.pose_inverse(poses[0, t_win_r].to(dtype=torch.float32).contiguous())   # fixed-order inverse (test_step.py)
-        BVs_predict_out = warp_homo.resample_vol_cuda(
-            src_vol=kv, rel_extM=rel_Rt, cam_intrinsic=Cam_Intrinsics[0], d_candi=d_candi,
-            padding_value=math.log(1. / float(len(d_candi))), clamp=(-1000., 0.)).unsqueeze(0)
-        r_dpv = dmap_cur_refined.detach()
-        dmap_kv_lowres = depth_val_regression(kv, d_candi, BV_log=True)
-        dmap_kv_highres = depth_val_regression(dmap_refined.detach(), d_candi, BV_log=True)
-    return r_dpv, BVs_predict_out, loss.detach(), dmap_kv_lowres, dmap_kv_highres
+    if A == 1:
+        return outs[0]
+    r_dpv, pred, loss, lo, hi = zip(*outs)
+    return torch.cat(r_dpv, 0), torch.cat(pred, 0), torch.stack(loss).mean(), torch.cat(lo, 0), torch.cat(hi, 0)
 
 
 class TrainGraph:
