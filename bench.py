@@ -156,10 +156,14 @@ class KernelTimer:
             return fn(*a, **k)
         return remembering
 
-    def measure(self, launches):
+    def measure(self, launches, warm=1):
+        """`warm` untimed launches first: after any idle gap (a host sync, the CPU baseline, a profiler child process) the part
+        takes 5-20 launches to come back to its steady state — the first ones run 15-30 % slow (profiles/r4_inframe_gap.txt:
+        2.6-2.8 ms against 2.18 ms sustained for the K-Net layer; round 3's "in-frame 2.50 ms" was this ramp, measured behind
+        the PMC child passes) — and the frame itself runs in the steady state."""
         a, k = self.last
-        self.fn(*a, **k)
-        torch.cuda.synchronize()
+        for _ in range(max(1, warm)):
+            self.fn(*a, **k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(launches):
@@ -246,12 +250,28 @@ def parity_block(cfg, gpu, oracle_out):
     return blk
 
 
+def respawn_under_torchrun(gpus):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a torchrun environment: re-exec this command line as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...`,
+    one rank per GPU.  Never returns.  (With RANK / WORLD_SIZE already set — the driver's own torchrun — nothing happens here.)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def init_world(gpus, backend):
-    """(world, rank, local) from the torchrun environment; the process group is created for world > 1."""
+    """(world, rank, local) from the torchrun environment; the process group is created for world > 1.  The world size must
+    equal --gpus: a mismatch is an error, never a silent single-GPU run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != gpus and world > 1:
+    if world != gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (gpus, world))
     if world > 1:
         import torch.distributed as dist
@@ -261,6 +281,15 @@ def init_world(gpus, backend):
         else:
             dist.init_process_group(backend)
     return world, rank, local
+
+
+def verified_ranks(world, device):
+    """Ranks that actually took part in a collective: an all-reduce (sum) of ones on `device` (RCCL for cuda tensors)."""
+    if world == 1:
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    torch.distributed.all_reduce(t)
+    return int(round(float(t.item())))
 
 
 def timed_steps(frame, steps, world, device):
@@ -289,78 +318,93 @@ def stub_main(args):
     path as the real run on a gloo group, with a frame function that only sleeps (rank r sleeps (r+1) x 5 ms, so the MAX
     is visible).  The line is marked "stub": true and carries no metric."""
     world, rank, _ = init_world(args.gpus, "gloo")
+    ranks = verified_ranks(world, torch.device("cpu"))
     frame = lambda i: time.sleep(0.005 * (rank + 1))
     for i in range(args.warmup):
         frame(i)
     dt = timed_steps(frame, args.steps, world, torch.device("cpu"))
     if rank == 0:
-        print(json.dumps({"stub": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        print(json.dumps({"stub": True, "n_gpus": world, "collective_ranks": ranks, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * dt / args.steps, "value": args.steps * world / dt, "scaling": "weak"}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
 
 def train_main(args):
-    """--mode train: BASELINE config 4 shape (ScanNet 384x256 image, grid 96x64, 64 candidates, one window per GPU per
-    iteration; the reference's global batch 32 = 8 GPUs x 4 sequential windows).  One step = one call of
-    neuralrgbd_amd.train_step.train (forward under autograd, 4 NLL terms, backward, bucketed RCCL all-reduce of the 21 MB
-    gradient when N > 1 — started from backward hooks —, Adam, PREDICT).  Not the headline metric: a separate, labelled line."""
+    """--mode train: BASELINE config 4 shape (ScanNet 384x256 image, grid 96x64, 64 candidates; the reference's global batch 32
+    = 8 GPUs x 4 sequential N = 1 windows).  One step = ONE optimizer step = `--accum` (default 4) windows per GPU through
+    neuralrgbd_amd.train_step (forward under autograd, 4 NLL terms, backward — accumulated over the windows —, ONE bucketed
+    RCCL all-reduce of the 21 MB gradient when N > 1, division by accum x N, Adam, PREDICT per window); hipGraph replay at
+    every N (train_step.TrainGraph: the split form for N > 1 or accum > 1).  Not the headline metric: a separate, labelled line."""
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     world, rank, local = init_world(args.gpus, "nccl")
+    ranks = verified_ranks(world, dev)
     import neuralrgbd_amd
     from neuralrgbd_amd import camera, distributed as nd, ops, synth
     from neuralrgbd_amd.train_step import TrainGraph, train
-    H, W, D = 256, 384, 64
+    H, W, D, A = 256, 384, 64, max(1, args.accum)
     cam = camera.scannet_intrinsics(W // 4, H // 4)
     d_candi = np.linspace(0.1, 5, D)
     model = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
     model.load_state_dict(synth.seeded_state_dict(model, 0))
     model = model.to(dev)
-    use_graph = world == 1 and not args.no_graph      # single-GPU: the iteration replayed as one hipGraph (train_step.TrainGraph)
+    use_graph = not args.no_graph
     opt = torch.optim.Adam(model.parameters(), lr=1e-5, betas=(.9, .999), capturable=use_graph)      # local_train_scanNet.sh
     reducer = nd.GradAllReduce(model) if world > 1 else None
-    tg = TrainGraph(model, opt, 2, d_candi, cam, warmup=0) if use_graph else None
+    tg = TrainGraph(model, opt, 2, d_candi, cam, warmup=0, grad_reducer=reducer, accum_steps=A) if use_graph else None
     rng = np.random.RandomState(rank)
-    wins = []
-    for it in range(4):
-        r, s_, p = synth.noise_window(100 * rank + it, H, W)
-        wins.append(([{"img": r.to(dev), "dmap": torch.from_numpy(rng.randint(0, D, (1, H // 4, W // 4))).to(dev),
-                       "dmap_imgsize_digit": torch.from_numpy(rng.randint(0, D, (1, H, W))).to(dev)}],
-                     [[{"img": s_[0, v:v + 1].to(dev)} for v in range(4)]], p.to(dev)))
+    n_ring = 3
+    wins = []                 # wins[slot][k]: the k-th window of accumulation slot `slot` (every slot is its own trajectory)
+    for slot in range(A):
+        ring = []
+        for it in range(n_ring):
+            r, s_, p = synth.noise_window(1000 * rank + 10 * slot + it, H, W)
+            ring.append(({"img": r.to(dev), "dmap": torch.from_numpy(rng.randint(0, D, (1, H // 4, W // 4))).to(dev),
+                          "dmap_imgsize_digit": torch.from_numpy(rng.randint(0, D, (1, H, W))).to(dev)},
+                         [{"img": s_[0, v:v + 1].to(dev)} for v in range(4)], p.to(dev)))
+        wins.append(ring)
     # the K-Net's 64 -> 64 layers run through ops.conv_wino_dw (forward and data gradient: autograd.Conv3dCL)
     knet_timer = KernelTimer(keep=lambda a, k: a[0].shape[-1] == 64)
     ops.conv_wino_dw = knet_timer.wrap(ops.conv_wino_dw)
-    state = {"pred": None, "loss": None}
+    state = {"pred": [None] * A, "loss": None}
 
     def step(i, eager=False):
-        ref, src, p = wins[i % len(wins)]
+        batch = [wins[slot][i % n_ring] for slot in range(A)]
         if tg is not None and not eager:
-            srcs = torch.cat([s_["img"] for s_ in src[0]], dim=0).unsqueeze(0)
-            loss, pred = tg.step(ref[0]["img"], srcs, p, ref[0]["dmap"], ref[0]["dmap_imgsize_digit"], state["pred"])
-            state["pred"], state["loss"] = pred.clone(), loss      # the graph's outputs are static buffers
+            windows = [(ref["img"], torch.cat([s_["img"] for s_ in src], dim=0).unsqueeze(0), p, ref["dmap"],
+                        ref["dmap_imgsize_digit"], state["pred"][slot]) for slot, (ref, src, p) in enumerate(batch)]
+            if tg.split:
+                state["loss"], state["pred"] = tg.step_windows(windows)
+            else:
+                loss, pred = tg.step(*windows[0])
+                state["pred"], state["loss"] = [pred.clone()], loss      # the graph's outputs are static buffers
             return
-        _, state["pred"], state["loss"], _, _ = train(world, model, opt, 2, d_candi, ref, src, p, state["pred"], [cam],
-                                                      grad_reducer=reducer)
-    for i in range(2):      # first frame + one update frame launched from Python: filter state, optimizer state, caches, vendor find
+        _, pred, state["loss"], _, _ = train(world, model, opt, 2, d_candi, [b_[0] for b_ in batch], [b_[1] for b_ in batch],
+                                             torch.cat([b_[2] for b_ in batch], dim=0), state["pred"], [cam],
+                                             grad_reducer=reducer, accum_steps=A)
+        state["pred"] = list(pred.split(1, dim=0))
+    for i in range(2):      # first frame + one update frame launched from Python: filter state, optimizer state, caches
         step(i, eager=True)
     for i in range(max(args.warmup, 2)):
         step(i + 2)
     dt = timed_steps(step, args.steps, world, dev)
     assert bool(torch.isfinite(state["loss"])), "training loss went non-finite"
     if rank == 0:
-        line = {"metric": "training windows/sec @grid 96x64x64cand, 5-view window, N=1 per GPU (BASELINE config 4 shape)",
-                "value": args.steps * world / dt, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        line = {"metric": "training windows/sec @grid 96x64x64cand, 5-view window, N=1 per forward (BASELINE config 4 shape)",
+                "value": args.steps * A * world / dt, "unit": "windows/s", "n_gpus": world, "rccl_ranks": ranks, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "ms_per_window": 1e3 * dt / (args.steps * A),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "ScanNet training window 384x256 image, grid 96x64x64cand, Adam lr 1e-5", "mode": "train",
-                           "launch": "hipGraph replay" if tg is not None else "eager",
-                           "parallelism": "data-parallel x%d, one bucketed gradient all-reduce per step (%.2f MB fp32)" %
-                                          (world, 4e-6 * sum(p.numel() for p in set(model.parameters()))),
+                           "accum_steps": A, "global_batch": A * world,
+                           "launch": ("hipGraph replay (%s)" % ("forward+backward graph x%d, all-reduce, optimizer graph" % A
+                                                                if tg.split else "one graph")) if tg is not None else "eager",
+                           "parallelism": "data-parallel x%d, %d windows per rank and step, one bucketed gradient all-reduce per step (%.2f MB fp32)" %
+                                          (world, A, 4e-6 * sum(p.numel() for p in set(model.parameters()))),
                            "loss": float(state["loss"])}}
         if knet_timer.last is not None:
-            c_ms = knet_timer.measure(5)
+            c_ms = knet_timer.measure(20, warm=30)
             a0 = knet_timer.last[0][0]
             blocks = (-(-a0.shape[0] // 2)) * (-(-a0.shape[1] // 2)) * (-(-a0.shape[2] // 2))
             flops = 2.0 * blocks * 64 * 64 * 64               # issued in the Winograd domain: 64 multiplies per 2x2x2 outputs and (ci, co)
@@ -371,7 +415,8 @@ def train_main(args):
                                 "flops": flops, "direct_conv_flops": 2.0 * a0.shape[0] * a0.shape[1] * a0.shape[2] * 64 * 64 * 27,
                                 "traffic": None, "kernel_ms": c_ms}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_train(model, cam, d_candi, wins, 10.0)
+            flat = [([ref], [src], p) for ring in wins for (ref, src, p) in ring]
+            line["cpu_baseline"] = cpu_baseline_train(model, cam, d_candi, flat, 10.0)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -390,9 +435,13 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="independent video streams per GPU, each on its own HIP stream "
                     "(a step is then one frame of EVERY stream; the extra streams fill the tails of each other's kernels)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU self-test of the N>1 harness
+    ap.add_argument("--accum", type=int, default=4, help="--mode train: windows per GPU and optimizer step (gradient accumulation; "
+                    "BASELINE config 4 = global batch 32 = 8 GPUs x 4)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train: a separate, labelled line for the "
                     "training iteration at BASELINE config 4's shape (not the headline metric)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        respawn_under_torchrun(args.gpus)          # never print n_gpus: 1 for --gpus N
     if args.stub:
         return stub_main(args)
     if args.mode == "train":
@@ -402,6 +451,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     world, rank, local = init_world(args.gpus, "nccl")
+    ranks = verified_ranks(world, dev)     # an actual RCCL all-reduce at N > 1: the line's "rccl_ranks"
 
     import neuralrgbd_amd
     from neuralrgbd_amd import camera, ops, synth
@@ -455,8 +505,9 @@ def main():
     assert bool(torch.isfinite(pred).all()), "filter state went non-finite"
 
     if rank == 0:
-        n_k = max(args.steps, 5)
-        k_ms = timer.measure(n_k)
+        n_k = max(args.steps, 20)
+        k_ms = timer.measure(n_k, warm=20)          # straight behind the timed frames, in the steady state (KernelTimer.measure)
+        c_ms = knet_timer.measure(20, warm=30) if knet_timer.last is not None else None
         algo = costvol_bytes(V, 67, D, h, w)
         achieved = algo / (k_ms * 1e-3) / 1e9
         traffic, traffic_note = (None, "")
@@ -467,7 +518,7 @@ def main():
             traffic, traffic_note = t2, (n2 if not traffic_note else "%s; live measurement unavailable: %s" % (n2, traffic_note))
         line = {
             "metric": "depth frames/sec @256x192x64cand, 5-view window; warp-kernel HBM GB/s vs peak",
-            "value": args.steps * S * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": args.steps * S * world / dt, "unit": "frames/s", "n_gpus": world, "rccl_ranks": ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "config_id": args.config, "grid_hw": [h, w], "depth_candidates": D,
@@ -477,11 +528,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "costvol_quad<L2,3> (fused warp + cost volume + log-softmax over depth, one launch)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes": algo, "kernel_ms": k_ms, "launches_timed": n_k,
-                         "timing": "HIP events around back-to-back launches of the frame's own costvol call (log-softmax launch included), right after the timed region",
+                         "timing": "HIP events around back-to-back launches of the frame's own costvol call (log-softmax launch included), after 20 untimed ones, right after the timed region",
                          "traffic": traffic, "traffic_source": traffic_note},
         }
-        if knet_timer.last is not None:   # secondary roofline: the matrix-core kernel that takes most of the frame
-            c_ms = knet_timer.measure(5)
+        if c_ms is not None:   # secondary roofline: the matrix-core kernel that takes most of the frame
             # F(2x2,3x3) in the plane and F(2,3) along depth: 64 multiplies per 2x2x2 outputs and (ci, co) instead of 216 -> the
             # MFMAs the kernel actually issues; the 27-tap figure is what a direct convolution would need for the same layer
             nominal = 2.0 * D * h * w * 64 * 64 * 27
@@ -493,7 +543,8 @@ def main():
                                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                      "flops": flops, "direct_conv_flops": nominal,
                                      "direct_conv_equivalent_tflops": nominal / (c_ms * 1e-3) / 1e12, "kernel_ms": c_ms,
-                                     "launches_timed": 5, "timing": "HIP events around back-to-back re-launches of the frame's own layer call"}
+                                     "launches_timed": 20, "timing": "HIP events around 20 back-to-back re-launches of the frame's own layer call, "
+                                     "after 30 untimed ones, straight behind the timed frames (steady state; profiles/r4_inframe_gap.txt)"}
         if world == 1 and not args.no_cpu_baseline:
             # the same frame on both sides: window ring[0] filtered with the stream's current state
             pred = pred.clone()

@@ -105,10 +105,16 @@ class TrainGraph:
     into a hipGraph and replayed: one training step launches ~1,300 kernels, and launched from Python the host, not the
     GPU, sets the pace (tools/bench_train.py: 62 ms eager vs 58 ms of kernels).
 
-    Single-GPU form (the gradient all-reduce of a multi-GPU run stays outside a graph).  The optimizer must be built
-    with `capturable=True`.  Inputs are copied into static buffers; the pose inverse for PREDICT is computed outside
-    the graph (the solver may allocate).  `step()` returns (loss, BV_predict for the next window); once the graph is
-    active these are static tensors that the next step() overwrites.
+    Two forms.
+      * ONE graph (grad_reducer None, accum_steps 1): forward + backward + Adam + PREDICT, gradients in the graph's pool.
+      * SPLIT (a `grad_reducer` for N > 1 ranks and / or accum_steps = A > 1; BASELINE config 4 = 8 GPUs x A = 4): graph 1 =
+        forward + losses + backward + PREDICT of ONE window, accumulating into persistent gradient buffers (the reducer's
+        bucket views, so the message IS the gradient); it is replayed A times, once per window; then the bucketed all-reduce
+        (RCCL; eager, between the graphs — replays run no autograd hooks, so every bucket is launched by `reducer()` in index
+        order; 21 MB over xGMI is ~0.3 ms of a ~150 ms step, there is nothing worth overlapping) and the division by
+        A x world; graph 2 = the optimizer step.  `step_windows()` drives this form.
+    The optimizer must be built with `capturable=True`.  Inputs are copied into static buffers; the pose inverse for PREDICT
+    is computed outside the graph.  Outputs are static tensors that the next replay overwrites.
 
     Capture needs state that only an executed iteration creates: Adam's exp_avg / exp_avg_sq / step (created inside a
     capture they would become graph nodes that reset the moments at every replay), the packed-weight and interpolation
@@ -118,12 +124,19 @@ class TrainGraph:
     (checked; a RuntimeError names the parameter otherwise).
     """
 
-    def __init__(self, model, optimizer, t_win_r, d_candi, cam_intrinsics, warmup=1):
+    def __init__(self, model, optimizer, t_win_r, d_candi, cam_intrinsics, warmup=1, grad_reducer=None, accum_steps=1):
         self.model, self.opt, self.t_win_r, self.d_candi, self.cam = model, optimizer, t_win_r, d_candi, cam_intrinsics
         self._graph = None
         self._st = None
         self._warmup = max(0, int(warmup))
         self._eager_steps = 0
+        self.reducer = grad_reducer
+        self.accum = int(accum_steps)
+        if self.accum < 1:
+            raise ValueError("accum_steps must be >= 1")
+        self.split = grad_reducer is not None or self.accum > 1
+        self._g_opt = None
+        self._grads = None
 
     def _optimizer_ready(self):
         """Every trainable parameter has populated optimizer state (else capture would record its creation)."""
@@ -134,28 +147,52 @@ class TrainGraph:
                     return names.get(p, "<unnamed %s>" % (tuple(p.shape),))
         return None
 
-    def _iteration(self, st):
+    def _fwd_bwd(self, st):
+        """forward + 4 NLL terms + backward + PREDICT of one window (no optimizer step)."""
         model = self.model
         r_cur, r_kv, d_dpv, kv_dpv = model(ref_frame=st["ref"], src_frames=st["src"], src_cam_poses=st["poses"],
                                            BatchIdx=torch.zeros(1), cam_intrinsics=[self.cam], BV_predict=st["bv"],
                                            dpv_valid=True)
-        loss = F.nll_loss(d_dpv, st["dmap"], ignore_index=0) + F.nll_loss(r_cur, st["dmap_full"], ignore_index=0) \
-            + F.nll_loss(kv_dpv, st["dmap"], ignore_index=0) + F.nll_loss(r_kv, st["dmap_full"], ignore_index=0)
+        loss = _nll_terms(d_dpv, r_cur, kv_dpv, r_kv, st["dmap"], st["dmap_full"], True)
         loss.backward()
-        self.opt.step()
         with torch.no_grad():
             nxt = warp_homo.resample_vol_cuda(src_vol=kv_dpv.detach(), rel_extM=st["inv"], cam_intrinsic=self.cam,
                                               d_candi=self.d_candi, padding_value=math.log(1. / float(len(self.d_candi))),
                                               clamp=(-1000., 0.)).unsqueeze(0)
         return loss.detach(), nxt
 
-    def step(self, ref_frame, src_frames, poses, dmap, dmap_full, bv_predict):
-        inv = ops.pose_inverse(poses[0, self.t_win_r].to(dtype=torch.float32).contiguous())
-        if self._graph is None and (self._eager_steps < self._warmup or self._optimizer_ready() is not None):
+    def _iteration(self, st):
+        out = self._fwd_bwd(st)
+        self.opt.step()
+        return out
+
+    def _upload_constants(self, dev):
+        # per-trajectory constants (intrinsics, ray table, d_candi) are uploaded once and cached per dict: do it now,
+        # an upload inside the capture is not allowed
+        for cam in (self.cam, getattr(self.model.d_net, "cam_intrinsics", self.cam)):
+            warp_homo._cam_dev(cam, dev)
+        for dc in (self.d_candi, getattr(self.model.d_net, "d_candi", self.d_candi), getattr(self.model, "d_candi", self.d_candi)):
+            warp_homo._d_candi_dev(dc, dev)
+
+    def _needs_eager(self):
+        if self._graph is not None:
+            return False
+        if self._eager_steps < self._warmup or self._optimizer_ready() is not None:
             if self._eager_steps >= max(self._warmup, 2):
                 raise RuntimeError("TrainGraph: parameter %s still has no optimizer state after %d eager iterations "
                                    "(unused in the loss?): the iteration cannot be captured" %
                                    (self._optimizer_ready(), self._eager_steps))
+            return True
+        return False
+
+    def step(self, ref_frame, src_frames, poses, dmap, dmap_full, bv_predict):
+        if self.split:
+            if self.accum != 1:
+                raise ValueError("accum_steps = %d: pass the windows of a step together (step_windows)" % self.accum)
+            loss, nxt = self.step_windows([(ref_frame, src_frames, poses, dmap, dmap_full, bv_predict)])
+            return loss, nxt[0]
+        inv = ops.pose_inverse(poses[0, self.t_win_r].to(dtype=torch.float32).contiguous())
+        if self._needs_eager():
             self.opt.zero_grad(set_to_none=True)
             out = self._iteration({"ref": ref_frame, "src": src_frames, "poses": poses, "dmap": dmap,
                                    "dmap_full": dmap_full, "bv": bv_predict, "inv": inv})
@@ -164,13 +201,7 @@ class TrainGraph:
         if self._graph is None:
             st = {"ref": ref_frame.clone(), "src": src_frames.clone(), "poses": poses.clone(), "dmap": dmap.clone(),
                   "dmap_full": dmap_full.clone(), "bv": bv_predict.clone(), "inv": inv.clone()}
-            # per-trajectory constants (intrinsics, ray table, d_candi) are uploaded once and cached per dict: do it now,
-            # an upload inside the capture is not allowed
-            dev = ref_frame.device
-            for cam in (self.cam, getattr(self.model.d_net, "cam_intrinsics", self.cam)):
-                warp_homo._cam_dev(cam, dev)
-            for dc in (self.d_candi, getattr(self.model.d_net, "d_candi", self.d_candi), getattr(self.model, "d_candi", self.d_candi)):
-                warp_homo._d_candi_dev(dc, dev)
+            self._upload_constants(ref_frame.device)
             self.opt.zero_grad(set_to_none=True)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -184,3 +215,64 @@ class TrainGraph:
         st["dmap"].copy_(dmap); st["dmap_full"].copy_(dmap_full); st["bv"].copy_(bv_predict); st["inv"].copy_(inv)
         self._graph.replay()
         return st["out"]
+
+    # ------------------------------------------------------------------ split form: N > 1 ranks and / or accumulation
+    def _zero_grads(self):
+        """Gradients of the split form live OUTSIDE the graphs: graph 1 accumulates into them over its A replays, the
+        all-reduce runs on them, graph 2 reads them."""
+        if self.reducer is not None:
+            self.reducer.hold = True                  # replays run no hooks; nothing may be launched from capture-time hooks
+            self.reducer.prepare(self.accum)
+            return
+        if self._grads is None:
+            self._grads = [(p, torch.zeros_like(p)) for p in {id(q): q for q in self.model.parameters() if q.requires_grad}.values()]
+        torch._foreach_zero_([g for _, g in self._grads])
+        for p, g in self._grads:
+            p.grad = g
+
+    def _reduce_grads(self):
+        if self.reducer is not None:
+            self.reducer()                            # every bucket, in index order; / (A x world)
+        elif self.accum > 1:
+            torch._foreach_div_([g for _, g in self._grads], float(self.accum))
+
+    def step_windows(self, windows):
+        """One optimizer step over `accum_steps` windows [(ref, src, poses, dmap, dmap_full, bv_predict), ...] of this rank.
+        Returns (mean loss, [BV_predict of each window's next frame]) — clones, valid until overwritten by the caller."""
+        if len(windows) != self.accum:
+            raise ValueError("%d windows for accum_steps=%d" % (len(windows), self.accum))
+        invs = [ops.pose_inverse(w[2][0, self.t_win_r].to(dtype=torch.float32).contiguous()) for w in windows]
+        keys = ("ref", "src", "poses", "dmap", "dmap_full", "bv")
+        if self._needs_eager():
+            self._zero_grads()
+            outs = [self._fwd_bwd(dict(zip(keys, w), inv=inv)) for w, inv in zip(windows, invs)]
+            self._reduce_grads()
+            self.opt.step()
+            self._eager_steps += 1
+            return torch.stack([o[0] for o in outs]).mean(), [o[1] for o in outs]
+        if self._graph is None:
+            w0 = windows[0]
+            st = dict(zip(keys, (t.clone() for t in w0)), inv=invs[0].clone())
+            self._upload_constants(w0[0].device)
+            self._zero_grads()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["out"] = self._fwd_bwd(st)         # accumulates into the persistent gradients
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g.pool()):
+                self.opt.step()
+            st["consts"] = warp_homo.cache_snapshot()
+            self._graph, self._g_opt, self._st = g, g2, st
+        st = self._st
+        self._zero_grads()
+        losses, preds = [], []
+        for w, inv in zip(windows, invs):
+            for k, t in zip(keys, w):
+                st[k].copy_(t)
+            st["inv"].copy_(inv)
+            self._graph.replay()
+            losses.append(st["out"][0].clone()); preds.append(st["out"][1].clone())
+        self._reduce_grads()
+        self._g_opt.replay()
+        return torch.stack(losses).mean(), preds

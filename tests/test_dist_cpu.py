@@ -212,3 +212,101 @@ def test_bucket_order_is_rank_independent_when_a_rank_skips_a_subnetwork():
     assert abs(sum(a["sums"][0]) - want0) < 1e-3 * a["numel"] and a["sums"][0] == b["sums"][0]
     assert abs(sum(a["sums"][1]) - 1.5 * a["numel"]) < 1e-3 * a["numel"] and a["sums"][1] == b["sums"][1]
     assert a["w"] == b["w"]
+
+
+def test_bench_spawns_its_own_ranks_without_torchrun():
+    """`python bench.py --gpus 2 ...` started WITHOUT torchrun must run two ranks (it re-executes itself
+    under torch.distributed.run) and report n_gpus 2 with both ranks seen by a collective — never a silent single-rank run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub"],
+                         capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["collective_ranks"] == 2 and rec["steps"] == 3
+    assert rec["ms_per_step"] >= 9.0                              # MAX over ranks: the slower rank sleeps 10 ms per step
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """A torchrun environment whose WORLD_SIZE differs from --gpus is an error, in both directions."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--stub"],
+                         capture_output=True, text=True, timeout=120, cwd=root, env=env)
+    assert out.returncode != 0 and "does not match WORLD_SIZE" in out.stderr + out.stdout
+
+
+def _accum_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    nd.init_from_env("gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    params = list(model.parameters())
+    A = 4
+    xs = [torch.randn(5, 6, generator=torch.Generator().manual_seed(100 * rank + k)) for k in range(A)]
+    # four single-window gradients, summed in window order (what accumulation into one buffer does)
+    singles = []
+    for x in xs:
+        for p in params:
+            p.grad = None
+        model(x).pow(2).mean().backward()
+        singles.append([p.grad.clone() for p in params])
+    local_sum = [singles[0][i].clone() for i in range(len(params))]
+    for k in range(1, A):
+        for i in range(len(params)):
+            local_sum[i] += singles[k][i]
+    # the reducer: prepare(accum_steps=4), four backward passes, one call
+    reducer = nd.GradAllReduce(model, bucket_mb=1e-4)
+    reducer.prepare(accum_steps=A)
+    for x in xs:
+        model(x).pow(2).mean().backward()
+    early = reducer.launched_in_backward          # buckets launched from hooks: only possible in the LAST pass
+    reducer()
+    q.put((rank, {"local_sum": [g.numpy().copy() for g in local_sum], "reduced": [p.grad.numpy().copy() for p in params],
+                  "early": early, "n_buckets": len(reducer.buckets),
+                  "order": list(reducer.launch_order)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_over_4_windows_equals_the_mean_of_the_single_window_gradients():
+    """accum_steps = 4 on two ranks == (sum over ranks and windows of the single-window gradients) / 8,
+    bit for bit (sums in window order, the two ranks' sums added, one exact division by a power of two); every rank launches
+    the buckets in index order."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i in range(len(res[0]["local_sum"])):
+        want = (res[0]["local_sum"][i] + res[1]["local_sum"][i]) / 8.0
+        assert np.array_equal(res[0]["reduced"][i], want) and np.array_equal(res[1]["reduced"][i], want)
+    assert res[0]["n_buckets"] > 1 and res[0]["early"] >= 1
+    assert [b for b, _ in res[0]["order"]] == list(range(res[0]["n_buckets"])) == [b for b, _ in res[1]["order"]]
+
+
+def test_gradient_accumulation_single_rank_divides_without_a_collective():
+    torch.manual_seed(1)
+    model = torch.nn.Linear(4, 2)
+    reducer = nd.GradAllReduce(model)
+    xs = [torch.randn(3, 4) for _ in range(4)]
+    reducer.prepare(accum_steps=4)
+    for x in xs:
+        model(x).sum().backward()
+    reducer()
+    want = sum(x.sum(0) for x in xs) / 4.0
+    assert torch.allclose(model.weight.grad[0], want, rtol=1e-6, atol=1e-6)
+    with __import__("pytest").raises(ValueError):
+        reducer.prepare(accum_steps=0)

@@ -26,7 +26,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 
 constexpr int kV = 8192, kRing = 16384, kStrip = 1280;   // floats: one V buffer, the weight ring (16 points x 4 KB), one strip
 
-template <int LAYOUT, int PW, int MID>
+// VK: the producers' VALU instruction kind, same COUNT per stage (96): 0 = as compiled from the packed-fp32 source, 1 = v_xor_b32
+// (integer), 2 = v_fma_f32, 3 = v_pk_fma_f32, 4 = v_pk_mul_f32, 5 = v_max_f32 — is it issue slots or the fp32 pipe they take?
+// WSRC (layout 8): the consumers' weight lines 0 = global memory (today), 1 = none (ring filled once), 2 = an LDS ring that
+// somebody filled for free (the upper bound of any LDS staging scheme)
+template <int LAYOUT, int PW, int MID, int VK = 0, int WSRC = 0>
 __global__ __launch_bounds__(LAYOUT == 12 ? 768 : 512) void probe(const f32x4* __restrict__ w, const f32x4* __restrict__ x, float* __restrict__ out,
                                                                    int stages, long long* clk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -84,7 +88,8 @@ __global__ __launch_bounds__(LAYOUT == 12 ? 768 : 512) void probe(const f32x4* _
 #pragma unroll
                         for (int r = 0; r < RB; ++r)
                             acc[xi][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[xi & 3][r][e], Bn[xi & 7][e], acc[xi][r], 0, 0, 0);
-                        if (e == 1) Bn[(xi + 7) & 7] = wl[(size_t)((s * 16 + xi + 7) & 63) * 256];
+                        if (e == 1 && WSRC == 0) Bn[(xi + 7) & 7] = wl[(size_t)((s * 16 + xi + 7) & 63) * 256];
+                        if (e == 1 && WSRC == 2) Bn[(xi + 7) & 7] = *reinterpret_cast<const f32x4*>(b0 + ((xi + 7) & 15) * 1024);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -122,6 +127,20 @@ __global__ __launch_bounds__(LAYOUT == 12 ? 768 : 512) void probe(const f32x4* _
             if (!(PW & 1)) return;
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
+                if (VK) {
+                    f32x4 v = r[u];
+                    if (combine) v += *reinterpret_cast<const f32x4*>(strip + u * 256 + lane * 4);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (VK == 1) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(v[k & 3]) : "v"(sc.x));
+                        if (VK == 2) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[k & 3]) : "v"(sc.x), "v"(sh.x));
+                        if (VK == 3) { f32x2 t = (k & 1) ? v.hi : v.lo; asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(t) : "v"(sc), "v"(sh)); if (k & 1) v.hi = t; else v.lo = t; }
+                        if (VK == 4) { f32x2 t = (k & 1) ? v.hi : v.lo; asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(t) : "v"(sc)); if (k & 1) v.hi = t; else v.lo = t; }
+                        if (VK == 5) asm volatile("v_max_f32 %0, %1, %0" : "+v"(v[k & 3]) : "v"(sc.x));
+                    }
+                    *reinterpret_cast<f32x4*>(strip + u * 256 + lane * 4) = v;
+                    continue;
+                }
                 f32x2 lo = __builtin_elementwise_fma(r[u].lo, sc, sh), hi = __builtin_elementwise_fma(r[u].hi, sc, sh);
                 lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f);
                 lo = lo * sc; hi = hi * sc;
@@ -243,6 +262,17 @@ int main() {
     run(&probe<8, 0, 0>, 512, "8 waves (today): consumers alone");
     run(&probe<8, 1, 0>, 512, "8 waves (today): + producer VALU/LDS");
     run(&probe<8, 3, 0>, 512, "8 waves (today): + producer VALU/LDS + refills");
+    run(&probe<8, 3, 0, 0, 1>, 512, "8 waves: full producers, consumers WITHOUT weight loads");
+    run(&probe<8, 3, 0, 0, 2>, 512, "8 waves: full producers, weight lines from a free LDS ring");
+    run(&probe<8, 0, 0, 0, 2>, 512, "8 waves: consumers alone, weight lines from a free LDS ring");
+    run(&probe<8, 1, 0, 1>, 512, "8 waves: + producer VALU as 96 v_xor_b32 / stage");
+    run(&probe<8, 1, 0, 2>, 512, "8 waves: + producer VALU as 96 v_fma_f32 / stage");
+    run(&probe<8, 1, 0, 3>, 512, "8 waves: + producer VALU as 96 v_pk_fma_f32 / stage");
+    run(&probe<8, 1, 0, 4>, 512, "8 waves: + producer VALU as 96 v_pk_mul_f32 / stage");
+    run(&probe<8, 1, 0, 5>, 512, "8 waves: + producer VALU as 96 v_max_f32 / stage");
+    run(&probe<12, 1, 0, 1>, 768, "12 waves: + producer VALU as 96 v_xor_b32 / stage");
+    run(&probe<12, 1, 0, 2>, 768, "12 waves: + producer VALU as 96 v_fma_f32 / stage");
+    run(&probe<12, 1, 0, 3>, 768, "12 waves: + producer VALU as 96 v_pk_fma_f32 / stage");
     run(&probe<12, 0, 0>, 768, "12 waves: consumers alone, one barrier per stage");
     run(&probe<12, 0, 1>, 768, "12 waves: consumers alone, two barriers per stage");
     run(&probe<12, 1, 0>, 768, "12 waves: + producer VALU/LDS, one barrier");
