@@ -100,6 +100,55 @@ def rendered_window(seed, H, W, cam_full, V=4, d_lo=0.6, d_hi=4.0):
     return ref, src, torch.from_numpy(poses[None]), depth
 
 
+def _render_view(tex_t, depth_t, K, Kinv, T, H, W, d_lo, d_hi):
+    """The scene (texture + depth map in the scene view) seen from the camera X_view = T X_scene: forward projection of a dense
+    pixel grid of the new view through the scene depth (fixed point on the new view's depth), as rendered_window does."""
+    ys, xs = np.meshgrid(np.arange(H) + 0.5, np.arange(W) + 0.5, indexing="ij")
+    pix = np.stack([xs, ys, np.ones_like(xs)], 0).reshape(3, -1)
+    Tinv = np.linalg.inv(T.astype(np.float64))
+    rays_s = Kinv @ pix
+    ds = np.full(pix.shape[1], 0.5 * (d_lo + d_hi))
+    g = None
+    for _ in range(8):
+        Xs = rays_s * ds
+        Xr = Tinv[:3, :3] @ Xs + Tinv[:3, 3:4]
+        ur = K @ (Xr / Xr[2:3])
+        g = np.stack([ur[0] / (W / 2.0) - 1.0, ur[1] / (H / 2.0) - 1.0], -1).reshape(1, H, W, 2)
+        zr = torch.nn.functional.grid_sample(depth_t.double(), torch.from_numpy(g), mode="bilinear",
+                                             padding_mode="border", align_corners=False)[0, 0].numpy().reshape(-1)
+        ds = ds * (zr / np.maximum(Xr[2], 1e-6))
+    img = torch.nn.functional.grid_sample(tex_t.double(), torch.from_numpy(g), mode="bilinear", padding_mode="border",
+                                          align_corners=False)[0]
+    return img.float()
+
+
+def rendered_stream(seed, H, W, cam_full, n_frames=2, V=4, d_lo=0.6, d_hi=4.0):
+    """A short VIDEO of one textured scene: n_frames consecutive windows (ref, src, poses) whose images are all renderings of
+    the same scene, with the reference camera moving the way the reference's driver loop assumes — the next reference frame
+    is this window's source t_win_r = 2 (test_KVNet.py:47-62 predicts the DPV into src_cam_poses[:, t_win_r]).  The cost
+    volume then has a true minimum, the DPV is peaked (log-probabilities of -50 and below away from the surface), and the
+    PREDICT step carries a consistent belief into the next frame: the regime the filter runs in, unlike N(0,1) windows.
+    Returns [(ref [1,3,H,W], src [1,V,3,H,W], poses [1,V,4,4]), ...]."""
+    rng = np.random.RandomState(seed)
+    tex = smooth_texture(rng, 3, H, W)
+    z = smooth_texture(rng, 1, H, W, octaves=2)[0]
+    z = (z - z.min()) / (z.max() - z.min() + 1e-12)
+    depth = (d_lo + (d_hi - d_lo) * z).astype(np.float32)
+    K = cam_full["intrinsic_M"][:3, :3]
+    Kinv = np.linalg.inv(K)
+    tex_t, depth_t = torch.from_numpy(tex)[None], torch.from_numpy(depth)[None, None]
+    A = np.eye(4)                                   # scene -> current reference camera
+    ref = tex_t.clone()
+    out = []
+    for _ in range(n_frames):
+        rel = random_poses(rng, V)                  # reference -> source v
+        views = [_render_view(tex_t, depth_t, K, Kinv, rel[v].astype(np.float64) @ A, H, W, d_lo, d_hi) for v in range(V)]
+        out.append((ref.float().clone(), torch.stack(views)[None], torch.from_numpy(rel[None])))
+        A = rel[2].astype(np.float64) @ A           # the next reference camera = this window's source 2
+        ref = views[2][None]
+    return out
+
+
 def seeded_state_dict(model, seed=0):
     """Deterministic, name-keyed weights for any module with the KVNET parameter names.
 

@@ -21,6 +21,8 @@ CPU under the installed torch.  Outputs (small, committed):
                    |reference - fp64| of the reference's own fp32 outputs: the yardstick for "DPV within 1e-4"
 
   net_fp64_S.npz   config S (256x384, D=64), two frames, in float64 at every 4th pixel + the CPU oracle's distance from it
+  scene_stream_S.npz  two frames of a RENDERED video at config S through the reference (update branch, peaked DPV)
+  net_fp64_B.npz   config B (grid 192x256), first + update frame in float64 at every 8th pixel + the CPU oracle's distance
   lba_small.npz    back_warp_th_Rt_msrc (LBA photometric warp through a depth map): warped images and torch autograd's
                    gradients w.r.t. (R, t), for a generic upstream gradient and for the masked L1 loss of opt_pose_numerical.py
   export_small.npz export_res_img run through the reference's own function; its two .pgm files read back
@@ -338,6 +340,74 @@ def gen_fp64_S(ref):
     np.savez(os.path.join(OUT, "net_fp64_S.npz"), **out)
 
 
+SCENE_S = dict(H=256, W=384, D=64, seed=21, sigma=10.0, d_min=0.1, d_max=5.0, weight_seed=0)      # config S, rendered video
+FP64_B = dict(H=768, W=1024, D=64, seeds=(131, 132), sigma=10.0, d_min=0.1, d_max=5.0, weight_seed=0, sub=8)   # = config B test / bench
+
+
+def gen_scene_stream(ref):
+    """two consecutive frames of a RENDERED scene (synth.rendered_stream: one textured depth map, the
+    camera moving into its own source view) at config S through the UNMODIFIED reference — the update branch in the regime
+    the filter runs in (peaked DPV, a consistent predicted belief).  Stored: BV_cur / DPV / BV_predict at every 2nd pixel, the
+    full arg-max maps, and the peak statistics that show the regime."""
+    n = SCENE_S
+    H, W, D = n["H"], n["W"], n["D"]
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(n["d_min"], n["d_max"], D)
+    with ref_shim.quiet():
+        model = ref.KVNET.KVNET(64, cam, d_candi, n["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    sd = synth.seeded_state_dict(model, n["weight_seed"])
+    model.load_state_dict(sd)
+    windows = synth.rendered_stream(n["seed"], H, W, camera.scannet_intrinsics(W, H), 2)
+    (dpv1, pred1, ref1), (dpv2, pred2, ref2) = run_stream(ref, model, cam, d_candi, windows)
+    np.savez_compressed(os.path.join(OUT, "scene_stream_S.npz"),
+                        bv_cur_f1_sub=dpv1[0, :, ::2, ::2].numpy(), pred_f1_sub=pred1[0, :, ::2, ::2].numpy(),
+                        dpv_f2_sub=dpv2[0, :, ::2, ::2].numpy(), pred_f2_sub=pred2[0, :, ::2, ::2].numpy(),
+                        bv_cur_f1_argmax=dpv1[0].argmax(0).numpy().astype(np.uint8), dpv_f2_argmax=dpv2[0].argmax(0).numpy().astype(np.uint8),
+                        refined_f2_argmax=ref2[0].argmax(0).numpy().astype(np.uint8),
+                        bv_cur_f1_sum=dpv1.double().sum().numpy(), dpv_f2_sum=dpv2.double().sum().numpy(), pred_f2_sum=pred2.double().sum().numpy(),
+                        inputs_checksum=checksum([w[0] for w in windows] + [w[1] for w in windows] + [w[2] for w in windows]))
+    top2 = dpv2[0].topk(2, dim=0).values
+    print("scene_stream_S: DPV f2 min %.1f, median peak %.3f, median gap to the runner-up %.3f, pixels whose peak holds > 0.5 of the mass: %.1f %%"
+          % (float(dpv2.min()), float(top2[0].median()), float((top2[0] - top2[1]).median()), 100.0 * float((top2[0] > math.log(0.5)).float().mean())))
+
+
+def gen_fp64_B(ref):
+    """Config B (768x1024 image, grid 192x256, D=64), first frame + update frame on the windows of the config-B parity test
+    and of bench.py's parity block, in float64 at every 8th grid pixel, with the distance of the fp32 CPU oracle from it:
+    the yardstick the bench line reports (|GPU - fp64| beside |oracle - fp64|).  ~10 GB of RAM, several minutes."""
+    from oracle import fp64_ref, kvnet_oracle as ko
+    n = FP64_B
+    H, W, D, sub = n["H"], n["W"], n["D"], n["sub"]
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(n["d_min"], n["d_max"], D)
+    with ref_shim.quiet():
+        model = ref.KVNET.KVNET(64, cam, d_candi, n["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    sd = synth.seeded_state_dict(model, n["weight_seed"])
+    del model
+    w1, w2 = (synth.noise_window(s, H, W) for s in n["seeds"])
+    out = {}
+    c1 = ko.step(sd, *w1, cam, d_candi, n["sigma"], None)
+    c2 = ko.step(sd, *w2, cam, d_candi, n["sigma"], c1[3])
+    c = {"bv_cur_f1": c1[2][0].numpy(), "bv_cur_f2": c2[2][0].numpy(), "dpv_f2": c2[1][0].numpy(), "pred_f2": c2[3][0].numpy()}
+    del c1, c2
+    o1 = fp64_ref.step(sd, *w1, cam, d_candi, n["sigma"], None)
+    o = {"bv_cur_f1": o1[2][0].numpy()}
+    o2 = fp64_ref.step(sd, *w2, cam, d_candi, n["sigma"], o1[3])
+    o.update({"bv_cur_f2": o2[2][0].numpy(), "dpv_f2": o2[1][0].numpy(), "pred_f2": o2[3][0].numpy()})
+    del o1, o2
+    for key in c:
+        e = np.abs(c[key].astype(np.float64) - o[key])
+        out[key] = o[key][:, ::sub, ::sub]
+        out["oracle_err_max_" + key] = e.max()
+        out["oracle_err_mean_" + key] = e.mean()
+        out["oracle_err_max_sub_" + key] = e[:, ::sub, ::sub].max()
+        out["oracle_err_mean_sub_" + key] = e[:, ::sub, ::sub].mean()
+        out["oracle_argmax_flips_" + key] = int((c[key].argmax(0) != o[key].argmax(0)).sum())
+        print("fp64 B: %-10s |oracle - fp64| max %.3e mean %.3e, arg-max flips of the fp32 oracle vs fp64: %d" %
+              (key, e.max(), e.mean(), out["oracle_argmax_flips_" + key]))
+    np.savez_compressed(os.path.join(OUT, "net_fp64_B.npz"), **out)
+
+
 def gen_pose_inv(ref):
     """What the reference's PREDICT step feeds to resample_vol_cuda for the NET windows: `Src_CamPoses[0, t_win_r].inverse()`
     (test_utils/test_KVNet.py:50) as torch's host LAPACK computes it HERE.  Its operation order is the library's (MKL), so
@@ -359,7 +429,8 @@ def main():
     torch.manual_seed(0)
     which = sys.argv[1:] or ["ops", "net", "scene", "ops67", "fp64", "fp64S", "lba", "export", "train", "pose_inv"]
     for name in which:
-        {"ops": gen_ops, "net": gen_net, "scene": gen_scene, "ops67": gen_ops67, "fp64": gen_fp64, "fp64S": gen_fp64_S, "lba": gen_lba, "export": gen_export, "train": gen_train, "pose_inv": gen_pose_inv}[name](ref)
+        {"ops": gen_ops, "net": gen_net, "scene": gen_scene, "ops67": gen_ops67, "fp64": gen_fp64, "fp64S": gen_fp64_S, "lba": gen_lba, "export": gen_export, "train": gen_train, "pose_inv": gen_pose_inv,
+         "scene_stream": gen_scene_stream, "fp64B": gen_fp64_B}[name](ref)
 
 
 if __name__ == "__main__":

@@ -186,3 +186,48 @@ def test_fp64_yardstick(golden_net):
         print("[parity] %-10s |GPU - fp64| max %.2e mean %.2e   |reference - fp64| max %.2e mean %.2e   (all pixels: ref max %.2e)" %
               (key, e.max(), e.mean(), er.max(), er.mean(), float(g64["ref_err_max_" + key])))
         assert e.mean() <= 1.25 * er.mean() + 1e-6 and e.max() <= 2.0 * float(g64["ref_err_max_" + key])
+
+
+def test_rendered_video_config_S_vs_reference_golden():
+    """the update branch on a RENDERED video (one textured scene, the camera moving into its own source
+    view: a true cost minimum, DPV log-probabilities down to -280, a consistent predicted belief) at config S against the
+    UNMODIFIED reference's outputs (tests/golden/scene_stream_S.npz).  Gates as everywhere: L1 < 1e-4, arg-max identical up to
+    oracle-side ties."""
+    n = gen_golden.SCENE_S
+    g = dict(np.load(os.path.join(GOLDEN, "scene_stream_S.npz")))
+    H, W, D = n["H"], n["W"], n["D"]
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(n["d_min"], n["d_max"], D)
+    model, _ = _model(cam, d_candi, n["sigma"], n["weight_seed"])
+    windows = synth.rendered_stream(n["seed"], H, W, camera.scannet_intrinsics(W, H), 2)
+    (bv1, _, p1), (_, dpv2, p2) = _gpu_two_frames(model, cam, d_candi, windows)
+    for name, got, key in (("BV_cur f1", bv1, "bv_cur_f1"), ("DPV f2", dpv2, "dpv_f2"), ("BV_predict f2", p2, "pred_f2")):
+        a = got[0].cpu().numpy()
+        mx, mean, _ = report("rendered video S " + name + " vs reference", a[:, ::2, ::2], g[key + "_sub"])
+        assert mean < L1_TOL, (name, mean)
+        assert abs(float(a.astype(np.float64).sum()) - float(g[key + "_sum"])) < 2e-5 * abs(float(g[key + "_sum"]))   # all pixels
+    assert float(dpv2.min()) < -100.0                         # the peaked regime, not the noise windows' (-20)
+    for name, got, key in (("BV_cur f1", bv1, "bv_cur_f1_argmax"), ("DPV f2", dpv2, "dpv_f2_argmax")):
+        flips = int((got[0].argmax(0).cpu().numpy() != g[key]).sum())
+        print("[parity] rendered video S %s: arg-max flips vs the reference %d / %d" % (name, flips, g[key].size))
+        assert flips <= MAX_TIE_FLIPS
+
+
+def test_rendered_video_config_B_vs_oracle():
+    """The same rendered video at the headline grid (image 768x1024, grid 192x256, D=64) against the CPU oracle run here:
+    update branch, peaked DPV (two oracle frames: ~40 s of host time)."""
+    H, W, D = 768, 1024, 64
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(0.1, 5.0, D)
+    model, sd = _model(cam, d_candi, 10.0)
+    windows = synth.rendered_stream(23, H, W, camera.scannet_intrinsics(W, H), 2)
+    (bv1, _, p1), (bv2, dpv2, p2) = _gpu_two_frames(model, cam, d_candi, windows)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    o1 = ko.step(sd, *windows[0], cam, d_candi, 10.0, None)
+    o2 = ko.step(sd, *windows[1], cam, d_candi, 10.0, o1[3])
+    m_bv1 = _check("rendered video B BV_cur f1", bv1, o1[2])
+    _check("rendered video B BV_predict f1", p1, o1[3], argmax=False, max_abs=m_bv1 + 2e-4)
+    _check("rendered video B BV_cur f2", bv2, o2[2])
+    m_dpv = _check("rendered video B DPV f2", dpv2, o2[1])
+    _check("rendered video B BV_predict f2", p2, o2[3], argmax=False, max_abs=m_dpv + 2e-4)
+    assert float(o2[1].min()) < -100.0

@@ -486,10 +486,15 @@ def test_train_accumulates_four_windows_into_one_optimizer_step():
     worst = max(float((a - b).abs().max()) for a, b in zip(got, want))
     print("[parity] accumulate-4 vs mean of 4 single-window gradients: max|d| = %.3e, identical tensors %d / %d" %
           (worst, sum(int(torch.equal(a, b)) for a, b in zip(got, want)), len(got)))
-    # same kernels, same accumulation order, an exact division: equal up to the run-to-run rounding of the cost-volume
-    # backward's LDS float atomics (ds_add_f32 order inside a workgroup is not fixed)
+    # Same kernels, same accumulation order, an exact division — but a single-window gradient is itself only reproducible to
+    # ~1e-3 of its largest entry from run to run (tools/r4_accum_diag.py: the cost-volume backward's LDS float atomics land in
+    # a different order, and the first layers' weight gradients are sums of ~1e5 O(1) terms that cancel to O(1): 4.8e-6 in
+    # one process, 3.7e-3 in the next, same window twice).  The bit-for-bit statement is tests/test_dist_cpu.py's (gloo);
+    # here: the mean of the four, not any one of them (a single window's gradient differs from the mean by ~60 %).
     scale = max(float(b.abs().max()) for b in want)
-    assert worst <= 2e-5 * scale, (worst, scale)
+    assert worst <= 1e-2 * scale, (worst, scale)
+    one = [t_ / 1.0 for t_ in total]                     # 4x the mean: what a missing division would hand the optimizer
+    assert max(float((a - b).abs().max()) for a, b in zip(got, one)) > 0.5 * scale
     # (3) the same through the bucketed reducer (one rank: no collective, the division still happens)
     model2 = copy.deepcopy(twin)
     red = nd.GradAllReduce(model2)
@@ -497,7 +502,7 @@ def test_train_accumulates_four_windows_into_one_optimizer_step():
           torch.cat([b[2] for b in batch], 0), preds, [cam], grad_reducer=red, accum_steps=A)
     want_by_name = dict(zip([n for n, _ in twin.named_parameters()], want))
     for n, q in model2.named_parameters():
-        assert float((q.grad - want_by_name[n]).abs().max()) <= 2e-5 * scale, n
+        assert float((q.grad - want_by_name[n]).abs().max()) <= 1e-2 * scale, n
 
 
 def test_split_train_graph_with_accumulation_equals_eager_accumulation():

@@ -271,3 +271,33 @@ def test_training_oracle_vs_reference_train_golden():
                 continue
             rel = np.abs(delta - ref_d).max() / np.abs(ref_d).max()
             assert rel < (2e-2 if it == 0 else 5e-2), (k, rel)
+
+
+def test_rendered_video_two_frames_vs_reference_golden():
+    """The CPU oracle on two consecutive frames of a RENDERED scene at config S (update branch on a peaked DPV with a
+    consistent predicted belief — the regime the filter runs in) against the unmodified reference's outputs
+    (tests/golden/scene_stream_S.npz, oracle/gen_golden.py::gen_scene_stream)."""
+    import os
+    from conftest import GOLDEN
+    n = gen_golden.SCENE_S
+    g = dict(np.load(os.path.join(GOLDEN, "scene_stream_S.npz")))
+    H, W, D = n["H"], n["W"], n["D"]
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(n["d_min"], n["d_max"], D)
+    import neuralrgbd_amd
+    model = neuralrgbd_amd.KVNET(64, cam, d_candi, n["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    sd = synth.seeded_state_dict(model, n["weight_seed"])
+    windows = synth.rendered_stream(n["seed"], H, W, camera.scannet_intrinsics(W, H), 2)
+    assert abs(gen_golden.checksum([w[0] for w in windows] + [w[1] for w in windows] + [w[2] for w in windows])
+               - float(g["inputs_checksum"])) < 1e-6 * abs(float(g["inputs_checksum"]))
+    o1 = ko.step(sd, *windows[0], cam, d_candi, n["sigma"], None)
+    o2 = ko.step(sd, *windows[1], cam, d_candi, n["sigma"], o1[3])
+    for name, got, key in (("BV_cur f1", o1[2], "bv_cur_f1"), ("DPV f2", o2[1], "dpv_f2"), ("BV_predict f2", o2[3], "pred_f2")):
+        mx, mean, _ = report("oracle rendered video " + name, got[0, :, ::2, ::2].numpy(), g[key + "_sub"])
+        assert mean < 1e-4, (name, mean)
+    # the regime: log-probabilities far below the noise windows' (-20), most pixels with one dominant candidate
+    assert float(o2[1].min()) < -100.0
+    for name, got, key in (("BV_cur f1", o1[2], "bv_cur_f1_argmax"), ("DPV f2", o2[1], "dpv_f2_argmax")):
+        flips = int((got[0].argmax(0).numpy() != g[key]).sum())
+        print("[parity] oracle rendered video %s: arg-max flips vs the reference %d / %d" % (name, flips, g[key].size))
+        assert flips <= 2          # the oracle's C sampler and ATen's grid_sample associate differently: ties only
