@@ -84,12 +84,17 @@ def pmc_traffic(cfg):
     return rec.get("traffic_bytes"), "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch on this bench's windows (tools/pmc_traffic.sh -> profiles/%s, kernel sources %s)" % (os.path.basename(TRAFFIC_FILE), doc.get("kernel_source_sha16"))
 
 
+SQ_PASS = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+           "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")      # 7 SQ slots (of 8) + 1 GRBM slot: one pass
+
+
 def live_pmc_traffic(cfg, timeout_s=240):
-    """HBM-side bytes per launch of the fused sampling kernel, MEASURED IN THIS RUN: this script is re-run as a child under
-    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domain beside them: MI355X_MICROARCH.md,
-    HBM section) with eager launches on the same windows (3 frames), and the per-dispatch counters of the sampling kernel are
-    averaged; FETCH_SIZE is doubled as the guide prescribes for gfx950.  Returns (bytes | None, note): None when rocprofv3 is
-    not there / fails / times out — the caller then falls back to the committed measurement (pmc_traffic)."""
+    """Counters of the fused sampling kernel MEASURED IN THIS RUN: this script is re-run as a child under rocprofv3 --pmc —
+    FETCH_SIZE, WRITE_SIZE and the SQ set above in three separate passes, no trace domain beside them (MI355X_MICROARCH.md,
+    HBM / PMC sections) — with eager launches on the same windows (3 frames); the per-dispatch counters of the sampling kernel
+    are averaged, FETCH_SIZE is doubled as the guide prescribes for gfx950.
+    Returns (HBM-side bytes per launch | None, note, sq | None): sq = per-launch means of SQ_PASS.  None when rocprofv3 is not
+    there / fails / times out — the caller then falls back to the committed measurement (pmc_traffic)."""
     import csv
     import glob
     import shutil
@@ -97,37 +102,62 @@ def live_pmc_traffic(cfg, timeout_s=240):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", None
     if "HSA_TOOLS_LIB" in os.environ or any(k.startswith(("ROCP_", "ROCPROFILER_")) for k in os.environ):
-        return None, "this process is itself running under a profiler"     # no nested rocprofv3
+        return None, "this process is itself running under a profiler", None     # no nested rocprofv3
     vals = {}
     root = tempfile.mkdtemp(prefix="nrgbd_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(root, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+        for tag, counters in (("FETCH_SIZE", ("FETCH_SIZE",)), ("WRITE_SIZE", ("WRITE_SIZE",)), ("SQ", SQ_PASS)):
+            out = os.path.join(root, tag)
+            cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__), "--config", cfg, "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline",
                    "--no-live-traffic"]
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
             except (OSError, subprocess.SubprocessError) as e:
-                return None, "rocprofv3 --pmc %s failed (%s)" % (counter, type(e).__name__)
-            got = []
+                if tag == "SQ":
+                    break                       # the traffic stands without the SQ pass
+                return None, "rocprofv3 --pmc %s failed (%s)" % (tag, type(e).__name__), None
+            got = {c: [] for c in counters}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if "costvol_quad" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                            got.append(float(row["Counter_Value"]))
-            if not got:
-                return None, "no %s rows for the sampling kernel in the rocprofv3 output" % counter
-            vals[counter] = (sum(got) / len(got), len(got))
+                        if "costvol_quad" in row["Kernel_Name"] and row["Counter_Name"] in got:
+                            got[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            if tag != "SQ" and not got[tag]:
+                return None, "no %s rows for the sampling kernel in the rocprofv3 output" % tag, None
+            for c in counters:
+                if got[c]:
+                    vals[c] = (sum(got[c]) / len(got[c]), len(got[c]))
     finally:
         shutil.rmtree(root, ignore_errors=True)
     f, w = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+    sq = {c: vals[c][0] for c in SQ_PASS if c in vals} or None
     return int(2 * f[0] * 1024 + w[0] * 1024), ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in two child passes of this "
                                                 "script (eager launches, same windows), mean over %d / %d dispatches of the sampling kernel; "
-                                                "FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB" % (f[1], w[1], f[0], w[0]))
+                                                "FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB" % (f[1], w[1], f[0], w[0])), sq
+
+
+def sq_fractions(sq, n_cu=256):
+    """VALU / LDS utilisation of a kernel from its SQ counters (MI355X_MICROARCH.md, PMC and cycle-constant sections):
+    GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles -> kernel cycles = / 8; SQ_ACTIVE_INST_VALU counts quad-cycles (x4) of VALU
+    issue summed over all SIMDs (4 per CU); SQ_LDS_IDX_ACTIVE counts LDS-array cycles summed over the CUs."""
+    if not sq or not sq.get("GRBM_GUI_ACTIVE"):
+        return {}
+    cyc = sq["GRBM_GUI_ACTIVE"] / 8.0
+    out = {"kernel_cycles": cyc}
+    if "SQ_ACTIVE_INST_VALU" in sq:
+        out["valu_frac"] = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (cyc * 4 * n_cu)
+    if "SQ_LDS_IDX_ACTIVE" in sq:
+        out["lds_frac"] = sq["SQ_LDS_IDX_ACTIVE"] / (cyc * n_cu)
+        if "SQ_LDS_BANK_CONFLICT" in sq:
+            out["lds_bank_conflict_frac"] = sq["SQ_LDS_BANK_CONFLICT"] / max(sq["SQ_LDS_IDX_ACTIVE"], 1.0)
+    if "SQ_WAVE_CYCLES" in sq and "SQ_WAIT_ANY" in sq:
+        out["waves_waiting_frac"] = sq["SQ_WAIT_ANY"] / max(sq["SQ_WAVE_CYCLES"], 1.0)
+        out["mean_waves_per_simd"] = 4.0 * sq["SQ_WAVE_CYCLES"] / (cyc * 4 * n_cu)
+    return out
 
 
 def costvol_bytes(V, C, D, h, w):
@@ -263,6 +293,59 @@ def respawn_under_torchrun(gpus):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush(); sys.stderr.flush()
     os.execv(sys.executable, cmd)
+
+
+FP64_FIXTURES = {   # config -> (file under tests/golden, window seeds, pixel stride of the stored float64 volumes)
+    "S": ("net_fp64_S.npz", (101, 102), 4),     # oracle/gen_golden.py::gen_fp64_S
+    "B": ("net_fp64_B.npz", (131, 132), 8),     # oracle/gen_golden.py::gen_fp64_B
+}
+TOLERANCE_POLICY = (
+    "north_star: arg-max depth index bit-exact, DPV floats within 1e-4.  Asserted here (pass): mean |d| (L1) < 1e-4 on every volume; "
+    "arg-max identical except at pixels whose two best candidates are within 1e-3 in the ORACLE's own volume (ties: <= 8 per frame and "
+    "volume, none beyond a tie); max|d| is REPORTED, not gated at 1e-4 — a builder-authored relaxation: the reference's own fp32 CPU "
+    "evaluation is 1e-3-class (max) away from the same graph in float64 (the `fp64` sub-block: |oracle - fp64| beside |GPU - fp64|), so "
+    "two fp32 evaluations of a 70-layer network cannot agree to 1e-4 max or on exact ties.  pass_strict = the gates as north_star words them.")
+
+
+def fp64_block(cfg, model, cam, d_candi, H, W, dev):
+    """|GPU - float64| beside |fp32 CPU oracle - float64| for a FIXED first-frame + update-frame sequence (the windows of the
+    config's parity test): the float64 evaluation of the same graph was generated once (oracle/fp64_ref.py via gen_golden.py) and
+    is stored sub-sampled under tests/golden/ together with the oracle's measured distance from it."""
+    import math
+    from neuralrgbd_amd import homography as warp_homo, ops, synth
+    if cfg not in FP64_FIXTURES:
+        return None
+    name, seeds, sub = FP64_FIXTURES[cfg]
+    path = os.path.join(ROOT, "tests", "golden", name)
+    if not os.path.isfile(path):
+        return None
+    g = dict(np.load(path))
+    pred, outs = None, {}
+    pad = math.log(1. / float(len(d_candi)))
+    for fi, seed in enumerate(seeds):
+        r, s_, p = (t.to(dev) for t in synth.noise_window(seed, H, W))
+        with torch.no_grad():
+            _, _, bv_cur, dpv = model(r, s_, p, torch.zeros(1), cam_intrinsics=[cam], BV_predict=pred)
+            pred = warp_homo.resample_vol_cuda(dpv, ops.pose_inverse(p[0, 2].contiguous()), cam_intrinsic=cam, d_candi=d_candi,
+                                               padding_value=pad, clamp=(-1000., 0.)).unsqueeze(0)
+        outs["bv_cur_f%d" % (fi + 1)] = bv_cur
+        if fi == 1:
+            outs["dpv_f2"], outs["pred_f2"] = dpv, pred
+    blk = {"fixture": "tests/golden/" + name, "windows": "noise windows, seeds %s: first frame + update frame" % (seeds,),
+           "pixels": "every %dth grid pixel in both directions" % sub}
+    for key in ("bv_cur_f1", "bv_cur_f2", "dpv_f2", "pred_f2"):
+        if key not in g:
+            continue
+        a = outs[key][0, :, ::sub, ::sub].double().cpu().numpy()
+        e = np.abs(a - g[key])
+        rec = {"gpu_minus_fp64_mean": float(e.mean()), "gpu_minus_fp64_max": float(e.max()),
+               "gpu_argmax_flips_vs_fp64": int((a.argmax(0) != g[key].argmax(0)).sum()), "pixels": int(a[0].size)}
+        for src_k, dst_k in (("oracle_err_mean_sub_" + key, "oracle_minus_fp64_mean"), ("oracle_err_max_sub_" + key, "oracle_minus_fp64_max"),
+                             ("oracle_err_max_" + key, "oracle_minus_fp64_max_all_pixels"), ("oracle_argmax_flips_" + key, "oracle_argmax_flips_vs_fp64_all_pixels")):
+            if src_k in g:
+                rec[dst_k] = float(g[src_k])
+        blk[key] = rec
+    return blk
 
 
 def init_world(gpus, backend):
@@ -510,9 +593,9 @@ def main():
         c_ms = knet_timer.measure(20, warm=30) if knet_timer.last is not None else None
         algo = costvol_bytes(V, 67, D, h, w)
         achieved = algo / (k_ms * 1e-3) / 1e9
-        traffic, traffic_note = (None, "")
+        traffic, traffic_note, sq = (None, "", None)
         if world == 1 and not args.no_live_traffic and not args.no_graph and S == 1:
-            traffic, traffic_note = live_pmc_traffic(args.config)      # measured now, by two rocprofv3 --pmc child passes
+            traffic, traffic_note, sq = live_pmc_traffic(args.config)      # measured now, by three rocprofv3 --pmc child passes
         if traffic is None:
             t2, n2 = pmc_traffic(args.config)                          # the committed measurement (refused if the kernel changed)
             traffic, traffic_note = t2, (n2 if not traffic_note else "%s; live measurement unavailable: %s" % (n2, traffic_note))
@@ -531,6 +614,11 @@ def main():
                          "timing": "HIP events around back-to-back launches of the frame's own costvol call (log-softmax launch included), after 20 untimed ones, right after the timed region",
                          "traffic": traffic, "traffic_source": traffic_note},
         }
+        if sq:
+            # the HBM target is structurally out of reach for this kernel (118 flop/B against a machine balance of 20, SURVEY.md
+            # 8d): what binds it is VALU issue and the LDS gather — their utilisation from the kernel's own SQ counters
+            line["roofline"].update(sq_fractions(sq))
+            line["roofline"]["sq_counters_per_launch"] = sq
         if c_ms is not None:   # secondary roofline: the matrix-core kernel that takes most of the frame
             # F(2x2,3x3) in the plane and F(2,3) along depth: 64 multiplies per 2x2x2 outputs and (ci, co) instead of 216 -> the
             # MFMAs the kernel actually issues; the 27-tap figure is what a direct convolution would need for the same layer
@@ -557,6 +645,10 @@ def main():
             torch.cuda.synchronize()
             line["cpu_baseline"], o = cpu_baseline(args.config, cam, d_candi, sd, ring[0], pred, sigma)
             line["parity"] = parity_block(args.config, (r_kv, dpv, bv_cur, nxt), o)
+            line["parity"]["tolerance_policy"] = TOLERANCE_POLICY
+            f64 = fp64_block(args.config, model, cam, d_candi, H, W, dev)
+            if f64 is not None:
+                line["parity"]["fp64"] = f64
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

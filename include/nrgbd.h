@@ -520,6 +520,16 @@ int nrgbd_spp_concat(const float* quarter, int Cq, const float* deep, int Cd,
                      const float* bz0, const float* bss0, int bh0, int bw0, const float* bz1, const float* bss1, int bh1, int bw1,
                      const float* bz2, const float* bss2, int bh2, int bw2, const float* bz3, const float* bss3, int bh3, int bw3,
                      int Cb, float* out, int N, int h, int w, void* stream);
+/*
+ * nrgbd_upsample_bilinear_ac — bilinear up-sampling with align_corners = True of a channels-last map and its exact adjoint
+ * (training path of the SPP branches).
+ * Replaces: F.upsample(mode='bilinear') of models/psm_submodule.py:153-158 and its autograd backward (ATen
+ * upsample_bilinear2d_backward: an atomic scatter).  backward = 0: x [N][bh][bw][C] -> y [N][H][W][C];
+ * backward = 1: x = gradient of the output [N][H][W][C] -> y = gradient of the input [N][bh][bw][C], every input element summed
+ * by one thread in a fixed order with the forward's own fp32 weights.  C % 4 == 0.
+ */
+int nrgbd_upsample_bilinear_ac(const float* x, float* y, int N, int bh, int bw, int H, int W, int C, int backward,
+                               void* stream);
 int nrgbd_nhwc_stats_workgroups(long P);
 int nrgbd_nhwc_stats(const float* x, long P, int C, float* stats, void* stream);
 int nrgbd_nhwc_act(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,

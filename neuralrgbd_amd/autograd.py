@@ -163,6 +163,22 @@ def batch_norm_act_cl(x_cl, bn, relu, residual=None):
     return y if residual is None else y + residual
 
 
+class UpsampleBilinearCL(torch.autograd.Function):
+    """F.upsample(bilinear, align_corners=True) of the tiny SPP maps (models/psm_submodule.py:153-158) under autograd, both
+    directions on csrc/spp.hip.  x is an NCHW tensor (channels_last memory: the NHWC view is free); so is the result."""
+
+    @staticmethod
+    def forward(ctx, x, H, W):
+        x_cl = x.permute(0, 2, 3, 1).contiguous()
+        ctx.in_size = (x.shape[2], x.shape[3])
+        return ops.upsample_bilinear_ac(x_cl, H, W).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy_cl = gy.permute(0, 2, 3, 1).contiguous()
+        return ops.upsample_bilinear_ac(gy_cl, ctx.in_size[0], ctx.in_size[1], backward=True).permute(0, 3, 1, 2), None, None
+
+
 class Conv2dCL(torch.autograd.Function):
     """3x3 convolution (stride 1, padding = dilation, no bias) of the feature CNN / R-Net under autograd, all three directions
     on the hand-written matrix-core kernels (models/psm_submodule.py:10-16, models/m_submodule.py:18-27 in training,
@@ -177,11 +193,12 @@ class Conv2dCL(torch.autograd.Function):
     DIRECT = {(32, 1), (64, 1), (96, 1), (128, 1), (128, 2)}    # (Cout, dilation) instantiated in conv2d.hip
 
     @staticmethod
-    def eligible(cin, cout, dil):
-        """Forward, data gradient (roles of Cin / Cout swapped) and weight gradient all have a kernel."""
+    def eligible(cin, cout, dil, need_dgrad=True):
+        """Forward, data gradient (roles of Cin / Cout swapped; not needed when the input is an image) and weight gradient all
+        have a kernel."""
         def fwd(ci, co):
             return (ci % 32 == 0 and co % 64 == 0 and dil in (1, 2)) or (ci % 16 == 0 and (co, dil) in Conv2dCL.DIRECT)
-        return fwd(cin, cout) and fwd(cout, cin) and cin % 16 == 0 and cout % 16 == 0
+        return fwd(cin, cout) and (fwd(cout, cin) or not need_dgrad) and cin % 16 == 0 and cout % 16 == 0
 
     @staticmethod
     def _conv(x_cl, w, dil, transposed=False, packed=None):
@@ -216,18 +233,138 @@ class Conv2dCL(torch.autograd.Function):
         return gx, gw, None
 
 
-def conv2d_module(conv, x):
-    """nn.Conv2d forward for the module (autograd) paths: every 3x3 stride-1 convolution with a kernel in all three directions
-    (CUDA, fp32, padding = dilation) goes through Conv2dCL.  NRGBD_TRAIN_CONV=vendor keeps the vendor library for A/B: at the
-    64x96 training grid, round 3, the iteration replayed as a hipGraph takes 38.7 ms on the hand-written kernels and 41.4 ms on
-    the vendor convolutions (round 2: 53.1 vs 51.4 ms — since then the weight-gradient kernel stages its dY tile in LDS and its
-    partials are reduced by 8 slices per workgroup)."""
+def _padded_widths(cin, cout, dil, need_dgrad):
+    """Smallest (cin_p, cout_p) >= (cin, cout), multiples of 16, for which Conv2dCL has every kernel it will need."""
+    best = None
+    for co in range(-(-cout // 16) * 16, cout + 129, 16):
+        for ci in range(-(-cin // 16) * 16, cin + 129, 16):
+            if Conv2dCL.eligible(ci, co, dil, need_dgrad) and (best is None or ci * co < best[0] * best[1]):
+                best = (ci, co)
+    return best
+
+
+# stride-2 3x3 (padding 1) on the space-to-depth input: y[Y] = sum_ky w[ky] x[2Y + ky - 1]; with x2[Yp, py] = x[2Yp + py] the three
+# taps are (Yp = Y - 1, py = 1), (Y, 0), (Y, 1): a 3x3 stride-1 kernel on x2 whose row r = dy + 1 and parity py select tap
+# _S2_TAP[r][py] (-1: no such tap).  Same along x.
+_S2_TAP = ((-1, 0), (1, 2), (-1, -1))
+# ConvTranspose2d(k4, s2, p1): output row 2Y + a collects input rows Y + dy with kernel row ky = a + 1 - 2 dy:
+# a = 0: (dy -1 -> 3), (0 -> 1);  a = 1: (0 -> 2), (+1 -> 0).  _T2_TAP[a][r = dy + 1]
+_T2_TAP = ((3, 1, -1), (-1, 2, 0))
+_index_cache = {}
+
+
+def _tap_select(kind, device):
+    """(flat source index, mask) that turn a flattened kernel into its embedded 3x3 form with ONE index_select (no GEMM: an
+    einsum with the 0/1 selection tensors would run on rocBLAS)."""
+    key = (kind, str(device))
+    hit = _index_cache.get(key)
+    if hit is None:
+        if kind == "s2":        # target [py, px, r, c] <- source [ky, kx] (3x3)
+            idx = torch.zeros(2, 2, 3, 3, dtype=torch.long)
+            msk = torch.zeros(2, 2, 3, 3)
+            for py in range(2):
+                for px in range(2):
+                    for r in range(3):
+                        for c in range(3):
+                            ky, kx = _S2_TAP[r][py], _S2_TAP[c][px]
+                            if ky >= 0 and kx >= 0:
+                                idx[py, px, r, c] = ky * 3 + kx
+                                msk[py, px, r, c] = 1.0
+        else:                   # "t2": target [a, b, r, c] <- source [ky, kx] (4x4)
+            idx = torch.zeros(2, 2, 3, 3, dtype=torch.long)
+            msk = torch.zeros(2, 2, 3, 3)
+            for a_ in range(2):
+                for b_ in range(2):
+                    for r in range(3):
+                        for c in range(3):
+                            ky, kx = _T2_TAP[a_][r], _T2_TAP[b_][c]
+                            if ky >= 0 and kx >= 0:
+                                idx[a_, b_, r, c] = ky * 4 + kx
+                                msk[a_, b_, r, c] = 1.0
+        hit = (idx.reshape(-1).to(device), msk.reshape(-1).to(device))
+        _index_cache[key] = hit
+    return hit
+
+
+def _conv3x3_cl(x, w, dil, bias, keep_width=False):
+    """3x3 stride-1 convolution through Conv2dCL, the channel counts zero-padded to widths the kernels have (67 -> 96 for the
+    R-Net's full-resolution layers, 12 -> 16 for the space-to-depth image).  None if no width fits.
+    x may already carry MORE channels than w reads (the padded output of the previous layer: its extra channels are zero).
+    keep_width: return the padded output [N, cout_p, H, W] (extra channels exactly zero when the bias is added here: its
+    padding is zero too) instead of a channel slice — the next layer then reads it as is."""
+    F = torch.nn.functional
+    cout, cin = w.shape[:2]
+    have = x.shape[1]
+    pw = _padded_widths(max(cin, have), cout, dil, x.requires_grad)
+    if pw is None:
+        return None
+    ci, co = pw
+    if ci != have:
+        x = F.pad(x, (0, 0, 0, 0, 0, ci - have))
+    if ci != cin:
+        w = F.pad(w, (0, 0, 0, 0, 0, ci - cin))
+    if co != cout:
+        w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, co - cout))
+    y = Conv2dCL.apply(x, w, dil)
+    if bias is not None:            # on the full-width channels-last tensor: the bias gradient is a contiguous column sum
+        y = y + (bias if co == cout else F.pad(bias, (0, co - cout))).view(1, -1, 1, 1)
+    if co != cout and not keep_width:
+        y = y[:, :cout]
+    return y
+
+
+def conv2d_module(conv, x, _any_device=False, keep_width=False):
+    """nn.Conv2d forward for the module (autograd) paths, on the hand-written kernels in all three directions:
+      * 3x3, stride 1, padding = dilation: Conv2dCL (channels zero-padded to a width the kernels have when needed: the R-Net's
+        67-channel layers run as 96-wide ones);
+      * 1x1 (stride 1 or 2, the trunk's shortcut / SPP / last layers, psm_submodule.py:90-139): the (strided) input through the
+        same op with the weight as the centre tap of a 3x3 kernel;
+      * 3x3, stride 2, padding 1 (firstconv, layer2: psm_submodule.py:90-99): space-to-depth (pixel_unshuffle) + the 3x3 kernel
+        that holds the 2x2 window of the stride-2 taps (`_S2_TAP`).
+    The weight embeddings are index / pad operations of torch, so autograd maps the weight gradient back by itself.
+    (_any_device: the CPU test of the embeddings, tests/test_host.py, which substitutes F.conv2d for Conv2dCL.)
+    NRGBD_TRAIN_CONV=vendor keeps the vendor library (developer A/B only)."""
     import os
-    d = conv.dilation[0]
-    if (x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and conv.padding == (d, d) and conv.dilation == (d, d) and conv.groups == 1
-            and Conv2dCL.eligible(conv.in_channels, conv.out_channels, d)
+    F = torch.nn.functional
+    k, st, pd, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+    if not ((x.is_cuda or _any_device) and x.dtype == torch.float32 and conv.groups == 1 and k[0] == k[1] and st[0] == st[1] and d[0] == d[1]
+            and pd[0] == pd[1] and conv.padding_mode == "zeros" and os.environ.get("NRGBD_TRAIN_CONV", "native") == "native"):
+        return conv(x)
+    w, y = conv.weight, None
+    if k == (3, 3) and st == (1, 1) and pd == d:
+        y = _conv3x3_cl(x, w, d[0], conv.bias, keep_width)
+    elif k == (1, 1) and pd == (0, 0) and st[0] in (1, 2):
+        xs = x if st[0] == 1 else x[:, :, ::2, ::2]
+        y = _conv3x3_cl(xs, F.pad(w, (1, 1, 1, 1)), 1, conv.bias)
+    elif k == (3, 3) and st == (2, 2) and pd == (1, 1) and d == (1, 1) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+        idx, msk = _tap_select("s2", w.device)
+        cout, cin = w.shape[:2]
+        # pixel_unshuffle orders its channels c * 4 + py * 2 + px
+        w2 = (w.reshape(cout, cin, 9).index_select(2, idx) * msk).reshape(cout, cin * 4, 3, 3)
+        y = _conv3x3_cl(F.pixel_unshuffle(x, 2), w2, 1, conv.bias)
+    if y is None:
+        return conv(x[:, :conv.in_channels] if x.shape[1] != conv.in_channels else x)
+    return y
+
+
+def conv_transpose2d_module(conv, x, _any_device=False):
+    """nn.ConvTranspose2d(kernel 4, stride 2, padding 1) of the R-Net (models/Refine.py:51-77, m_submodule.py:36-45) under autograd
+    on the hand-written kernels: its four sub-pixel phases are 2x2-tap convolutions of the input (`_T2_TAP`); embedded in 3x3
+    kernels and stacked along the output channels (4 Cout, ordered co * 4 + a * 2 + b) they are ONE Conv2dCL launch per direction,
+    and pixel_shuffle interleaves the phases."""
+    import os
+    F = torch.nn.functional
+    if not ((x.is_cuda or _any_device) and x.dtype == torch.float32 and conv.groups == 1 and conv.kernel_size == (4, 4) and conv.stride == (2, 2)
+            and conv.padding == (1, 1) and conv.output_padding == (0, 0) and conv.dilation == (1, 1)
             and os.environ.get("NRGBD_TRAIN_CONV", "native") == "native"):
-        y = Conv2dCL.apply(x, conv.weight, d)
-        return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
-    return conv(x)
+        return conv(x)
+    w = conv.weight                                  # [Cin, Cout, 4, 4]
+    cin, cout = w.shape[:2]
+    idx, msk = _tap_select("t2", w.device)
+    w4 = (w.permute(1, 0, 2, 3).reshape(cout, cin, 16).index_select(2, idx) * msk)       # [Cout, Cin, (a, b, r, c)]
+    w4 = w4.reshape(cout, cin, 4, 9).permute(0, 2, 1, 3).reshape(cout * 4, cin, 3, 3)   # rows co * 4 + (a * 2 + b)
+    y = _conv3x3_cl(x, w4, 1, None)
+    if y is None:
+        return conv(x)
+    y = F.pixel_shuffle(y, 2)
+    return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)

@@ -61,7 +61,91 @@ __global__ __launch_bounds__(256) void spp_concat_kernel(const SppArgs a) {
     }
 }
 
+// ---- training: the bilinear up-sampling (align_corners = True) of one tiny SPP map and its exact adjoint, channels-last.
+// The weights of an output row / column are ATen's (see the header comment); the backward thread of an INPUT element walks the
+// output rows / columns that can reach it and recomputes the same fp32 weights, so it is the adjoint of the forward to the bit
+// and sums in a fixed order (F.interpolate's backward scatters with atomics: 0.82 ms per branch at the ScanNet grid and not
+// reproducible; the two-matmul form of rounds 2-3 ran on rocBLAS).
+struct UpW { int i0, i1; float l0, l1; };
+__device__ __forceinline__ UpW up_weights(int dst, int n_in, float scale) {
+    const float r = scale * (float)dst;
+    UpW u;
+    u.i0 = min((int)r, n_in - 1);
+    u.i1 = u.i0 + (u.i0 < n_in - 1 ? 1 : 0);
+    u.l1 = fminf(fmaxf(r - (float)u.i0, 0.f), 1.f);
+    u.l0 = 1.f - u.l1;
+    return u;
+}
+
+__global__ __launch_bounds__(256) void upsample_ac_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int bh, int bw,
+                                                              int H, int W, int C) {
+    const int c4n = C >> 2;
+    const long total = (long)N * H * W * c4n;
+    const float sch = H > 1 ? (float)(bh - 1) / (float)(H - 1) : 0.f, scw = W > 1 ? (float)(bw - 1) / (float)(W - 1) : 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        long t = idx / c4n;
+        const int xo = (int)(t % W); t /= W;
+        const int yo = (int)(t % H);
+        const int n = (int)(t / H);
+        const UpW a = up_weights(yo, bh, sch), b = up_weights(xo, bw, scw);
+        const sf32x4* z = reinterpret_cast<const sf32x4*>(x) + (long)n * bh * bw * c4n + c4;
+        const sf32x4 v00 = z[((long)a.i0 * bw + b.i0) * c4n], v01 = z[((long)a.i0 * bw + b.i1) * c4n];
+        const sf32x4 v10 = z[((long)a.i1 * bw + b.i0) * c4n], v11 = z[((long)a.i1 * bw + b.i1) * c4n];
+        reinterpret_cast<sf32x4*>(y)[idx] = a.l0 * (b.l0 * v00 + b.l1 * v01) + a.l1 * (b.l0 * v10 + b.l1 * v11);
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_ac_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int N, int bh, int bw,
+                                                              int H, int W, int C) {
+    const int c4n = C >> 2;
+    const long total = (long)N * bh * bw * c4n;
+    const float sch = H > 1 ? (float)(bh - 1) / (float)(H - 1) : 0.f, scw = W > 1 ? (float)(bw - 1) / (float)(W - 1) : 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        long t = idx / c4n;
+        const int bx = (int)(t % bw); t /= bw;
+        const int by = (int)(t % bh);
+        const int n = (int)(t / bh);
+        // output rows / columns whose source position lies in (b - 1, b + 1), with a margin of one for the fp32 rounding of
+        // scale * dst; membership is then decided by the forward's own weights
+        int y0 = 0, y1 = H - 1, x0 = 0, x1 = W - 1;
+        if (sch > 0.f) { y0 = max(0, (int)floorf((float)(by - 1) / sch) - 1); y1 = min(H - 1, (int)ceilf((float)(by + 1) / sch) + 1); }
+        if (scw > 0.f) { x0 = max(0, (int)floorf((float)(bx - 1) / scw) - 1); x1 = min(W - 1, (int)ceilf((float)(bx + 1) / scw) + 1); }
+        const sf32x4* g = reinterpret_cast<const sf32x4*>(gy) + (long)n * H * W * c4n + c4;
+        sf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int yo = y0; yo <= y1; ++yo) {
+            const UpW a = up_weights(yo, bh, sch);
+            const float wy = (a.i0 == by ? a.l0 : 0.f) + (a.i1 == by ? a.l1 : 0.f);
+            if (wy == 0.f) continue;
+            sf32x4 row = {0.f, 0.f, 0.f, 0.f};
+            for (int xo = x0; xo <= x1; ++xo) {
+                const UpW b = up_weights(xo, bw, scw);
+                const float wx = (b.i0 == bx ? b.l0 : 0.f) + (b.i1 == bx ? b.l1 : 0.f);
+                if (wx != 0.f) row = row + wx * g[((long)yo * W + xo) * c4n];
+            }
+            acc = acc + wy * row;
+        }
+        reinterpret_cast<sf32x4*>(gx)[idx] = acc;
+    }
+}
+
 }  // namespace nrgbd
+
+extern "C" int nrgbd_upsample_bilinear_ac(const float* x, float* y, int N, int bh, int bw, int H, int W, int C, int backward,
+                                          void* stream) {
+    using namespace nrgbd;
+    if (!x || !y) return NRGBD_E_NULL;
+    if (N <= 0 || bh <= 0 || bw <= 0 || H <= 0 || W <= 0 || C <= 0) return NRGBD_E_SHAPE;
+    if (C & 3) return NRGBD_E_ALIGN;
+    const long total = (long)N * (backward ? (long)bh * bw : (long)H * W) * (C >> 2);
+    const long blocks = (total + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192));
+    if (backward) hipLaunchKernelGGL(upsample_ac_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, N, bh, bw, H, W, C);
+    else hipLaunchKernelGGL(upsample_ac_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, N, bh, bw, H, W, C);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
 
 extern "C" int nrgbd_spp_concat(const float* quarter, int Cq, const float* deep, int Cd,
                                 const float* bz0, const float* bss0, int bh0, int bw0,

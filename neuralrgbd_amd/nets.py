@@ -295,36 +295,14 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
             return out
         return {w: F.avg_pool2d(deep, (w, w), stride=(w, w)) for w in self.SPP_WINDOWS}
 
-    _interp_cache = {}
-
-    @classmethod
-    def _interp_matrix(cls, n_out, n_in, device):
-        """[n_out, n_in] matrix of 1-D linear interpolation with align_corners=True (same source-index arithmetic
-        as F.interpolate: src = dst * (n_in-1)/(n_out-1) in fp32)."""
-        key = (n_out, n_in, str(device))
-        A = cls._interp_cache.get(key)
-        if A is None:
-            scale = (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
-            src = torch.arange(n_out, dtype=torch.float32) * np.float32(scale)
-            i0 = src.floor().long().clamp_(0, n_in - 1)
-            i1 = (i0 + 1).clamp_(max=n_in - 1)
-            w1 = src - i0.to(torch.float32)
-            A = torch.zeros(n_out, n_in)
-            rows = torch.arange(n_out)
-            A.index_put_((rows, i0), 1.0 - w1, accumulate=True)
-            A.index_put_((rows, i1), w1, accumulate=True)
-            A = A.to(device)
-            cls._interp_cache[key] = A
-        return A
 
     def _upsample(self, y, size):
-        """Bilinear up-sampling (align_corners=True) of the tiny SPP maps.  Under autograd it is written as two
-        small matrix products (rows, then columns): the backward of F.interpolate scatters every output gradient
-        into a handful of inputs with atomics (0.82 ms per branch at the ScanNet grid), the matmul backward does not."""
-        if y.is_cuda and torch.is_grad_enabled():
-            Ay = self._interp_matrix(size[0], y.shape[2], y.device)
-            Ax = self._interp_matrix(size[1], y.shape[3], y.device)
-            return torch.matmul(torch.matmul(Ay, y), Ax.t())
+        """Bilinear up-sampling (align_corners=True) of the tiny SPP maps.  Under autograd both directions run on csrc/spp.hip
+        (autograd.UpsampleBilinearCL): the backward of F.interpolate scatters every output gradient into a handful of inputs
+        with atomics (0.82 ms per branch at the ScanNet grid), the hand-written adjoint sums each input in a fixed order."""
+        if y.is_cuda and torch.is_grad_enabled() and y.dtype == torch.float32 and y.shape[1] % 4 == 0:
+            from .autograd import UpsampleBilinearCL
+            return UpsampleBilinearCL.apply(y, int(size[0]), int(size[1]))
         return F.interpolate(y, size=size, mode="bilinear", align_corners=True)
 
     # ------------------------------------------------------------------ matrix-core inference path
@@ -494,7 +472,11 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
             y = _conv_bn_act(pools[self.SPP_WINDOWS[i - 1]], branch[1], relu=True)
             pyramid.append(self._upsample(y, size))
         y = _conv_bn_act(torch.cat([quarter, deep] + pyramid, dim=1), self.lastconv[0], relu=True)
-        feat = self.lastconv[2](y)
+        if y.is_cuda and torch.is_grad_enabled():
+            from .autograd import conv2d_module
+            feat = conv2d_module(self.lastconv[2], y)       # the 1x1 head on the hand-written kernels in all three directions
+        else:
+            feat = self.lastconv[2](y)
         return (half, feat) if self.multi_scale else feat
 
 
@@ -939,13 +921,19 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 and (dpv_raw.shape[2] * dpv_raw.shape[3]) % 4 == 0:
             return self._forward_fused_tail(dpv_raw, img_features)
         quarter, half, full = img_features
-        from .autograd import conv2d_module
+        from .autograd import conv2d_module, conv_transpose2d_module
 
         def cl(m, x):   # conv2d_leakyRelu block: the convolution on the hand-written kernels where they apply
             return F.leaky_relu(conv2d_module(m[0], x), 0.01)
+
+        def tl(m, x):   # conv2dTranspose_leakyRelu block (four sub-pixel phases as one 3x3 launch per direction)
+            return F.leaky_relu(conv_transpose2d_module(m[0], x), 0.01)
         x = cl(self.conv0_1, cl(self.conv0, torch.cat([dpv_raw, quarter], dim=1)))
-        x = self.trans_conv0(x)
+        x = tl(self.trans_conv0, x)
         x = cl(self.conv1_1, cl(self.conv1, torch.cat([x, half], dim=1)))
-        x = self.trans_conv1(x)
-        x = conv2d_module(self.conv2_2, cl(self.conv2_1, cl(self.conv2, torch.cat([x, full], dim=1))))
+        x = tl(self.trans_conv1, x)
+        # conv2 (67 -> 67) runs 96 wide; its padded output (29 exact zeros: zero weights, zero bias, LeakyReLU(0) = 0) feeds
+        # conv2_1 as it is — no channel slice, no re-padding at full resolution
+        x = F.leaky_relu(conv2d_module(self.conv2[0], torch.cat([x, full], dim=1), keep_width=True), 0.01)
+        x = conv2d_module(self.conv2_2, cl(self.conv2_1, x))
         return F.log_softmax(x, dim=1)

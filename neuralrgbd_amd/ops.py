@@ -815,6 +815,19 @@ def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, 
     return ss
 
 
+def upsample_bilinear_ac(x, H, W, backward=False):
+    """Bilinear up-sampling (align_corners=True) of a channels-last map x [N,bh,bw,C] -> [N,H,W,C] (nrgbd_upsample_bilinear_ac);
+    backward=True: x is the gradient of the output [N,H2,W2,C] and (H, W) the INPUT size -> gradient of the input [N,H,W,C]."""
+    x = _need(x, "x")
+    N, a, b, C = x.shape
+    y = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    bh, bw, Ho, Wo = (H, W, a, b) if backward else (a, b, H, W)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_upsample_bilinear_ac(_p(x), _p(y), N, bh, bw, Ho, Wo, C, int(backward), _stream(x))
+    _lib.check(rc, "nrgbd_upsample_bilinear_ac")
+    return y
+
+
 def spp_concat(quarter, deep, branches):
     """[quarter | deep | up(relu(bn(z_0))) | ... | up(relu(bn(z_3)))] -> [N,h,w,Cq+Cd+4*Cb] in one pass (nrgbd_spp_concat).
     quarter [N,h,w,Cq], deep [N,h,w,Cd] channels-last; branches: four (z [N,bh,bw,Cb] raw 1x1-conv output, ss [Cb,2]) in the

@@ -109,22 +109,11 @@ def test_synth_is_deterministic():
     assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3, dtype=torch.float64).expand(4, 3, 3), atol=1e-6)
 
 
-def test_spp_autograd_forms_match_torch_ops():
-    """The training-path rewrites of the SPP branch (nets.PSMFeatures: pooling as crop+reshape+mean, bilinear
-    align_corners up-sampling as two matrix products) equal avg_pool2d / F.interpolate, values and gradients."""
+def test_spp_pooling_rewrite_matches_avg_pool():
+    """The training-path rewrite of the SPP pooling (nets.PSMFeatures: crop + reshape + mean) equals avg_pool2d.  (The bilinear
+    up-sampling of the branches is a kernel pair now: tests/test_gpu_cnn.py::test_upsample_bilinear_align_corners_forward_and_adjoint.)"""
     import torch.nn.functional as F
-    from neuralrgbd_amd.nets import PSMFeatures
     g = torch.Generator().manual_seed(0)
-    for (ph, pw, h, w) in [(1, 1, 64, 96), (2, 3, 64, 96), (4, 6, 64, 96), (8, 12, 64, 96), (3, 4, 120, 160)]:
-        y = torch.randn(2, 5, ph, pw, generator=g, requires_grad=True)
-        Ay, Ax = PSMFeatures._interp_matrix(h, ph, "cpu"), PSMFeatures._interp_matrix(w, pw, "cpu")
-        got = torch.matmul(torch.matmul(Ay, y), Ax.t())
-        want = F.interpolate(y, size=(h, w), mode="bilinear", align_corners=True)
-        assert (got - want).abs().max().item() < 2e-6
-        go = torch.randn(got.shape, generator=g)
-        g1, = torch.autograd.grad(got, y, go, retain_graph=True)
-        g2, = torch.autograd.grad(want, y, go)
-        assert (g1 - g2).abs().max().item() < 1e-4 * max(1.0, g2.abs().max().item())
     d = torch.randn(2, 3, 64, 96, generator=g)
     for k in (64, 32, 16, 8):
         ph, pw = 64 // k, 96 // k
@@ -217,8 +206,9 @@ def test_bench_refuses_a_traffic_measurement_taken_on_other_kernel_sources(tmp_p
 
 
 def test_live_traffic_measurement_parses_the_counter_files_and_fails_soft(tmp_path, monkeypatch):
-    """bench.live_pmc_traffic: two rocprofv3 --pmc child passes -> FETCH_SIZE x2 + WRITE_SIZE per dispatch of the sampling kernel;
-    a missing profiler, a failing child or an output without the kernel give (None, reason) and the caller falls back to the file."""
+    """bench.live_pmc_traffic: three rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE, the SQ set) -> FETCH_SIZE x2 + WRITE_SIZE
+    per dispatch of the sampling kernel + its mean SQ counters (-> roofline.valu_frac / lds_frac); a missing profiler, a failing
+    child or an output without the kernel give (None, reason, None) and the caller falls back to the committed file."""
     import subprocess
     import bench
     calls = []
@@ -226,23 +216,82 @@ def test_live_traffic_measurement_parses_the_counter_files_and_fails_soft(tmp_pa
     def fake_run(cmd, **kw):
         calls.append(cmd)
         assert "--pmc" in cmd and "--no-live-traffic" in cmd and "--no-graph" in cmd      # the child cannot recurse
-        counter, out = cmd[cmd.index("--pmc") + 1], cmd[cmd.index("-d") + 1]
+        counters, out = cmd[cmd.index("--pmc") + 1:cmd.index("--output-format")], cmd[cmd.index("-d") + 1]
         os.makedirs(os.path.join(out, "host", "1"), exist_ok=True)
         with open(os.path.join(out, "host", "1", "p_counter_collection.csv"), "w") as f:
             f.write("Kernel_Name,Counter_Name,Counter_Value\n")
-            for v in (100.0, 300.0):
-                f.write('"void nrgbd::costvol_quad<0, 3, false, 188, 3, false>(nrgbd::CostvolArgs)",%s,%f\n' % (counter, v))
-            f.write('"other_kernel",%s,999999\n' % counter)
+            for counter in counters:
+                for v in (100.0, 300.0):
+                    f.write('"void nrgbd::costvol_quad<0, 3, false, 188, 3, false>(nrgbd::CostvolArgs)",%s,%f\n' % (counter, v))
+                f.write('"other_kernel",%s,999999\n' % counter)
         return subprocess.CompletedProcess(cmd, 0)
 
     import shutil
     monkeypatch.setattr(shutil, "which", lambda name: sys.executable)       # any existing file stands in for the profiler
     monkeypatch.setattr(subprocess, "run", fake_run)
-    val, note = bench.live_pmc_traffic("B")
-    assert val == int(2 * 200 * 1024 + 200 * 1024) and "measured in this run" in note and len(calls) == 2
+    val, note, sq = bench.live_pmc_traffic("B")
+    assert val == int(2 * 200 * 1024 + 200 * 1024) and "measured in this run" in note and len(calls) == 3
+    assert set(sq) == set(bench.SQ_PASS) and sq["SQ_ACTIVE_INST_VALU"] == 200.0
+    fr = bench.sq_fractions({"GRBM_GUI_ACTIVE": 8e6, "SQ_ACTIVE_INST_VALU": 1.28e8, "SQ_LDS_IDX_ACTIVE": 6.4e7, "SQ_LDS_BANK_CONFLICT": 0.0,
+                             "SQ_WAVE_CYCLES": 1e9, "SQ_WAIT_ANY": 2.5e8})
+    assert abs(fr["valu_frac"] - 0.5) < 1e-9 and abs(fr["lds_frac"] - 0.25) < 1e-9 and abs(fr["waves_waiting_frac"] - 0.25) < 1e-9
 
     def failing(cmd, **kw):
         raise subprocess.CalledProcessError(1, cmd)
     monkeypatch.setattr(subprocess, "run", failing)
-    val, note = bench.live_pmc_traffic("B")
-    assert val is None and "failed" in note
+    val, note, sq = bench.live_pmc_traffic("B")
+    assert val is None and "failed" in note and sq is None
+
+
+def test_conv_embeddings_of_the_training_path_are_exact(monkeypatch):
+    """autograd.conv2d_module / conv_transpose2d_module express the stride-2 3x3, the 1x1 (stride 1 / 2), the odd-width (67
+    channel) and the ConvTranspose2d(k4, s2, p1) layers as ONE 3x3 stride-1 convolution on padded / space-to-depth tensors with
+    an embedded weight (psm_submodule.py:90-139, Refine.py:51-77).  With F.conv2d standing in for the device kernel, forward,
+    input gradient, weight gradient and bias gradient must equal the torch module's — the index maps are exact, only summation
+    order differs."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from neuralrgbd_amd import autograd as ag
+
+    class FakeConv2dCL:
+        calls = []
+
+        @staticmethod
+        def eligible(cin, cout, dil, need_dgrad=True):
+            return cin % 16 == 0 and cout % 16 == 0
+
+        @staticmethod
+        def apply(x, w, dil):
+            FakeConv2dCL.calls.append((tuple(x.shape), tuple(w.shape), dil))
+            return F.conv2d(x, w, None, 1, dil, dil)
+    monkeypatch.setattr(ag, "Conv2dCL", FakeConv2dCL)
+    torch.manual_seed(0)
+    cases = [
+        (nn.Conv2d(3, 32, 3, 2, 1, bias=False), (2, 3, 16, 24), ag.conv2d_module),          # firstconv: image -> 12 -> 16 channels
+        (nn.Conv2d(32, 64, 3, 2, 1, bias=False), (2, 32, 12, 8), ag.conv2d_module),         # layer2 entry
+        (nn.Conv2d(32, 64, 1, 2, 0, bias=False), (2, 32, 12, 8), ag.conv2d_module),         # strided 1x1 shortcut
+        (nn.Conv2d(128, 32, 1, 1, 0, bias=False), (1, 128, 5, 7), ag.conv2d_module),        # SPP branch
+        (nn.Conv2d(67, 67, 3, 1, 1, bias=True), (1, 67, 10, 12), ag.conv2d_module),         # R-Net conv2 (67 -> 67, bias)
+        (nn.Conv2d(67, 64, 3, 1, 1, bias=True), (1, 67, 10, 12), ag.conv2d_module),         # R-Net conv2_1
+        (nn.Conv2d(64, 64, 3, 1, 2, 2, bias=False), (1, 64, 9, 11), ag.conv2d_module),      # dilated trunk layer: passes straight through
+        (nn.ConvTranspose2d(128, 64, 4, 2, 1, bias=True), (1, 128, 6, 5), ag.conv_transpose2d_module),
+        (nn.ConvTranspose2d(96, 64, 4, 2, 1, bias=True), (2, 96, 4, 7), ag.conv_transpose2d_module),
+    ]
+    for mod, shape, fn in cases:
+        mod = mod.double()
+        x = torch.randn(*shape, dtype=torch.float64, requires_grad=True)
+        monkeypatch.setattr(torch, "float32", torch.float64)      # the dtype gate of the module functions (fp32 on the device)
+        n0 = len(FakeConv2dCL.calls)
+        y = fn(mod, x, _any_device=True)
+        monkeypatch.undo(); monkeypatch.setattr(ag, "Conv2dCL", FakeConv2dCL)
+        assert len(FakeConv2dCL.calls) == n0 + 1, "the layer must run as ONE stride-1 3x3 convolution"
+        want = mod(x)
+        assert y.shape == want.shape
+        g = torch.randn_like(want)
+        params = [mod.weight] + ([mod.bias] if mod.bias is not None else [])
+        got_g = torch.autograd.grad(y, [x] + params, g)
+        want_g = torch.autograd.grad(want, [x] + params, g)
+        assert torch.allclose(y, want, rtol=1e-12, atol=1e-12), type(mod)
+        for a, b in zip(got_g, want_g):
+            assert torch.allclose(a, b, rtol=1e-11, atol=1e-11), (type(mod), a.shape)
