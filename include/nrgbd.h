@@ -345,19 +345,6 @@ int nrgbd_avgpool8(const float* x, float* y, int NC, int H, int W, void* stream)
 int nrgbd_bias_act_nchw(float* x, const float* bias, float slope, int N, int C, long HW, void* stream);
 
 /*
- * nrgbd_conv3d_wino_f32 — the K-Net's 64 -> 64 layer (same contract as nrgbd_conv3d_3x3x3_f32 with Cin = Cout = 64) with the
- * two in-plane dimensions in the Winograd domain F(2x2, 3x3): 2.25x fewer fp32 multiplies (MFMAs) per layer, exact-algorithm
- * fp32 (rounding order differs, as in any Winograd convolution).  Replaces the same reference lines (models/basic.py:71-94).
- *   w_wino: 12 stages (4 input-channel blocks x 3 depth taps) x 16 transform points x [4 waves][64 lanes][4] floats =
- *           U[xi][kd][ci][co] = (G g G^T) packed by the host mirror (neuralrgbd_amd/ops.py::conv3d_wino_pack), 196,608 floats
- *   stats [nrgbd_conv3d_wino_workgroups(D,H,W)][128]  (nrgbd_bn3d_finalize reduces them like the direct kernel's)
- */
-int nrgbd_conv3d_wino_workgroups(int D, int H, int W);
-int nrgbd_conv3d_wino_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
-                          int res_relu, float* materialized, const float* w_wino, float* y, float* stats,
-                          int D, int H, int W, void* stream);
-
-/*
  * nrgbd_conv_wino_f32 — generation 2 of the Winograd-domain convolution (csrc/wino_pc.hip): a persistent 8-wave workgroup per
  * CU, 4 consumer waves that only issue MFMAs and 4 producer waves that load / normalise / transform the operand two stages
  * ahead.  One entry for
@@ -411,19 +398,7 @@ int nrgbd_conv_wino_dw_pack(const float* w, float* w_wino, int Cin, int Cout, in
 int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
                            int res_relu, float* materialized, const float* w_wino, float* y, float* stats,
                            int N, int H, int W, int Cin, int Cout, void* stream);
-/* The same with the BatchNorm3d finalisation of models/basic.py:53-68 (convbn_3d: batch statistics, running-statistics update)
- * FUSED into the launch: every workgroup leaves its per-channel sums (fp64) in wg_scratch and takes a ticket; the last one turns
- * them into scale_shift [Cout][2] = (gamma * invstd, beta - mean * gamma * invstd) — what nrgbd_bn_finalize_cm does in a launch of
- * its own from 2 Cout x tiles floats.  Cout = 64.
- *   wg_scratch [nrgbd_conv_wino_dw_workgroups(N,H,W,Cout)][2*Cout] doubles (no initialisation needed);
- *   ticket     one int, ZERO before the first launch; the finalising workgroup resets it, so one ticket serves every launch of
- *              a stream (hipGraph replays included).  Not to be shared between launches that can overlap in time. */
 int nrgbd_conv_wino_dw_workgroups(int N, int H, int W, int Cout);
-int nrgbd_conv_wino_dw_bn_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
-                              int res_relu, float* materialized, const float* w_wino, float* y, int N, int H, int W,
-                              int Cin, int Cout, const float* gamma, const float* beta, float eps, float momentum,
-                              float* running_mean, float* running_var, double* wg_scratch, int* ticket,
-                              float* scale_shift, void* stream);
 
 /*
  * R-Net (DPV up-sampler) on the same matrix-core kernel.  Replaces, per layer of models/Refine.py:51-107:

@@ -47,8 +47,6 @@ SIGNATURES = {
     "nrgbd_conv3d_pack_weights": (_I, [_P, _P, _I, _P]),
     "nrgbd_conv3d_3x3x3_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv3d_3x3x3_cout1_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
-    "nrgbd_conv3d_wino_workgroups": (_I, [_I, _I, _I]),
-    "nrgbd_conv3d_wino_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "nrgbd_conv_wino_tiles": (_I, [_I, _I, _I, _I]),
     "nrgbd_conv_wino_rnet_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_rnet_ex_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -58,7 +56,6 @@ SIGNATURES = {
     "nrgbd_conv_wino_dw_pack": (_I, [_P, _P, _I, _I, _I, _P]),
     "nrgbd_conv_wino_dw_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_dw_workgroups": (_I, [_I, _I, _I, _I]),
-    "nrgbd_conv_wino_dw_bn_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     "nrgbd_conv3d_wgrad_workgroups": (_I, []),
     "nrgbd_conv3d_wgrad_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "nrgbd_bn3d_finalize": (_I, [_P, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P]),

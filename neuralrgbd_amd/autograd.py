@@ -3,7 +3,8 @@
 Inference never touches this module.  Under autograd the D-Net uses
     texels = PackNHWC(features, frames)        backward: channel slice + layout change (no gradient to the images)
     cost   = PlaneSweepCost(texels, ...)       backward: csrc/costvol_bwd.hip
-and everything else (log-softmax, K-Net, R-Net, losses) is ordinary torch autograd on the vendor kernels.
+the convolutions / BatchNorms of the three networks go through Conv2dCL / Conv3dCL / BatchNormActCL / UpsampleBilinearCL below
+(hand-written kernels in all three directions); log-softmax, LeakyReLU and the NLL losses are ATen element-wise kernels.
 """
 import torch
 
@@ -140,9 +141,9 @@ class BatchNormActCL(torch.autograd.Function):
 
 
 def batch_norm_act_cl(x_cl, bn, relu, residual=None):
-    """Train-mode nn.BatchNorm{2,3}d `bn` (+ ReLU, + residual) applied to the channels-last tensor x_cl [..., C] under autograd.
-    NRGBD_TRAIN_BN=vendor keeps torch's batch_norm / relu / add (A/B); shapes bn_train.hip has no form for take that path too."""
-    import os
+    """Train-mode nn.BatchNorm{2,3}d `bn` (+ ReLU, + residual) applied to the channels-last tensor x_cl [..., C] under autograd:
+    csrc/bn_train.hip in both directions; eval-mode norms and the few shapes bn_train.hip has no form for (C / 4 not dividing a
+    256-lane workgroup) are torch's batch_norm / relu / add."""
     import torch.nn.functional as F
     C = x_cl.shape[-1]
     use_batch = bn.training or not bn.track_running_stats
@@ -150,8 +151,7 @@ def batch_norm_act_cl(x_cl, bn, relu, residual=None):
     if upd:
         bn.num_batches_tracked += 1
     m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-    if (use_batch and x_cl.is_cuda and x_cl.dtype == torch.float32 and bn.affine and ops.bn_cl_supported(x_cl.numel() // C, C)
-            and os.environ.get("NRGBD_TRAIN_BN", "native") == "native"):
+    if use_batch and x_cl.is_cuda and x_cl.dtype == torch.float32 and bn.affine and ops.bn_cl_supported(x_cl.numel() // C, C):
         if x_cl.numel() // C <= 1:      # nn.BatchNorm's own refusal (torch/nn/functional.py::_verify_batch_size)
             raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x_cl.shape),))
         return BatchNormActCL.apply(x_cl, bn.weight, bn.bias, residual, bn.eps, relu, m,
@@ -323,12 +323,11 @@ def conv2d_module(conv, x, _any_device=False, keep_width=False):
         that holds the 2x2 window of the stride-2 taps (`_S2_TAP`).
     The weight embeddings are index / pad operations of torch, so autograd maps the weight gradient back by itself.
     (_any_device: the CPU test of the embeddings, tests/test_host.py, which substitutes F.conv2d for Conv2dCL.)
-    NRGBD_TRAIN_CONV=vendor keeps the vendor library (developer A/B only)."""
-    import os
+    Shapes none of this covers (other strides / kernel sizes, groups) are the module's own forward."""
     F = torch.nn.functional
     k, st, pd, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
     if not ((x.is_cuda or _any_device) and x.dtype == torch.float32 and conv.groups == 1 and k[0] == k[1] and st[0] == st[1] and d[0] == d[1]
-            and pd[0] == pd[1] and conv.padding_mode == "zeros" and os.environ.get("NRGBD_TRAIN_CONV", "native") == "native"):
+            and pd[0] == pd[1] and conv.padding_mode == "zeros"):
         return conv(x)
     w, y = conv.weight, None
     if k == (3, 3) and st == (1, 1) and pd == d:
@@ -352,11 +351,9 @@ def conv_transpose2d_module(conv, x, _any_device=False):
     on the hand-written kernels: its four sub-pixel phases are 2x2-tap convolutions of the input (`_T2_TAP`); embedded in 3x3
     kernels and stacked along the output channels (4 Cout, ordered co * 4 + a * 2 + b) they are ONE Conv2dCL launch per direction,
     and pixel_shuffle interleaves the phases."""
-    import os
     F = torch.nn.functional
     if not ((x.is_cuda or _any_device) and x.dtype == torch.float32 and conv.groups == 1 and conv.kernel_size == (4, 4) and conv.stride == (2, 2)
-            and conv.padding == (1, 1) and conv.output_padding == (0, 0) and conv.dilation == (1, 1)
-            and os.environ.get("NRGBD_TRAIN_CONV", "native") == "native"):
+            and conv.padding == (1, 1) and conv.output_padding == (0, 0) and conv.dilation == (1, 1)):
         return conv(x)
     w = conv.weight                                  # [Cin, Cout, 4, 4]
     cin, cout = w.shape[:2]

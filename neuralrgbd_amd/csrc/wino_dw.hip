@@ -111,57 +111,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
             step = G >> 3;
         } else { first = b; end = a.ntiles; step = G; }
     }
-    const bool bnf = a.bn.ss != nullptr;       // BatchNorm finalisation fused into this launch
-    // Every workgroup takes a ticket when it is done; the last one reduces the per-workgroup sums and resets the ticket for the
-    // next launch.  NO FENCES: on this chip a release / acquire fence at agent scope writes back / invalidates an XCD's L2
-    // (measured: +59 us per layer, i.e. slower than the separate finalise launch it replaces).  Instead the sums are WRITTEN
-    // with device-scope atomic exchanges (performed at the coherence point, complete when their value returns — before the
-    // barrier that precedes the ticket) and READ with device-scope atomic loads.
-    auto bn_finish = [&]() __attribute__((always_inline)) {
-        __shared__ int s_last;
-        __shared__ double s_red[4][2 * 64];       // fused BatchNorm is offered for Cout = 64 (the K-Net): 4 KB beside 149 KB
-        __syncthreads();
-        if (tid == 0) s_last = atomicAdd(a.bn.ticket, 1) == (int)gridDim.x - 1;
-        __syncthreads();
-        if (!s_last) return;
-        // thread = (quarter of the workgroups, r): r < C sums, r >= C sums of squares; fixed order
-        const int nwg = (int)gridDim.x, C = a.Cout;
-        {
-            const int r = tid & 127, part = tid >> 7;
-            const int g0 = (nwg * part) >> 2, g1 = (nwg * (part + 1)) >> 2;
-            double acc = 0.0;
-            const unsigned long long* wgb = reinterpret_cast<const unsigned long long*>(a.bn.wg);
-            for (int g = g0; g < g1; ++g)
-                acc += __builtin_bit_cast(double, __hip_atomic_load(wgb + (size_t)g * (2 * C) + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            s_red[part][r] = acc;
-        }
-        __syncthreads();
-        for (int c = tid; c < C; c += 512) {
-            const double sum1 = (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
-            const double sum2 = (s_red[0][C + c] + s_red[1][C + c]) + (s_red[2][C + c] + s_red[3][C + c]);
-            const double mean = sum1 / a.bn.count;
-            double var = sum2 / a.bn.count - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)a.bn.eps));
-            const float sc = a.bn.gamma[c] * invstd;
-            a.bn.ss[2 * c] = sc;
-            a.bn.ss[2 * c + 1] = a.bn.beta[c] - (float)mean * sc;
-            if (a.bn.running_mean) {
-                a.bn.running_mean[c] = (1.f - a.bn.momentum) * a.bn.running_mean[c] + a.bn.momentum * (float)mean;
-                const double unbiased = a.bn.count > 1.0 ? var * a.bn.count / (a.bn.count - 1.0) : var;
-                a.bn.running_var[c] = (1.f - a.bn.momentum) * a.bn.running_var[c] + a.bn.momentum * (float)unbiased;
-            }
-        }
-        if (tid == 0) atomicExch(a.bn.ticket, 0);
-    };
-    if (first >= end) {                        // a workgroup without tiles (uniform): zero sums, and still a ticket
-        if (bnf) {
-            for (int r = tid; r < 2 * a.Cout; r += 512)
-                atomicExch(reinterpret_cast<unsigned long long*>(a.bn.wg) + (size_t)blockIdx.x * (2 * a.Cout) + r, 0ull);
-            bn_finish();
-        }
-        return;
-    }
+    if (first >= end) return;                  // a workgroup without tiles (uniform)
     const int count = (end - first + step - 1) / step;
     const unsigned plane = (unsigned)((size_t)a.H * a.W * a.Cin);
     // The per-channel (scale, shift) pairs go to LDS once (identity where the pointer is null).  Loading a stage's pairs from
@@ -191,7 +141,6 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
         for (int b = 0; b < kPcBD; ++b) Bn[b] = wt[b * 256];
         __syncthreads();                               // producers finish stage 0
         int buf = 0;
-        double S1w = 0.0, S2w = 0.0;                   // fused BatchNorm: this lane's channel, summed over the workgroup's tiles
         An[0][0] = *reinterpret_cast<const f32x4*>(Vb + a0);
         An[0][1] = *reinterpret_cast<const f32x4*>(Vb + a1);
         float neg1 = -1.f;
@@ -319,12 +268,11 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                         }
                     }
                     if constexpr (EMIT) {
-                        if (a.stats || bnf) {   // the wave owns its 16 channels: reduce over the 4 lanes (kq) that share a channel
+                        if (a.stats) {   // the wave owns its 16 channels: reduce over the 4 lanes (kq) that share a channel
                             float s1 = S1.x + S1.y, s2 = S2.x + S2.y;
                             s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
                             s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                            S1w += (double)s1; S2w += (double)s2;
-                            if (a.stats && kq == 0) {
+                            if (kq == 0) {
                                 const int row = tl.row0 + (T == 3 ? 1 : 0);
                                 a.stats[(size_t)co * a.rows + row] = s1;
                                 a.stats[(size_t)(a.Cout + co) * a.rows + row] = s2;
@@ -339,12 +287,6 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
             phase(std::integral_constant<int, 3>{});
             tl = tn;
             wt = wt_next;
-        }
-        if (bnf && kq == 0) {                          // co of the LAST tile's channel group: Cout = 64 has one group
-            const int co = tl.cg * 64 + wv * 16 + jj;
-            unsigned long long* wgb = reinterpret_cast<unsigned long long*>(a.bn.wg) + (size_t)blockIdx.x * (2 * a.Cout);
-            atomicExch(wgb + co, __builtin_bit_cast(unsigned long long, S1w));
-            atomicExch(wgb + a.Cout + co, __builtin_bit_cast(unsigned long long, S2w));
         }
     } else {
         // =========================================== producer: tile row pw (8 Winograd tiles) ===========================
@@ -579,7 +521,6 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
         }
         __syncthreads();                       // the consumers' last stage
     }
-    if (bnf) bn_finish();
 }
 
 // w [Cout][Cin][3][3][3] -> U_t = sum_kd Gd[t][kd] (G g_kd G^T) (float64, rounded once) in the kernel's B-operand order
@@ -656,7 +597,7 @@ extern "C" int nrgbd_conv_wino_dw_workgroups(int N, int H, int W, int Cout) {
 
 static int conv_wino_dw_launch(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
                                int res_relu, float* materialized, const float* w_wino, float* y, float* stats, int N,
-                               int H, int W, int Cin, int Cout, const nrgbd::BnFuseArgs& bn, void* stream) {
+                               int H, int W, int Cin, int Cout, void* stream) {
     using namespace nrgbd;
     if (!x || !w_wino || !y) return NRGBD_E_NULL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cin > kDwMaxCin || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
@@ -667,7 +608,7 @@ static int conv_wino_dw_launch(const float* x, const float* x_ss, int x_relu, co
     const long nt = (long)(rows / 2) * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
     WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt, rows,
-                 nullptr, 0, 0, 0, 0, dev_env_int("NRGBD_WINO_ABL"), bn};
+                 nullptr, 0, 0, 0, 0, dev_env_int("NRGBD_WINO_ABL")};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -695,22 +636,5 @@ static int conv_wino_dw_launch(const float* x, const float* x_ss, int x_relu, co
 extern "C" int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
                                       int res_relu, float* materialized, const float* w_wino, float* y, float* stats, int N,
                                       int H, int W, int Cin, int Cout, void* stream) {
-    return conv_wino_dw_launch(x, x_ss, x_relu, res, res_ss, res_relu, materialized, w_wino, y, stats, N, H, W, Cin, Cout,
-                               nrgbd::BnFuseArgs{}, stream);
-}
-
-extern "C" int nrgbd_conv_wino_dw_bn_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
-                                         int res_relu, float* materialized, const float* w_wino, float* y, int N, int H, int W,
-                                         int Cin, int Cout, const float* gamma, const float* beta, float eps, float momentum,
-                                         float* running_mean, float* running_var, double* wg_scratch, int* ticket,
-                                         float* scale_shift, void* stream) {
-    if (!gamma || !beta || !wg_scratch || !ticket || !scale_shift) return NRGBD_E_NULL;
-    if ((running_mean == nullptr) != (running_var == nullptr)) return NRGBD_E_NULL;
-    if (Cout != 64) return NRGBD_E_SHAPE;          // a lane keeps ONE channel's sums across the workgroup's tiles
-    nrgbd::BnFuseArgs bn;
-    bn.gamma = gamma; bn.beta = beta; bn.running_mean = running_mean; bn.running_var = running_var;
-    bn.ss = scale_shift; bn.wg = wg_scratch; bn.ticket = ticket;
-    bn.count = (double)N * H * W; bn.eps = eps; bn.momentum = momentum;
-    return conv_wino_dw_launch(x, x_ss, x_relu, res, res_ss, res_relu, materialized, w_wino, y, nullptr, N, H, W, Cin, Cout, bn,
-                               stream);
+    return conv_wino_dw_launch(x, x_ss, x_relu, res, res_ss, res_relu, materialized, w_wino, y, stats, N, H, W, Cin, Cout, stream);
 }

@@ -21,19 +21,6 @@ constexpr int kPcNPF = (kPcItems + 63) / 64;    // per producer lane and stage (
 #endif
 constexpr int kPcBD = 7, kPcNB = 8;             // weight ring: distance / slots
 
-// BatchNorm finalisation fused into the convolution (wino_dw.hip): the last workgroup to finish turns the per-workgroup fp64
-// partial sums into (scale, shift) and updates the running statistics — no separate nrgbd_bn_finalize_cm launch, and 2C x
-// workgroups doubles of partials instead of 2C x tiles floats.  ss == nullptr: not fused (per-tile partials in `stats`).
-struct BnFuseArgs {
-    const float* gamma = nullptr; const float* beta = nullptr;
-    float* running_mean = nullptr; float* running_var = nullptr;   // both or neither
-    float* ss = nullptr;          // out: [Cout][2] (scale, shift)
-    double* wg = nullptr;         // scratch: [gridDim.x][2*Cout] per-workgroup sums
-    int* ticket = nullptr;        // zero before the launch; reset to zero by the finalising workgroup
-    double count = 0.0;           // elements per channel (N*H*W)
-    float eps = 0.f, momentum = 0.f;
-};
-
 struct WinoPcArgs {
     const float* x;       // [N][H][W][Cin] raw input (pre-activation); N = depth slices when KD = 3
     const float* x_ss;    // [Cin][2] (scale, shift) applied to x, or null
@@ -53,7 +40,6 @@ struct WinoPcArgs {
                                   // the R-Net writes into concat buffers and pads 67 / 96 outputs to the 64-column groups
     int abl;              // developer ablation bits, honoured by -DNRGBD_DEV builds only: 1 = producers only, 2 = consumers only,
                           // 4 = no transform, 8 = no publish, 16 / 32 = s_setprio 2 for the consumers / producers
-    BnFuseArgs bn;        // wino_dw.hip only
 };
 
 struct PcTile { int n, y0, x0, py, px, cg, row; };

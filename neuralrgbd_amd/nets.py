@@ -16,7 +16,6 @@ BatchNorm2d are built with track_running_stats=False, the two residual-shortcut 
 eleven BatchNorm3d keep (and update) running statistics.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -121,12 +120,6 @@ def _packed_s2(owner, conv):
         hit = (key, ops.conv_s2_pack(w.detach().contiguous()))
         cache[("s2", id(conv))] = hit
     return hit[1]
-
-
-def _small_convs_native():
-    """The stride-2 3x3 and the 1x1 convolutions of the trunk on csrc/conv2d.hip (round 2); NRGBD_CNN_SMALL=vendor keeps MIOpen /
-    rocBLAS for them (A/B)."""
-    return os.environ.get("NRGBD_CNN_SMALL", "native") != "vendor"
 
 
 def invalidate_packed_weights(module):
@@ -318,10 +311,9 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
                 and conv.in_channels % 16 == 0 and (conv.out_channels, d) in self._MFMA_SHAPES)
         # Winograd-domain kernel (csrc/wino_pc.hip) for every layer it covers (Cin % 32 == 0, Cout % 64 == 0: all but the
         # 32-channel half-resolution layers): 0.116 vs 0.193 ms (64 -> 64), 0.37 vs 0.69 ms (128 -> 128), 0.80 vs 1.62 ms
-        # (320 -> 128) at config B, and 2.4-3x at the 64x96 grid where 16x16 tiles under-fill the chip.  NRGBD_CNN_CONV=direct
-        # keeps conv2d.hip for A/B.
+        # (320 -> 128) at config B, and 2.4-3x at the 64x96 grid where 16x16 tiles under-fill the chip; conv2d.hip (direct) serves
+        # the 32-channel half-resolution layers.
         wino = (mfma and d in (1, 2) and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
-                and os.environ.get("NRGBD_CNN_CONV", "wino") != "direct"
                 and ops.conv_wino_supported(a.z.shape[0], a.z.shape[1], a.z.shape[2], conv.in_channels, conv.out_channels, 1))
         if wino:
             z, st, mat = ops.conv_wino(a.z, _packed_wino(self, conv), conv.out_channels, 1, d, x_ss=a.ss, x_relu=a.relu,
@@ -335,7 +327,7 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
             mat = a.z if (a.ss is None and a.r is None and not a.relu) else \
                 ops.nhwc_act(a.z, a.ss, a.relu, a.r, a.r_ss, a.r_relu)
             s2 = (conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and d == 1
-                  and mat.shape[1] % 2 == 0 and mat.shape[2] % 2 == 0 and conv.out_channels in (32, 64) and _small_convs_native())
+                  and mat.shape[1] % 2 == 0 and mat.shape[2] % 2 == 0 and conv.out_channels in (32, 64))
             if s2:   # stride 2 = a 2x2-window convolution on the space-to-depth image of the input
                 z, st = ops.conv2d_taps(ops.space_to_depth2(mat), _packed_s2(self, conv), conv.out_channels, 4,
                                         want_stats=_needs_stats(bn))
@@ -353,7 +345,7 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         if stride != 1:
             m = m[:, ::stride, ::stride, :]
         N, H, W, C = m.shape
-        if C % 16 == 0 and conv.out_channels in (32, 64, 128) and _small_convs_native():
+        if C % 16 == 0 and conv.out_channels in (32, 64, 128):
             z, st = ops.conv2d_taps(m.contiguous(), _packed_weights(self, conv), conv.out_channels, 1, want_stats=_needs_stats(bn))
         else:
             z = torch.mm(m.reshape(-1, C), conv.weight.view(conv.out_channels, C).t()).view(N, H, W, conv.out_channels)
@@ -373,21 +365,18 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         """Inference on the GPU -> the matrix-core trunk (forward_channels_last).  With the 8x16-pixel tiles of the persistent
         Winograd kernel it wins at every SURVEY grid (round 2: trunk 2.6 vs 3.7 ms at 256x384 images, 11.7 vs 19.5 ms at
         1024x768; with round 1's 16x16-tile direct kernel the small grids under-filled the chip and stayed on the vendor
-        convolutions).  NRGBD_CNN=vendor|mfma overrides."""
-        if not (x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32):
-            return False
-        return os.environ.get("NRGBD_CNN", "auto") != "vendor"
+        convolutions)."""
+        return x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32
 
     def forward_channels_last(self, x):
         """Inference on the hand-written kernels: x [N,3,H,W] -> (layer1 [N,H/2,W/2,32], feat [N,H/4,W/4,F]), both
         channels-last.  Same graph as forward() (psm_submodule.py:136-167); every 3x3 stride-1 conv is one fused pass
         (conv on the fp32 matrix cores, BatchNorm statistics in its epilogue, normalise + ReLU + residual in the next
         layer's loader); the stride-2 3x3 convs run as 2x2-window convolutions on the space-to-depth image, the 1x1 convs as
-        the 1-tap form of the same kernel.  What is left of torch here: SPP average pooling, the bilinear up-sampling of its four
-        tiny maps and one concat (NRGBD_CNN_SMALL=vendor keeps MIOpen / rocBLAS for the small convs as the A/B)."""
+        the 1-tap form of the same kernel.  What is left of torch here: the SPP average pooling of the deep map."""
         from . import ops
         conv, bn = self.firstconv[0]
-        if x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and _small_convs_native():
+        if x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
             # 3 -> 32, stride 2: the image as a 12(+4)-channel space-to-depth tensor, then a 2x2-window convolution
             z, st = ops.conv2d_taps(ops.space_to_depth2(x.contiguous(), nchw=True), _packed_s2(self, conv), conv.out_channels, 4,
                                     want_stats=_needs_stats(bn))
@@ -428,14 +417,11 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         for i in (4, 3, 2, 1):
             branch = getattr(self, "branch%d" % i)
             pool = pools[self.SPP_WINDOWS[i - 1]]
-            if _small_convs_native():                                      # 1x1 conv + BatchNorm + ReLU on the tiny map
-                pb = self._pointwise_bn_cl(branch[1], pool.permute(0, 2, 3, 1).contiguous())
-                if pb.ss is not None and os.environ.get("NRGBD_SPP", "fused") == "fused":
-                    fused.append((pb.z, pb.ss))                            # normalise + ReLU at the taps of spp_concat
-                    continue
-                y = ops.nhwc_act(pb.z, pb.ss, True).permute(0, 3, 1, 2)    # channels-last memory, NCHW view
-            else:
-                y = _conv_bn_act(pool.contiguous(), branch[1], relu=True).contiguous(memory_format=torch.channels_last)
+            pb = self._pointwise_bn_cl(branch[1], pool.permute(0, 2, 3, 1).contiguous())   # 1x1 conv + BatchNorm statistics on the tiny map
+            if pb.ss is not None:
+                fused.append((pb.z, pb.ss))                                # normalise + ReLU at the taps of spp_concat
+                continue
+            y = ops.nhwc_act(pb.z, pb.ss, True).permute(0, 3, 1, 2)        # eval-mode norm: channels-last memory, NCHW view
             y = F.interpolate(y, size=(h, w), mode="bilinear", align_corners=True)
             pyramid.append(y.permute(0, 2, 3, 1))                          # channels-last in memory already
         if len(fused) == 4:
@@ -446,7 +432,7 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
             cat = torch.cat([quarter, deep] + pyramid, dim=3)              # [N,h,w,320]
         y, _ = self._conv_bn_cl(self.lastconv[0], _Act(cat), relu=True)
         head = self.lastconv[2]
-        if head.out_channels in (32, 64, 128) and _small_convs_native():   # 1x1 head; BatchNorm + ReLU of lastconv[0] in its loader
+        if head.out_channels in (32, 64, 128):   # 1x1 head; BatchNorm + ReLU of lastconv[0] in its loader
             feat, _ = ops.conv2d_taps(y.z, _packed_weights(self, head), head.out_channels, 1, x_ss=y.ss, x_relu=True, want_stats=False)
         else:
             y = ops.nhwc_act(y.z, y.ss, True)
@@ -547,18 +533,6 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
             cache[id(conv)] = hit
         return hit[1]
 
-    def _packed_wino(self, conv):
-        """Winograd-domain weights U = G g G^T of a 64 -> 64 layer, re-packed only when its weight changes."""
-        from . import ops
-        cache = self.__dict__.setdefault("_wp_cache", {})
-        w = conv.weight
-        key = (w.data_ptr(), w._version, str(w.device), "wino")
-        hit = cache.get(("wino", id(conv)))
-        if hit is None or hit[0] != key:
-            hit = (key, ops.conv3d_wino_pack(w.detach().contiguous()))
-            cache[("wino", id(conv))] = hit
-        return hit[1]
-
     def _bn_scale_shift(self, bn, stats, count, cm=False):
         """(scale, shift) of a BatchNorm3d: batch statistics in train mode (the reference never leaves it,
         SURVEY §0.2) incl. the running-statistics side effect; running statistics in eval mode.
@@ -576,19 +550,24 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 
-    def forward_channels_last(self, vol):
+    def forward_channels_last(self, vol, generation=None):
         """Inference on the hand-written kernels: vol [D,H,W,Cin] (channels-last) -> gain [D,H,W].
 
-        One fused pass per layer (conv3d.hip): conv on the fp32 matrix cores, BatchNorm statistics in
-        its epilogue, normalise + affine + ReLU + residual applied by the next layer's loader.
-        Same graph as forward() (basic.py:113-132):
+        One fused pass per layer: conv on the fp32 matrix cores, BatchNorm statistics in its epilogue, normalise + affine +
+        ReLU + residual applied by the next layer's loader.  Same graph as forward() (basic.py:113-132):
             c0 = relu(bn(conv(relu(bn(conv(vol))))))
             c_i = bn(conv(relu(bn(conv(c_{i-1}))))) + c_{i-1}     i = 1..4
             gain = conv(relu(bn(conv(c4))))
-        """
+        The 3x3x3 layers run on wino_dw.hip (Winograd in all three dimensions: F(2,3) along depth on top of the in-plane
+        F(2x2,3x3), 8 multiplies per output voxel) where the grid is whole 8x16 tiles and D is even — every configuration of
+        the path —, on wino_pc.hip (12 multiplies) where only that fits, on conv3d.hip (direct, 27) otherwise.
+        generation: None = that choice; "wino_pc" / "direct" = start the choice at that kernel (tests compare the kernels on
+        the whole stack; nothing in the package passes it)."""
         from . import ops
         if self.if_normalize or self.up_sample_ratio is not None:
             raise NotImplementedError("if_normalize / up_sample_ratio are never enabled by the reference scripts")
+        if generation not in (None, "wino_pc", "direct"):
+            raise ValueError("generation: None | 'wino_pc' | 'direct'")
         D, H, W, C = vol.shape
         if C != self.in_channels:
             raise AssertionError("Input volume should have correct # of channels !")
@@ -596,41 +575,15 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         count = D * H * W
         need_stats = lambda bn: bn.training or not bn.track_running_stats
 
-        import os
-        # the ten 64 -> 64 layers in the Winograd domain: wino_dw.hip (round 3: F(2,3) along depth on top of the in-plane
-        # F(2x2,3x3), 8 multiplies per output voxel) where the grid is whole tiles and D is even — every configuration of the
-        # path —, wino_pc.hip (12 multiplies) otherwise.  NRGBD_KNET = wino2 (wino_pc.hip everywhere) | wino64 (only its
-        # 64 -> 64 layers) | wino1 (conv3d_wino.hip) | direct (conv3d.hip) select the older generations for A/B.
-        mode = os.environ.get("NRGBD_KNET", "auto")
-        wino = mode != "direct"
-        dw_layers = os.environ.get("NRGBD_KNET_DW", "16,64")  # which input widths take wino_dw.hip: "16,64" | "64" | ""
-        dw_cin = {int(v) for v in dw_layers.split(",") if v} if mode == "auto" else set()
-        # BatchNorm finalisation inside the conv launch (nrgbd_conv_wino_dw_bn_f32, NRGBD_KNET_BN=fused) is built and tested but
-        # NOT the default: measured 42.70 vs 42.79 ms per frame at config B and 6.54 vs 6.41 at S — the last workgroup's serial
-        # reduction costs what the tiny separate launch costs
-        fuse_bn = os.environ.get("NRGBD_KNET_BN", "separate") == "fused"
-
         def run(i, x, x_ss, x_relu, res=None, materialize=False):
             conv, bn = L[i]
             cm = False
-            if (conv.in_channels in dw_cin and conv.out_channels == 64
+            if (generation is None and conv.in_channels in (16, 64) and conv.out_channels == 64
                     and ops.conv_wino_dw_supported(D, H, W, conv.in_channels, 64)):
-                if need_stats(bn) and fuse_bn:
-                    # BatchNorm3d finalisation inside the conv launch (last workgroup reduces the per-workgroup sums)
-                    upd = bn.training and bn.track_running_stats
-                    if upd:
-                        bn.num_batches_tracked += 1
-                    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                    return ops.conv_wino_dw_bn(x, _packed_wino_dw(self, conv), bn.weight.detach(), bn.bias.detach(), bn.eps,
-                                               momentum, bn.running_mean if upd else None, bn.running_var if upd else None,
-                                               x_ss=x_ss, x_relu=x_relu, res=res, materialize=materialize)
                 y, st, mat = ops.conv_wino_dw(x, _packed_wino_dw(self, conv), 64, x_ss=x_ss, x_relu=x_relu, res=res,
                                               materialize=materialize, want_stats=need_stats(bn))
                 cm = True
-            elif wino and conv.in_channels == 64 and mode == "wino1":
-                y, st, mat = ops.conv3d_wino(x, self._packed_wino(conv), x_ss=x_ss, x_relu=x_relu, res=res,
-                                             materialize=materialize, want_stats=need_stats(bn))
-            elif wino and (conv.in_channels == 64 or (conv.in_channels == 16 and res is None and mode != "wino64")) \
+            elif generation != "direct" and (conv.in_channels == 64 or (conv.in_channels == 16 and res is None)) \
                     and ops.conv_wino_supported(D, H, W, conv.in_channels, 64, 3):
                 # 64 -> 64 (12 stages per tile) and the first layer 16 -> 64 (3 stages: the odd-stage-count instantiation)
                 y, st, mat = ops.conv_wino(x, _packed_wino(self, conv), 64, 3, x_ss=x_ss, x_relu=x_relu, res=res,
@@ -773,11 +726,8 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         """The R-Net on the hand-written kernels (inference, batch 1 or 2) at EVERY grid (round 3; rounds 1-2 handed grids below
         64 16x16-tiles — configs S and K — to MIOpen): the six conv2d_leakyRelu layers on the Winograd kernel's R-Net form
         (csrc/wino_pc.hip, 8x16-pixel tiles of a persistent launch fill the chip at every grid), the transposed convolutions
-        and the log-softmax layer on csrc/conv2d.hip.  NRGBD_RNET=vendor keeps the vendor path as the A/B; widths without an
-        instantiation (D not in {64, 128}) and autograd use it too."""
-        import os
-        mode = os.environ.get("NRGBD_RNET", "auto")
-        if mode == "vendor" or self._widths() is None or not dpv.is_cuda or torch.is_grad_enabled() or dpv.shape[0] not in (1, 2):
+        and the log-softmax layer on csrc/conv2d.hip.  Widths without an instantiation (D not in {64, 128}) take the module graph."""
+        if self._widths() is None or not dpv.is_cuda or torch.is_grad_enabled() or dpv.shape[0] not in (1, 2):
             return False
         return True
 
@@ -834,8 +784,6 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
             """Winograd-domain stream of a conv2d_leakyRelu layer for the persistent kernel's R-Net form, widths padded with zero
             weights to Cin % 32 == 0 (the buffer it reads) and Cout % 64 == 0; (stream, bias, packed columns, valid columns)."""
             c = m[0]
-            if os.environ.get("NRGBD_RNET_WINO", "1") == "0":
-                return None
             w, b = c.weight.detach(), c.bias.detach()
             cin_p, cout_p = pad32(w.shape[1]), (w.shape[0] + 63) // 64 * 64
             wp = w.new_zeros(cout_p, cin_p, 3, 3)

@@ -330,43 +330,6 @@ def conv3d(x, w_packed, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu
     return y, stats, mat
 
 
-def conv3d_wino_pack(w):
-    """w [64, 64, 3, 3, 3] -> Winograd-domain B-operand stream of nrgbd_conv3d_wino_f32: U = G g G^T over (ky, kx) in
-    float64, rounded once to fp32, laid out [stage = cb*3 + kd][xi = 4*xi_y + xi_x][wave][lane = kq*16 + j][e] with
-    ci = cb*16 + 4*kq + e and co = 16*wave + j."""
-    w = _need(w, "w")
-    if tuple(w.shape) != (64, 64, 3, 3, 3):
-        raise ValueError("conv3d_wino_pack expects [64, 64, 3, 3, 3], got %s" % (tuple(w.shape),))
-    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
-    U = torch.einsum("ay,ockyx,bx->ockab", G, w.detach().double(), G).reshape(64, 64, 3, 16)      # [co, ci, kd, xi]
-    U = U.reshape(4, 16, 4, 4, 4, 3, 16)                     # co -> (wave, j); ci -> (cb, kq, e)
-    U = U.permute(2, 5, 6, 0, 3, 1, 4).contiguous()          # [cb, kd, xi, wave, kq, j, e]
-    return U.to(torch.float32).reshape(-1)
-
-
-def conv3d_wino_workgroups(D, H, W):
-    return int(_lib.load().nrgbd_conv3d_wino_workgroups(D, H, W))
-
-
-def conv3d_wino(x, w_wino, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False, materialize=False, want_stats=True):
-    """Channels-last 3x3x3 convolution 64 -> 64 with the in-plane dimensions in the Winograd domain (same arguments and
-    results as conv3d): x [D,H,W,64] -> (y [D,H,W,64], stats | None, materialized | None)."""
-    x = _need(x, "x")
-    D, H, W, Cin = x.shape
-    if Cin != 64:
-        raise ValueError("conv3d_wino: 64 input channels, got %d" % Cin)
-    y = torch.empty((D, H, W, 64), dtype=torch.float32, device=x.device)
-    stats = torch.empty((conv3d_wino_workgroups(D, H, W), 128), dtype=torch.float32, device=x.device) if want_stats else None
-    mat = torch.empty_like(x) if materialize else None
-    if res is not None:
-        res = _need(res, "res", x.shape)
-    with torch.cuda.device(x.device):
-        rc = _lib.load().nrgbd_conv3d_wino_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(mat),
-                                                _p(w_wino), _p(y), _p(stats), D, H, W, _stream(x))
-    _lib.check(rc, "nrgbd_conv3d_wino_f32")
-    return y, stats, mat
-
-
 def conv_wino_pack(w, transposed=False):
     """w [Cout, Cin, 3, 3, 3] (kd = 3) or [Cout, Cin, 3, 3] (kd = 1) -> Winograd-domain B-operand stream of nrgbd_conv_wino_f32:
     U = G g G^T over (ky, kx) in float64, rounded once to fp32, laid out [cg][stage = cb*kd + depth tap][xi = 4*xi_y + xi_x]
@@ -493,47 +456,6 @@ def conv_wino_dw(x, w_wino, Cout, x_ss=None, x_relu=False, res=None, res_ss=None
                                                  _p(w_wino), _p(y), _p(stats), N, H, W, Cin, Cout, _stream(x))
     _lib.check(rc, "nrgbd_conv_wino_dw_f32")
     return y, stats, mat
-
-
-_bn_tickets = {}
-
-
-def _bn_ticket(device):
-    """One zero-initialised int per (device, stream): the finalising workgroup of a fused-BatchNorm launch resets it, so it
-    serves every such launch of that stream, hipGraph replays included."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    t = _bn_tickets.get(key)
-    if t is None:
-        t = torch.zeros(1, dtype=torch.int32, device=device)
-        _bn_tickets[key] = t
-    return t
-
-
-def conv_wino_dw_bn(x, w_wino, gamma, beta, eps, momentum, running_mean=None, running_var=None, x_ss=None, x_relu=False,
-                    res=None, res_ss=None, res_relu=False, materialize=False):
-    """conv_wino_dw (Cout = 64) with the BatchNorm3d finalisation fused into the launch (nrgbd_conv_wino_dw_bn_f32):
-    -> (y [D,H,W,64], scale_shift [64,2], materialized | None); running statistics updated in place when given."""
-    x = _need(x, "x")
-    N, H, W, Cin = x.shape
-    Cout = 64
-    y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
-    mat = torch.empty_like(x) if materialize else None
-    if res is not None:
-        res = _need(res, "res", x.shape)
-    if w_wino.numel() != (Cin // 16) * 4 * 16 * 1024:
-        raise ValueError("conv_wino_dw_bn: packed weights do not match Cin=%d Cout=64" % Cin)
-    nwg = int(_lib.load().nrgbd_conv_wino_dw_workgroups(N, H, W, Cout))
-    if nwg <= 0:
-        raise ValueError("conv_wino_dw_bn: unsupported shape %s" % (tuple(x.shape),))
-    wg = torch.empty((nwg, 2 * Cout), dtype=torch.float64, device=x.device)
-    ss = torch.empty((Cout, 2), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        rc = _lib.load().nrgbd_conv_wino_dw_bn_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(mat),
-                                                    _p(w_wino), _p(y), N, H, W, Cin, Cout, _p(gamma), _p(beta), float(eps),
-                                                    float(momentum), _p(running_mean), _p(running_var), _p(wg),
-                                                    _p(_bn_ticket(x.device)), _p(ss), _stream(x))
-    _lib.check(rc, "nrgbd_conv_wino_dw_bn_f32")
-    return y, ss, mat
 
 
 def conv3d_wgrad(x, gy):

@@ -289,7 +289,7 @@ def test_spp_concat_vs_torch():
 
 
 @pytest.mark.parametrize("N,bh,bw,H,W,C", [(5, 1, 1, 64, 96, 32), (5, 2, 3, 64, 96, 32), (2, 4, 6, 64, 96, 32), (1, 8, 12, 64, 96, 32),
-                                           (2, 3, 4, 17, 23, 8), (1, 5, 5, 5, 5, 4), (1, 7, 2, 1, 9, 4)])
+                                           (2, 3, 4, 17, 23, 8), (1, 5, 5, 5, 5, 4), (1, 7, 2, 1, 9, 4), (1, 2, 2, 40, 56, 128), (1, 3, 3, 12, 12, 256)])
 def test_upsample_bilinear_align_corners_forward_and_adjoint(N, bh, bw, H, W, C):
     """nrgbd_upsample_bilinear_ac (training path of the SPP branches, psm_submodule.py:153-158) against F.interpolate(bilinear,
     align_corners=True) and ITS autograd backward in float64: forward and the exact adjoint, through autograd.UpsampleBilinearCL."""
@@ -305,7 +305,7 @@ def test_upsample_bilinear_align_corners_forward_and_adjoint(N, bh, bw, H, W, C)
     e_f, e_b = (y.double() - want).abs().max().item(), (gx.double() - gx64).abs().max().item()
     print("[parity] upsample (align_corners) %dx%d -> %dx%d C%d: forward max|d| %.2e, adjoint max|d| %.2e (|g|max %.1f)" %
           (bh, bw, H, W, C, e_f, e_b, gx64.abs().max().item()))
-    assert e_f < 2e-6 and e_b < 2e-5 * max(1.0, gx64.abs().max().item())
+    assert e_f < 5e-6 and e_b < 2e-5 * max(1.0, gx64.abs().max().item())
     # <adjoint(gy), x> == <gy, forward(x)> (the kernel pair is an exact adjoint pair up to fp32 summation)
     lhs, rhs = (gx.double() * x.detach().double()).sum().item(), (gy.double() * y.detach().double()).sum().item()
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(rhs))

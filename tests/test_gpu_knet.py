@@ -144,51 +144,6 @@ def test_avgpool8_and_feature_cnn_fused_vs_modules():
         assert torch.allclose(b1.float(), b2.float(), rtol=1e-3, atol=1e-4), n1
 
 
-# ----------------------------------------------------------------------------- Winograd-domain 64 -> 64 layer (conv3d_wino.hip)
-@pytest.mark.parametrize("D,H,W", [(4, 16, 32), (2, 8, 16), (5, 13, 21), (3, 10, 40), (8, 24, 48)])
-def test_conv3d_wino_plain_vs_torch(D, H, W):
-    """F(2x2,3x3) in the plane x 3 depth taps on the matrix cores vs F.conv3d in float64 (the direct kernel's error is
-    printed beside it: both are fp32 roundings of the same exact result)."""
-    from neuralrgbd_amd import ops
-    g = torch.Generator().manual_seed(D * 1000 + H)
-    x = torch.randn(64, D, H, W, generator=g).to(DEV)
-    w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).to(DEV)
-    want = F.conv3d(x[None].double(), w.double(), padding=1)[0]
-    y, stats, _ = ops.conv3d_wino(_cl(x), ops.conv3d_wino_pack(w))
-    yd, _, _ = ops.conv3d(_cl(x), ops.conv3d_pack_weights(w))
-    err = (y.permute(3, 0, 1, 2).double() - want).abs().max().item()
-    err_d = (yd.permute(3, 0, 1, 2).double() - want).abs().max().item()
-    scale = want.abs().max().item()
-    print("[parity] conv3d_wino %dx%dx%d max|d vs fp64|=%.3e (direct kernel %.3e, |y|max %.2f)" % (D, H, W, err, err_d, scale))
-    assert err < 2e-5 * max(1.0, scale)
-    s = stats.double().sum(0)
-    assert torch.allclose(s[:64], want.sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
-    assert torch.allclose(s[64:], (want ** 2).sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
-
-
-def test_conv3d_wino_fused_prologue_and_materialize():
-    from neuralrgbd_amd import ops
-    D, H, W, C = 4, 10, 20, 64
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(C, D, H, W, generator=g).to(DEV)
-    r = torch.randn(C, D, H, W, generator=g).to(DEV)
-    w = (torch.randn(64, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
-    ss = torch.randn(C, 2, generator=g).to(DEV)
-    rs = torch.randn(C, 2, generator=g).to(DEV)
-    act = torch.relu(x * ss[:, 0, None, None, None] + ss[:, 1, None, None, None]) \
-        + torch.relu(r * rs[:, 0, None, None, None] + rs[:, 1, None, None, None])
-    want = F.conv3d(act[None], w, padding=1)[0]
-    wp = ops.conv3d_wino_pack(w)
-    y, _, mat = ops.conv3d_wino(_cl(x), wp, x_ss=ss, x_relu=True, res=_cl(r), res_ss=rs, res_relu=True, materialize=True)
-    assert (y.permute(3, 0, 1, 2) - want).abs().max().item() < 2e-4
-    assert (mat.permute(3, 0, 1, 2) - act).abs().max().item() < 1e-5
-    act2 = (x * ss[:, 0, None, None, None] + ss[:, 1, None, None, None]) + r
-    y2, _, _ = ops.conv3d_wino(_cl(x), wp, x_ss=ss, res=_cl(r))
-    assert (y2.permute(3, 0, 1, 2) - F.conv3d(act2[None], w, padding=1)[0]).abs().max().item() < 2e-4
-    y3, _, _ = ops.conv3d_wino(_cl(x), wp, x_ss=ss, res=_cl(r))
-    assert torch.equal(y2, y3)                                  # deterministic
-
-
 # ----------------------------------------------------------------------------- generation 2: producer / consumer waves (wino_pc.hip)
 @pytest.mark.parametrize("D,H,W", [(4, 16, 32), (2, 8, 16), (5, 13, 21), (3, 10, 40), (8, 24, 48), (1, 8, 16), (40, 40, 72)])
 def test_conv_wino_pc_3d_plain_vs_torch(D, H, W):
@@ -208,9 +163,9 @@ def test_conv_wino_pc_3d_plain_vs_torch(D, H, W):
     s = stats.double().sum(1)
     assert torch.allclose(s[:64], want.sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
     assert torch.allclose(s[64:], (want ** 2).sum((1, 2, 3)), rtol=1e-5, atol=1e-3)
-    y1, _, _ = ops.conv3d_wino(_cl(x), ops.conv3d_wino_pack(w))
-    print("[parity] conv_wino_pc vs generation 1: max|d|=%.3e" % (y - y1).abs().max().item())
-    assert (y - y1).abs().max().item() < 1e-5 * max(1.0, scale)
+    yd, _, _ = ops.conv3d(_cl(x), ops.conv3d_pack_weights(w))
+    print("[parity] conv_wino_pc vs the direct kernel: max|d|=%.3e" % (y - yd).abs().max().item())
+    assert (y - yd).abs().max().item() < 2e-5 * max(1.0, scale)
 
 
 def test_conv_wino_pc_3d_fused_prologue_and_materialize():
@@ -344,50 +299,21 @@ def test_conv_wino_dw_pack_and_shape_contract():
             ops.conv_wino_dw(torch.zeros(D, H, W, 64, device=DEV), w, 64)
 
 
-def test_knet_stack_dw_vs_generation_2(monkeypatch):
-    """The whole K-Net on wino_dw.hip (default) vs the same stack on wino_pc.hip: same graph, rounding order only."""
+def test_knet_stack_dw_vs_the_other_kernels():
+    """The whole K-Net on wino_dw.hip (what the path runs) vs the same stack on wino_pc.hip and on the direct kernel
+    (`generation=`: a test-only argument): same graph, rounding order only."""
     from neuralrgbd_amd import nets
     torch.manual_seed(0)
     net = nets.KalmanGainNet(16, feature_dim=64).to(DEV)
     vol = torch.randn(8, 16, 32, 16, device=DEV)
     with torch.no_grad():
-        monkeypatch.setenv("NRGBD_KNET", "wino2")
-        a = net.forward_channels_last(vol)
-        monkeypatch.setenv("NRGBD_KNET", "auto")
+        a = net.forward_channels_last(vol, generation="wino_pc")
         b = net.forward_channels_last(vol)
-        monkeypatch.setenv("NRGBD_KNET_DW", "64")
-        c = net.forward_channels_last(vol)
-    print("[parity] K-Net stack: dw vs generation 2 max|d| %.3e (|gain| max %.2f); first layer on generation 2: %.3e" %
+        c = net.forward_channels_last(vol, generation="direct")
+    print("[parity] K-Net stack: dw vs wino_pc max|d| %.3e (|gain| max %.2f); direct kernel vs wino_pc: %.3e" %
           ((a - b).abs().max().item(), a.abs().max().item(), (a - c).abs().max().item()))
     assert (a - b).abs().max().item() < 2e-4 * max(1.0, a.abs().max().item())
     assert (a - c).abs().max().item() < 2e-4 * max(1.0, a.abs().max().item())
-
-
-def test_conv_wino_dw_fused_batchnorm_finalisation():
-    """nrgbd_conv_wino_dw_bn_f32: (scale, shift) and the running statistics from the per-workgroup fp64 sums reduced by the last
-    workgroup inside the conv launch == the separate path (per-tile partials + nrgbd_bn_finalize_cm) and torch's batch_norm
-    statistics; the ticket is reset (a second launch gives the same answer); grids with more / fewer tile pairs than CUs."""
-    from neuralrgbd_amd import ops
-    g = torch.Generator().manual_seed(21)
-    for (D, H, W) in ((4, 16, 32), (40, 40, 80), (64, 8, 16)):
-        x = torch.randn(64, D, H, W, generator=g).to(DEV)
-        w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).to(DEV)
-        gamma, beta = torch.rand(64, generator=g).to(DEV) + 0.5, torch.randn(64, generator=g).to(DEV)
-        wp = ops.conv_wino_dw_pack(w)
-        y0, st, _ = ops.conv_wino_dw(_cl(x), wp, 64)
-        rm0, rv0 = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
-        ss0 = ops.bn_finalize_cm(st, D * H * W, gamma, beta, 1e-5, 0.1, rm0, rv0)
-        for rep in range(2):
-            rm1, rv1 = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
-            y1, ss1, _ = ops.conv_wino_dw_bn(_cl(x), wp, gamma, beta, 1e-5, 0.1, rm1, rv1)
-            assert torch.equal(y0, y1)
-            assert (ss1 - ss0).abs().max().item() <= 2e-6 * ss0.abs().max().item()
-            assert (rm1 - rm0).abs().max().item() < 1e-6 and (rv1 - rv0).abs().max().item() < 1e-6
-        yd = y0.permute(3, 0, 1, 2).double()
-        mean, var = yd.mean((1, 2, 3)), yd.var((1, 2, 3), unbiased=False)
-        sc = gamma.double() / torch.sqrt(var + 1e-5)
-        want = torch.stack((sc, beta.double() - mean * sc), 1)
-        assert (ss1.double() - want).abs().max().item() < 1e-5 * want.abs().max().item()
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 3, 3), (128, 64, 3, 3), (128, 320 - 64, 3, 3), (64, 64, 3, 3, 3)])

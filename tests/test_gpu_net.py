@@ -32,11 +32,8 @@ def _stream(model, cam, d_candi, windows, R_net=False):
     return outs
 
 
-@pytest.mark.parametrize("cnn", ["mfma", "vendor"])
-def test_two_frame_stream_vs_golden(golden_net, monkeypatch, cnn):
-    """Both executions of the feature CNN (hand-written matrix-core trunk / vendor convolutions + fused BatchNorm;
-    the default picks by grid size) against the reference's outputs."""
-    monkeypatch.setenv("NRGBD_CNN", cnn)
+def test_two_frame_stream_vs_golden(golden_net):
+    """Two frames (first-frame and update branch) through the path against the reference's own outputs."""
     n, g = gen_golden.NET, golden_net
     cam = camera.scannet_intrinsics(n["W"] // 4, n["H"] // 4)
     d_candi = np.linspace(n["d_min"], n["d_max"], n["D"])
@@ -62,10 +59,9 @@ def test_two_frame_stream_vs_golden(golden_net, monkeypatch, cnn):
     assert r_mean < 1e-4 and r_mism == 0
 
 
-def test_update_frame_vs_cpu_oracle_config_S_small(monkeypatch):
+def test_update_frame_vs_cpu_oracle_config_S_small():
     """One update-branch frame at a second shape/seed against the oracle run on this machine's CPU."""
     H, W, D = 256, 256, 24
-    monkeypatch.setenv("NRGBD_CNN", "mfma")
     cam = camera.scannet_intrinsics(W // 4, H // 4)
     d_candi = np.linspace(0.1, 5, D)
     model, sd = _model(cam, d_candi, 10.0, seed=1)
@@ -80,9 +76,7 @@ def test_update_frame_vs_cpu_oracle_config_S_small(monkeypatch):
     assert a[2] == 0 and b[2] == 0
 
 
-@pytest.mark.parametrize("cnn", ["mfma", "vendor"])
-def test_rendered_scene_vs_golden(golden_scene, monkeypatch, cnn):
-    monkeypatch.setenv("NRGBD_CNN", cnn)
+def test_rendered_scene_vs_golden(golden_scene):
     s, g = gen_golden.SCENE, golden_scene
     cam = camera.scannet_intrinsics(s["W"] // 4, s["H"] // 4)
     cam_full = camera.scannet_intrinsics(s["W"], s["H"])

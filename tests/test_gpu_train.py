@@ -333,26 +333,25 @@ def test_conv2d_autograd_function_vs_fp64(N, H, W, Cin, Cout, dil):
     assert e_y < 5e-6 and e_x < 5e-6 and e_w < 5e-6
 
 
-def test_feature_cnn_training_path_native_vs_vendor_convs(monkeypatch):
-    """The module (autograd) path of the feature CNN with its 3x3 stride-1 convolutions on the hand-written kernels against the
-    same modules on the vendor convolutions: outputs and every parameter gradient."""
+def test_feature_cnn_training_path_vs_fp64_module_autograd():
+    """The module (autograd) path of the feature CNN — every convolution form (3x3, stride-2 3x3, 1x1, strided 1x1), BatchNorm
+    and the SPP up-sampling on the hand-written kernels in all three directions — against float64 CPU autograd of the same
+    nn.Module graph (psm_submodule.py:76-167): outputs and every parameter gradient."""
     import copy
     from neuralrgbd_amd import nets
     net = nets.FeatureExtractor(feature_dim=64, multi_scale=True)
     net.load_state_dict(synth.seeded_state_dict(net, 4))
-    a, b = copy.deepcopy(net).to(DEV), copy.deepcopy(net).to(DEV)
-    img = torch.randn(2, 3, 256, 320, generator=torch.Generator().manual_seed(1)).to(DEV)
-    monkeypatch.setenv("NRGBD_TRAIN_CONV", "native")
-    ha, fa = a(img)
+    a, b = copy.deepcopy(net).to(DEV), copy.deepcopy(net).double()
+    img = torch.randn(2, 3, 256, 320, generator=torch.Generator().manual_seed(1))
+    ha, fa = a(img.to(DEV))
     (fa.square().mean() + ha.square().mean()).backward()
-    monkeypatch.setenv("NRGBD_TRAIN_CONV", "vendor")
-    hb, fb = b(img)
+    hb, fb = b(img.double())
     (fb.square().mean() + hb.square().mean()).backward()
-    assert (fa - fb).abs().max().item() < 2e-3 * fb.abs().max().item()
-    worst = max(((pa.grad - pb.grad).abs().max() / pb.grad.abs().max().clamp_min(1e-12)).item()
+    assert (fa.cpu() - fb.float()).abs().max().item() < 2e-3 * fb.abs().max().item()
+    worst = max(((pa.grad.cpu() - pb.grad.float()).abs().max() / pb.grad.abs().max().clamp_min(1e-12)).item()
                 for (_, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()))
-    print("[parity] feature CNN training path, hand-written vs vendor convolutions: worst parameter-gradient difference %.2e" % worst)
-    # two fp32 evaluations of a 60-layer ReLU network: a pre-activation within rounding of the kink flips side now and then and
+    print("[parity] feature CNN training path vs float64 module autograd: worst parameter-gradient difference %.2e" % worst)
+    # an fp32 evaluation of a 60-layer ReLU network: a pre-activation within rounding of the kink flips side now and then and
     # moves one layer's gradient by ~1e-2 of its scale (see test_knet_training_path_vs_fp64_autograd); the convolutions
     # themselves agree with float64 to 1e-6 (test_conv2d_autograd_function_vs_fp64)
     assert worst < 5e-2
@@ -393,32 +392,32 @@ def test_batchnorm_act_channels_last_vs_fp64_autograd(rows, C, relu, res):
         assert err < 2e-5 * scale, name
 
 
-def test_batch_norm_module_glue_native_vs_vendor(monkeypatch):
-    """autograd.batch_norm_act_cl on nn.BatchNorm3d / nn.BatchNorm2d modules: the HIP path (NRGBD_TRAIN_BN unset) and torch's batch_norm
-    (NRGBD_TRAIN_BN=vendor) give the same output, gradients, running statistics and batch counter; widths bn_train.hip has no form for
-    (C = 48: its 12 channel quads do not tile a 256-lane workgroup) and eval-mode norms take the torch path by themselves."""
+def test_batch_norm_module_glue_vs_torch_batch_norm():
+    """autograd.batch_norm_act_cl on nn.BatchNorm3d / nn.BatchNorm2d modules (csrc/bn_train.hip) against torch's batch_norm +
+    relu + add on a twin module: output, gradients, running statistics and batch counter; widths bn_train.hip has no form for
+    (C = 48: its 12 channel quads do not tile a 256-lane workgroup) and eval-mode norms take torch's path by themselves."""
     from neuralrgbd_amd import ops
     from neuralrgbd_amd.autograd import batch_norm_act_cl
-    g = torch.Generator(device="cpu").manual_seed(5)
     for C, track in ((64, True), (32, False), (48, True)):
         res = {}
-        for mode in ("native", "vendor"):
-            monkeypatch.setenv("NRGBD_TRAIN_BN", mode)
+        for mode in ("path", "torch"):
             bn = torch.nn.BatchNorm3d(C, track_running_stats=track).to(DEV)
             with torch.no_grad():
                 bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
             x = torch.randn(6, 5, 7, C, generator=torch.Generator().manual_seed(C)).to(DEV).requires_grad_(True)
             r = torch.randn(6, 5, 7, C, generator=torch.Generator().manual_seed(C + 1)).to(DEV).requires_grad_(True)
-            y = batch_norm_act_cl(x, bn, True, r)
+            if mode == "path":
+                y = batch_norm_act_cl(x, bn, True, r)
+            else:      # [6,5,7,C] -> (N = 6*5*7, C): the (N, C) form of batch_norm has the same statistics
+                y = torch.relu(bn(x.reshape(-1, C, 1, 1, 1)).reshape(x.shape)) + r
             (y * torch.arange(y.numel(), device=DEV).reshape(y.shape).remainder(7).float()).sum().backward()
             res[mode] = (y.detach(), x.grad, r.grad, bn.weight.grad, bn.bias.grad,
                          bn.running_mean.clone() if track else None, int(bn.num_batches_tracked) if track else None)
         assert ops.bn_cl_supported(6 * 5 * 7, C) == (C != 48)
-        for a, b in zip(res["native"][:5], res["vendor"][:5]):
+        for a, b in zip(res["path"][:5], res["torch"][:5]):
             assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
         if track:
-            assert (res["native"][5] - res["vendor"][5]).abs().max().item() < 1e-6 and res["native"][6] == res["vendor"][6] == 1
-    monkeypatch.delenv("NRGBD_TRAIN_BN")
+            assert (res["path"][5] - res["torch"][5]).abs().max().item() < 1e-6 and res["path"][6] == res["torch"][6] == 1
     with pytest.raises(ValueError):                                  # torch's own error for a single value per channel in training
         batch_norm_act_cl(torch.randn(1, 1, 1, 32, device=DEV), torch.nn.BatchNorm3d(32).to(DEV), False)
     bn = torch.nn.BatchNorm2d(32).to(DEV).eval()                     # running statistics in use: torch's own path

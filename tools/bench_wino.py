@@ -39,16 +39,14 @@ def main():
     r = torch.randn(D, H, W, 64, generator=g).cuda()
     w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).cuda()
     ss = torch.rand(64, 2, generator=g).cuda()
-    wd, ww = ops.conv3d_pack_weights(w), ops.conv3d_wino_pack(w)
+    wd, ww = ops.conv3d_pack_weights(w), ops.conv_wino_pack(w)
     wdw = ops.conv_wino_dw_pack(w)
     flops = 2.0 * D * H * W * 64 * 64 * 27
     for name, fn in (("direct plain", lambda: ops.conv3d(x, wd, x_ss=ss, x_relu=True)),
-                     ("wino   plain", lambda: ops.conv3d_wino(x, ww, x_ss=ss, x_relu=True)),
                      ("wino-pc plain", lambda: ops.conv_wino(x, ww, 64, 3, x_ss=ss, x_relu=True)),
                      ("wino-dw plain", lambda: ops.conv_wino_dw(x, wdw, 64, x_ss=ss, x_relu=True)),
                      ("wino-dw res+mat", lambda: ops.conv_wino_dw(x, wdw, 64, x_ss=ss, res=r, materialize=True)),
                      ("direct res+mat", lambda: ops.conv3d(x, wd, x_ss=ss, res=r, materialize=True)),
-                     ("wino   res+mat", lambda: ops.conv3d_wino(x, ww, x_ss=ss, res=r, materialize=True)),
                      ("wino-pc res+mat", lambda: ops.conv_wino(x, ww, 64, 3, x_ss=ss, res=r, materialize=True))):
         if args.only and args.only not in name:
             continue
@@ -68,8 +66,6 @@ def main():
     if args.only:
         return
     y1 = ops.conv3d(x, wd, x_ss=ss, x_relu=True)[0]
-    y2 = ops.conv3d_wino(x, ww, x_ss=ss, x_relu=True)[0]
-    print("max|wino - direct| = %.3e (|y|max %.2f)" % ((y1 - y2).abs().max().item(), y1.abs().max().item()))
     y3 = ops.conv_wino(x, ww, 64, 3, x_ss=ss, x_relu=True)[0]
     print("max|wino-pc - direct| = %.3e" % (y1 - y3).abs().max().item())
     if args.cnn:
