@@ -42,7 +42,12 @@ extern "C" {
 #define NRGBD_MAX_D        256   /* depth candidates per volume */
 #define NRGBD_MAX_V         16   /* source views per window     */
 
-/* Library / build identification ("gfx950"), and error text for a return code. */
+/* Library / build identification ("nrgbd_hip <interface version> (gfx950, CDNA4)"), and error text for a return code.
+ * The interface version changes whenever an entry point changes its signature or disappears: bind against the version you
+ * were built for.  0.4 (round 4): nrgbd_costvol_bwd takes (workspace, workspace_bytes) before `stream` (since round 3: query
+ * nrgbd_costvol_bwd_workspace first); nrgbd_conv3d_wino_* and nrgbd_conv_wino_dw_bn_f32 are gone; nrgbd_upsample_bilinear_ac
+ * is new. */
+#define NRGBD_INTERFACE_VERSION "0.4"
 const char* nrgbd_version(void);
 const char* nrgbd_strerror(int code);
 

@@ -31,14 +31,19 @@ __global__ __launch_bounds__(kBnclThreads) void bn_cl_stats_kernel(const float* 
     float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sf = sc, mu = sc;
     if (BWD) { sc = ld4(coef + 4 * q); sf = ld4(coef + C + 4 * q); mu = ld4(coef + 2 * C + 4 * q); }
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    // forward: sums of (x - k) and (x - k)^2 with k = the channel's value in row 0 (the same for every workgroup): the variance
+    // E[(x-k)^2] - E[x-k]^2 then has no cancellation when |mean| >> std (a sample of the channel is within a few std of its
+    // mean), which E[x^2] - mean^2 on fp32 sums has (torch's kernel is Welford)
+    const float4 k = BWD ? a : ld4(x + 4 * q);
     const long step = (long)gridDim.x * S;
 #pragma unroll 4
     for (long r = (long)blockIdx.x * S + slot; r < rows; r += step) {
         const float4 v = ld4(x + r * C + 4 * q);
         if (!BWD) {
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-            b.x = __builtin_fmaf(v.x, v.x, b.x); b.y = __builtin_fmaf(v.y, v.y, b.y);
-            b.z = __builtin_fmaf(v.z, v.z, b.z); b.w = __builtin_fmaf(v.w, v.w, b.w);
+            const float4 d = make_float4(v.x - k.x, v.y - k.y, v.z - k.z, v.w - k.w);
+            a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+            b.x = __builtin_fmaf(d.x, d.x, b.x); b.y = __builtin_fmaf(d.y, d.y, b.y);
+            b.z = __builtin_fmaf(d.z, d.z, b.z); b.w = __builtin_fmaf(d.w, d.w, b.w);
         } else {
             float4 g = ld4(gy + r * C + 4 * q);
             if (relu) {
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(kBnclThreads) void bn_cl_finalize_kernel(const floa
                                                                       float eps, float momentum, float* __restrict__ running_mean,
                                                                       float* __restrict__ running_var, float* __restrict__ coef,
                                                                       float* __restrict__ g_gamma, float* __restrict__ g_beta,
-                                                                      float* __restrict__ coef2) {
+                                                                      float* __restrict__ coef2, const float* __restrict__ shift_row) {
     __shared__ double sh[2][16][16];
     const int lane = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + lane;
@@ -91,8 +96,9 @@ __global__ __launch_bounds__(kBnclThreads) void bn_cl_finalize_kernel(const floa
 #pragma unroll
     for (int q = 1; q < 16; ++q) { s1 += sh[0][q][lane]; s2 += sh[1][q][lane]; }
     if (!BWD) {
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
+        const double dm = s1 / count;                       // mean of (x - k), k = shift_row[c] (row 0 of x)
+        const double mean = (double)shift_row[c] + dm;
+        double var = s2 / count - dm * dm;
         var = var > 0.0 ? var : 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float scale = gamma[c] * invstd;
@@ -180,7 +186,7 @@ extern "C" int nrgbd_bn_cl_fwd(const float* x, const float* res, const float* ga
     const int G = nrgbd_bn_cl_workgroups(rows, C);
     hipLaunchKernelGGL(bn_cl_stats_kernel<false>, dim3(G), dim3(kBnclThreads), 0, s, x, nullptr, nullptr, 0, partial, rows, C);
     hipLaunchKernelGGL(bn_cl_finalize_kernel<false>, dim3((C + 15) / 16), dim3(kBnclThreads), 0, s, partial, G, C, (double)rows, gamma,
-                       beta, eps, momentum, running_mean, running_var, coef, nullptr, nullptr, nullptr);
+                       beta, eps, momentum, running_mean, running_var, coef, nullptr, nullptr, nullptr, x);
     const long n4 = rows * (C >> 2);
     hipLaunchKernelGGL(bn_cl_apply_kernel, dim3((unsigned)ceil_div(n4, (long)kBnclThreads)), dim3(kBnclThreads), 0, s, x, res, coef, relu,
                        y, n4, C);
@@ -197,7 +203,7 @@ extern "C" int nrgbd_bn_cl_bwd(const float* x, const float* gy, const float* coe
     const int G = nrgbd_bn_cl_workgroups(rows, C);
     hipLaunchKernelGGL(bn_cl_stats_kernel<true>, dim3(G), dim3(kBnclThreads), 0, s, x, gy, coef, relu, partial, rows, C);
     hipLaunchKernelGGL(bn_cl_finalize_kernel<true>, dim3((C + 15) / 16), dim3(kBnclThreads), 0, s, partial, G, C, (double)rows, nullptr,
-                       nullptr, 0.f, 0.f, nullptr, nullptr, const_cast<float*>(coef), g_gamma, g_beta, coef2);
+                       nullptr, 0.f, 0.f, nullptr, nullptr, const_cast<float*>(coef), g_gamma, g_beta, coef2, nullptr);
     const long n4 = rows * (C >> 2);
     hipLaunchKernelGGL(bn_cl_bwd_apply_kernel, dim3((unsigned)ceil_div(n4, (long)kBnclThreads)), dim3(kBnclThreads), 0, s, x, gy, coef,
                        coef2, relu, gx, n4, C);

@@ -141,15 +141,19 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_reduce_kernel(const float* _
 
 }  // namespace nrgbd
 
-// workgroups per 64 x 64 weight block (each writes a 147 KB partial that the reduction reads back)
+// workgroups per 64 x 64 weight block; each writes a 147,456-byte partial (9 taps x 64 x 64 floats, also for narrower layers)
+// that the reduction reads back, so the scratch is blocks x workgroups x 147 KB: bounded to ~256 MB here (it used to
+// reach 1.5 GB for the 320 -> 128 layer on large grids)
 extern "C" int nrgbd_conv2d_wgrad_workgroups(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 16 || Cout <= 0 || Cout % 16) return NRGBD_E_SHAPE;
     const int blocks = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     const long ntiles = (long)N * ((H + nrgbd::kGH - 1) / nrgbd::kGH) * ((W + nrgbd::kGW - 1) / nrgbd::kGW);
-    // one pixel tile per workgroup up to 1,024 workgroups per weight block (37 MB of partials per block at most), beyond that
-    // the workgroups walk the tile list
-    (void)blocks;
-    return (int)(ntiles < 1024 ? ntiles : 1024);
+    // one pixel tile per workgroup while the partials of all blocks stay below ~256 MB (1,820 partials) and 1,024 per block;
+    // beyond that the workgroups walk the tile list.  >= 64 per block keeps every CU busy for single-block layers.
+    long cap = 1820 / blocks;
+    if (cap < 64) cap = 64;
+    if (cap > 1024) cap = 1024;
+    return (int)(ntiles < cap ? ntiles : cap);
 }
 
 extern "C" int nrgbd_conv2d_wgrad_f32(const float* x, const float* gy, float* partial, float* dw, int N, int H, int W, int Cin,

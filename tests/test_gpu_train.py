@@ -392,6 +392,27 @@ def test_batchnorm_act_channels_last_vs_fp64_autograd(rows, C, relu, res):
         assert err < 2e-5 * scale, name
 
 
+def test_batchnorm_statistics_survive_a_large_mean():
+    """channels with |mean| >> std (mean 1e2, std 1e-1) — E[x^2] - mean^2 on fp32 sums would lose the variance to
+    cancellation; the kernel sums (x - x[0])-shifted moments instead.  Output and running statistics vs float64."""
+    from neuralrgbd_amd.autograd import BatchNormActCL
+    g = torch.Generator(device="cpu").manual_seed(9)
+    rows, C = 20000, 64
+    x = (torch.randn(rows, C, generator=g) * 0.1 + torch.linspace(-150.0, 150.0, C)).to(DEV)
+    w, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    y = BatchNormActCL.apply(x, w, b, None, 1e-5, False, 1.0, rm, rv)
+    xd = x.double()
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    want = (xd - mean) / torch.sqrt(var + 1e-5)
+    err = (y.double() - want).abs().max().item()
+    print("[parity] bn_cl, mean up to 150, std 0.1: max|d y| %.2e, running var rel. err %.2e" %
+          (err, ((rv.double() - xd.var(0)) / xd.var(0)).abs().max().item()))
+    assert err < 5e-3                         # |x - mean| / std with x itself rounded to 1.5e-5 at 150: ~1e-3 is the input's own ulp
+    assert ((rv.double() - xd.var(0)) / xd.var(0)).abs().max().item() < 1e-3
+    assert (rm.double() - mean).abs().max().item() < 1e-4
+
+
 def test_batch_norm_module_glue_vs_torch_batch_norm():
     """autograd.batch_norm_act_cl on nn.BatchNorm3d / nn.BatchNorm2d modules (csrc/bn_train.hip) against torch's batch_norm +
     relu + add on a twin module: output, gradients, running statistics and batch counter; widths bn_train.hip has no form for
