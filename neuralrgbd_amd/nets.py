@@ -550,6 +550,8 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 
+    _split_residual = True      # measured (tools/r4_knet_split.py): K-Net 25.37 -> 24.67 ms at config B, 3.26 -> 3.18 at S, 20.03 -> 19.60 at H; identical bits
+
     def forward_channels_last(self, vol, generation=None):
         """Inference on the hand-written kernels: vol [D,H,W,Cin] (channels-last) -> gain [D,H,W].
 
@@ -578,6 +580,14 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         def run(i, x, x_ss, x_relu, res=None, materialize=False):
             conv, bn = L[i]
             cm = False
+            if res is not None and self._split_residual:
+                # the residual layers as TWO launches: in = bn(x) + res materialised by one HBM-bound pass (nrgbd_nhwc_act), then the
+                # plain form of the convolution on it.  In the fused form the producers of wino_dw.hip load and add the second
+                # operand 2-3 times per tile pair — 10 more vector-memory instructions and ~100 more VALU per stage on SIMDs whose
+                # issue slots are what bounds the kernel (profiles/r4_wino_design_probe.txt)
+                x = ops.nhwc_act(x, x_ss, x_relu, res)
+                y, ss, _ = run(i, x, None, False)
+                return y, ss, x
             if (generation is None and conv.in_channels in (16, 64) and conv.out_channels == 64
                     and ops.conv_wino_dw_supported(D, H, W, conv.in_channels, 64)):
                 y, st, mat = ops.conv_wino_dw(x, _packed_wino_dw(self, conv), 64, x_ss=x_ss, x_relu=x_relu, res=res,
