@@ -170,7 +170,7 @@ extern "C" int nrgbd_costvol_fwd_gen(const float* ref_nhwc, const float* src_nhw
     if ((Cp & 3) || Cp < C || Cp - C > 3) return NRGBD_E_ALIGN;
     if ((reinterpret_cast<uintptr_t>(ref_nhwc) | reinterpret_cast<uintptr_t>(src_nhwc)) & 15) return NRGBD_E_ALIGN;
     if (dist != NRGBD_DIST_L2 && dist != NRGBD_DIST_L1) return NRGBD_E_ARG;
-    if (generation < NRGBD_GEN_AUTO || generation > NRGBD_GEN_QUAD_ACC) return NRGBD_E_ARG;
+    if (generation < NRGBD_GEN_AUTO || generation > NRGBD_GEN_QUAD) return NRGBD_E_ARG;
     CostvolArgs a{ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, out_cost, out_logp, cx, cy, sigma,
                   dist, align_corners, V, C, Cp, D, h, w, 0, 0, 1, D, 0,
                   (float)(1.0 / (double)cx), (float)(1.0 / (double)cy), (float)(1.0 / (double)sigma)};
@@ -181,15 +181,11 @@ extern "C" int nrgbd_costvol_fwd_gen(const float* ref_nhwc, const float* src_nhw
     // AUTO: generation 3 (quad) for the path's own texel (64 feature channels [+ RGB word]); generation 2 (LDS, lane =
     // pixel) for the other channel counts it instantiates; generation 1 (gather) for everything else.  An explicit
     // generation that does not support the shape is an error, never a silent substitution.
-    if ((generation == NRGBD_GEN_QUAD || generation == NRGBD_GEN_QUAD_ACC) && !costvol_quad_supported(a)) return NRGBD_E_SHAPE;
+    if (generation == NRGBD_GEN_QUAD && !costvol_quad_supported(a)) return NRGBD_E_SHAPE;
     if (generation == NRGBD_GEN_LDS && !costvol_lds_supported(Cp >> 2)) return NRGBD_E_SHAPE;
-    if (generation == NRGBD_GEN_QUAD || generation == NRGBD_GEN_QUAD_ACC || (generation == NRGBD_GEN_AUTO && costvol_quad_supported(a))) {
+    if (generation == NRGBD_GEN_QUAD || (generation == NRGBD_GEN_AUTO && costvol_quad_supported(a))) {
         bool did_softmax = false;
-        // AUTO = generation 3.  Generation 4 (the views' partial costs accumulate in LDS, every output written once) removes the
-        // read-modify-write traffic but pays for its 16 KB of accumulators with patch texels or a workgroup slot, and the kernel
-        // is bound by tap issue and staging latency, not by traffic: 415 us (128-texel patch, 3 workgroups per CU) / 326 us
-        // (188 texels, 2 per CU) vs 281 us at config B; slower on S, K and H as well (profiles/r3_costvol_gen4.txt).
-        int rc = launch_costvol_quad(a, s, &did_softmax, generation == NRGBD_GEN_QUAD_ACC);
+        int rc = launch_costvol_quad(a, s, &did_softmax);
         if (rc != NRGBD_OK) return rc;
         if (out_logp && !did_softmax)
             return launch_logsoftmax_d(out_cost ? out_cost : out_logp, nullptr, -1.f, out_logp, D, (size_t)h * w, s);

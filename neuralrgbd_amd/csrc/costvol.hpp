@@ -30,14 +30,14 @@ struct CostvolArgs {
 #define NRGBD_DBG(a, bits) 0
 #endif
 
-enum { NRGBD_GEN_AUTO = 0, NRGBD_GEN_GATHER = 1, NRGBD_GEN_LDS = 2, NRGBD_GEN_QUAD = 3, NRGBD_GEN_QUAD_ACC = 4 };
+enum { NRGBD_GEN_AUTO = 0, NRGBD_GEN_GATHER = 1, NRGBD_GEN_LDS = 2, NRGBD_GEN_QUAD = 3 };
 
 // costvol_lds.hip: LDS-staged generation (returns NRGBD_E_SHAPE when Cp/4 has no instantiation)
 int launch_costvol_lds(const CostvolArgs& a, hipStream_t stream);
 bool costvol_lds_supported(int cp4);
 // costvol_quad.hip: generation 3 (4 lanes per (pixel, candidate), conflict-free LDS taps, fused log-softmax)
 bool costvol_quad_supported(const CostvolArgs& a);
-int launch_costvol_quad(const CostvolArgs& a, hipStream_t stream, bool* did_softmax, bool lds_accumulators);
+int launch_costvol_quad(const CostvolArgs& a, hipStream_t stream, bool* did_softmax);
 // softmax.hip
 int launch_logsoftmax_d(const float* a, const float* b, float scale, float* out, int D, size_t n,
                         hipStream_t stream);

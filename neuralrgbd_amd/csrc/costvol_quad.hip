@@ -39,10 +39,10 @@ namespace {
 
 constexpr int kQT = 8;            // tile edge
 constexpr int kQRun = 16;         // candidates per staged run (groups of 4)
-// texels of the patch (x 272 B) and workgroups per CU of the two builds of the kernel:
-//   generation 3: 188 texels = 50 KB + 20 B per candidate -> 3 workgroups per CU; the views' partial costs meet in global memory
-//   generation 4: the (candidate, pixel) accumulators live in LDS (256 B per candidate) next to the patch
-constexpr int kQPatch3 = 188, kQPatch4 = 128;   // generation 4 at 3 workgroups per CU: 16 KB of accumulators instead of 60 patch texels (D = 64)
+// texels of the patch (x 272 B): 188 texels = 50 KB + 20 B per candidate -> 3 workgroups per CU; the views' partial costs meet
+// in global memory.  (Round 3's generation 4 kept them in LDS accumulators next to a 128-texel patch: bit-identical and slower,
+// 415 vs 281 us at config B — profiles/r3_costvol_gen4.txt; removed in round 4.)
+constexpr int kQPatch3 = 188;
 constexpr int kQFeatBytes = 256;  // feature plane: 16 words of 16 B per texel
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -126,10 +126,8 @@ __device__ __forceinline__ float rgb_word(const f32x4 A, const f32x4 B, const f3
 
 // TAIL: valid channels of the texel's 17th word (Cp = 68: channels 64..66 = pooled RGB => 3; -1 = a.C - 64 at run time);
 // 0 = no 17th word (Cp = 64).  ALIGN: grid_sample's align_corners.
-// ACC (generation 4): a candidate's cost is accumulated over the views in LDS (accL[candidate of the chunk][pixel of the tile])
-// and every output is written exactly once; generation 3 read-modify-writes out[k][p] in global memory once per view, which
-// the fabric counters showed as 4.9x the output in writes and the re-reads on top (profiles/r2_costvol_traffic.json).
-template <int DIST, int TAIL, bool ALIGN, int PATCH, int WGS, bool ACC>
+// A candidate's cost is read-modify-written in global memory (out[k][p], L2-resident) once per view by the quad that owns it.
+template <int DIST, int TAIL, bool ALIGN, int PATCH, int WGS>
 __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     constexpr bool EXTRA = TAIL != 0;
     constexpr int kQPatch = PATCH, kQPatchR = (PATCH + 63) / 64 * 64;   // RGB plane: a wave instruction fills 64 slots
@@ -138,7 +136,6 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     char* ldsR = smem + kQPatch * kQFeatBytes;                          // [kQPatchR][16 B]
     int4* boxes = reinterpret_cast<int4*>(ldsR + kQPatchR * 16);        // [D] footprint of the tile per candidate (this view)
     float* dcand = reinterpret_cast<float*>(boxes + a.D);               // [D] depth candidates
-    float* accL = dcand + a.D;                                          // ACC: [kchunk][64] costs summed over the views so far
     float* red = reinterpret_cast<float*>(smem);                        // softmax scratch (the patch is dead by then)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -441,65 +438,20 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
 #pragma unroll 1
                 for (int g = 0; g < ngroups; ++g) {
                     const int k0 = j0 + 4 * g, nc = min(4, n - 4 * g);   // candidates j0 .. j0 + n - 1 = this run
-                    float* o = ACC ? accL + (min(k0 + j, ke - 1) - kb) * 64 + quad
-                                   : out + (size_t)min(k0 + j, a.D - 1) * hw + p;
+                    float* o = out + (size_t)min(k0 + j, a.D - 1) * hw + p;
                     const float prev = (v > 0) ? *o : 0.f;     // this quad's own store of the previous view
                     float acc;
                     if (!staged) acc = group(F_{}, N4{}, sv, st, k0, nc, 0, 0, 0, 0, 0);
                     else if (nc == 1) acc = group(T_{}, N1{}, sv, st, k0, 1, xlo, xhi, ylo, yhi, cols);
                     else if (nc == 2) acc = group(T_{}, N2{}, sv, st, k0, 2, xlo, xhi, ylo, yhi, cols);
                     else acc = group(T_{}, N4{}, sv, st, k0, 4, xlo, xhi, ylo, yhi, cols);
-                    if ((ACC || inside) && j < nc) *o = prev + div_by_const(acc, a.sigma, a.rsigma);   // homography.py:325 (/ sigma), views in order
+                    if (inside && j < nc) *o = prev + div_by_const(acc, a.sigma, a.rsigma);   // homography.py:325 (/ sigma), views in order
                 }
             }
             if (rev) hi -= n; else lo += n;
         }
     }
 
-    if constexpr (ACC) {
-        // ---- every output once, from the LDS accumulators: thread = (pixel, quarter of the chunk's candidates) ----
-        __syncthreads();
-        const int pp = tid & 63, part = tid >> 6;
-        const int x2 = tx * kQT + (pp & 7), y2 = ty * kQT + (pp >> 3);
-        const bool in2 = (x2 < a.w) && (y2 < a.h);
-        const size_t p2 = (size_t)min(y2, a.h - 1) * a.w + min(x2, a.w - 1);
-        const int nk = ke - kb;
-        if (a.out_cost || !a.fuse_softmax) {        // the raw cost (chunked grids: the log-softmax is its own launch)
-            if (in2)
-                for (int k = part; k < nk; k += 4) out[(size_t)(kb + k) * hw + p2] = accL[k * 64 + pp];
-        }
-        if (!a.fuse_softmax) return;
-        // log_softmax(-cost) over the D candidates of the tile's pixels (models/basic.py:299-300)
-        constexpr int KMAX = 32;                              // D <= 128
-        float col[KMAX];
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < KMAX; ++t) {
-            const int k = part + 4 * t;
-            col[t] = (k < a.D) ? -accL[k * 64 + pp] : -INFINITY;
-            m = fmaxf(m, col[t]);
-        }
-        __syncthreads();                                       // `red` overlaps the patch: every wave is past its last taps
-        red[part * 64 + pp] = m;
-        __syncthreads();
-        m = fmaxf(fmaxf(red[pp], red[64 + pp]), fmaxf(red[128 + pp], red[192 + pp]));
-        float s = 0.f;
-#pragma unroll
-        for (int t = 0; t < KMAX; ++t)
-            if (part + 4 * t < a.D) s += expf(col[t] - m);
-        red[256 + part * 64 + pp] = s;
-        __syncthreads();
-        s = (red[256 + pp] + red[256 + 64 + pp]) + (red[256 + 128 + pp] + red[256 + 192 + pp]);
-        const float ls = logf(s);
-        if (in2) {
-#pragma unroll
-            for (int t = 0; t < KMAX; ++t) {
-                const int k = part + 4 * t;
-                if (k < a.D) a.out_logp[(size_t)k * hw + p2] = (col[t] - m) - ls;
-            }
-        }
-        return;
-    }
     if (!a.fuse_softmax) return;
     // ---- log_softmax(-cost) over the D candidates of the tile's pixels (models/basic.py:299-300) ----
     // thread = (pixel, quarter of the candidates); the costs were written by other lanes of THIS workgroup: make the stores
@@ -548,8 +500,8 @@ bool costvol_quad_supported(const CostvolArgs& a) {
     return (extra || plain) && (long)a.h * a.w * a.Cp * 4 < (1L << 31) && a.D <= NRGBD_MAX_D;
 }
 
-// Returns NRGBD_OK and sets *did_softmax when the launch also produced out_logp.  acc: generation 4 (LDS accumulators).
-int launch_costvol_quad(const CostvolArgs& args, hipStream_t stream, bool* did_softmax, bool acc) {
+// Returns NRGBD_OK and sets *did_softmax when the launch also produced out_logp.
+int launch_costvol_quad(const CostvolArgs& args, hipStream_t stream, bool* did_softmax) {
     CostvolArgs a = args;
     const int tiles = ceil_div(a.w, kQT) * ceil_div(a.h, kQT);
     // one workgroup per tile owns all D candidates when that fills the chip (3 workgroups per CU); smaller grids split the
@@ -561,29 +513,20 @@ int launch_costvol_quad(const CostvolArgs& args, hipStream_t stream, bool* did_s
     a.kchunk = ceil_div(a.D, nchunk);
     a.fuse_softmax = (nchunk == 1 && a.out_logp != nullptr && a.D <= 128) ? 1 : 0;
     *did_softmax = a.fuse_softmax != 0;
-    // developer builds: NRGBD_QUAD4 = 2 selects the 188-texel patch at 2 workgroups per CU for generation 4
-    const bool big = acc && dev_env_int("NRGBD_QUAD4") == 2;
-    const int patch = !acc ? kQPatch3 : (big ? kQPatch3 : kQPatch4);
-    const size_t lds = (size_t)patch * kQFeatBytes + (size_t)((patch + 63) / 64 * 64) * 16 +
-                       (size_t)a.D * (sizeof(int4) + sizeof(float)) + (acc ? (size_t)a.kchunk * 64 * sizeof(float) : 0);
+    const int patch = kQPatch3;
+    const size_t lds = (size_t)patch * kQFeatBytes + (size_t)((patch + 63) / 64 * 64) * 16 + (size_t)a.D * (sizeof(int4) + sizeof(float));
     const dim3 grid(tiles * nchunk);
     const int tail = a.Cp == 68 ? (a.C - 64 == 3 ? 3 : -1) : 0;
     const bool al = a.align != 0;
     hipError_t e = hipSuccess;
-#define NRGBD_QUAD_LAUNCH(DIST, TL, AL, PATCH, WGS, ACC)                                                                       \
+#define NRGBD_QUAD_CFG(DIST, TL, AL)                                                                                           \
     do {                                                                                                                       \
         if (lds > 64 * 1024) {                                                                                                 \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&costvol_quad<DIST, TL, AL, PATCH, WGS, ACC>),               \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&costvol_quad<DIST, TL, AL, kQPatch3, 3>),                   \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
             if (e != hipSuccess) return (int)e;                                                                                \
         }                                                                                                                      \
-        hipLaunchKernelGGL((costvol_quad<DIST, TL, AL, PATCH, WGS, ACC>), grid, dim3(256), lds, stream, a);                    \
-    } while (0)
-#define NRGBD_QUAD_CFG(DIST, TL, AL)                                                                                           \
-    do {                                                                                                                       \
-        if (!acc) NRGBD_QUAD_LAUNCH(DIST, TL, AL, kQPatch3, 3, false);                                                         \
-        else if (big) NRGBD_QUAD_LAUNCH(DIST, TL, AL, kQPatch3, 2, true);                                                      \
-        else NRGBD_QUAD_LAUNCH(DIST, TL, AL, kQPatch4, 3, true);                                                               \
+        hipLaunchKernelGGL((costvol_quad<DIST, TL, AL, kQPatch3, 3>), grid, dim3(256), lds, stream, a);                        \
     } while (0)
 #define NRGBD_QUAD_DISPATCH(DIST)                                                                   \
     if (tail == 3) { if (al) NRGBD_QUAD_CFG(DIST, 3, true); else NRGBD_QUAD_CFG(DIST, 3, false); }        \
@@ -592,7 +535,6 @@ int launch_costvol_quad(const CostvolArgs& args, hipStream_t stream, bool* did_s
     if (a.dist == NRGBD_DIST_L2) { NRGBD_QUAD_DISPATCH(NRGBD_DIST_L2) } else { NRGBD_QUAD_DISPATCH(NRGBD_DIST_L1) }
 #undef NRGBD_QUAD_DISPATCH
 #undef NRGBD_QUAD_CFG
-#undef NRGBD_QUAD_LAUNCH
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

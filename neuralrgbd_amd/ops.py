@@ -11,7 +11,7 @@ import torch
 from . import _lib
 
 DIST = {"L2": 0, "L1": 1}
-GENERATION = {None: 0, "auto": 0, "gather": 1, "lds": 2, "quad": 3, "quad4": 4}   # kernel generations of nrgbd_costvol_fwd_gen
+GENERATION = {None: 0, "auto": 0, "gather": 1, "lds": 2, "quad": 3}   # kernel generations of nrgbd_costvol_fwd_gen
 
 
 def _need(t, name, shape=None, strided=False):
@@ -108,7 +108,7 @@ def pack_nhwc(feat, rgb=None, Cp=None, channels_last=False):
 def costvol(ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, cx, cy, sigma, C, dist="L2",
             align_corners=False, want_cost=True, want_logp=False, generation=None):
     """Fused warp + cost volume (+ log-softmax).  Returns (cost [D,h,w] | None, logp [D,h,w] | None).
-    `generation` (None = automatic | "gather" | "lds" | "quad" | "quad4") pins the kernel generation for tests / A-B timing
+    `generation` (None = automatic | "gather" | "lds" | "quad") pins the kernel generation for tests / A-B timing
     (automatic = "quad" for the path's 64(+3)-channel texel; "quad4" = the same kernel with its per-view accumulators in LDS:
     bit-identical, every output written once, measured slower — profiles/r3_costvol_gen4.txt)."""
     src_nhwc = _need(src_nhwc, "src_nhwc")
