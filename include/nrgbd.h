@@ -500,6 +500,18 @@ int nrgbd_spp_concat(const float* quarter, int Cq, const float* deep, int Cd,
                      const float* bz2, const float* bss2, int bh2, int bw2, const float* bz3, const float* bss3, int bh3, int bw3,
                      int Cb, float* out, int N, int h, int w, void* stream);
 /*
+ * nrgbd_bias_lrelu_cl_fwd / _bwd — y = leaky_relu(x + bias[c], slope) on channels-last rows [rows][C] and its backward
+ * (training path of the R-Net).  Replaces: the bias add + nn.LeakyReLU of m_submodule.conv2d_leakyRelu /
+ * conv2dTranspose_leakyRelu (models/m_submodule.py:18-27,36-45; slope = 1: the bias of Refine.py:71) and, in backward, ATen's
+ * leaky_relu_backward + the bias gradient's sum.  backward: gx = gy * (y > 0 ? 1 : slope) (y = the forward's OUTPUT),
+ * g_bias[c] = sum over rows of gx; partial = scratch of nrgbd_bias_lrelu_cl_workgroups(rows, C) x C floats (added in index
+ * order, in double).  C % 4 == 0, C <= 1024.
+ */
+int nrgbd_bias_lrelu_cl_workgroups(long rows, int C);
+int nrgbd_bias_lrelu_cl_fwd(const float* x, const float* bias, float slope, float* y, long rows, int C, void* stream);
+int nrgbd_bias_lrelu_cl_bwd(const float* y, const float* gy, float slope, float* gx, float* g_bias, float* partial,
+                            long rows, int C, void* stream);
+/*
  * nrgbd_upsample_bilinear_ac — bilinear up-sampling with align_corners = True of a channels-last map and its exact adjoint
  * (training path of the SPP branches).
  * Replaces: F.upsample(mode='bilinear') of models/psm_submodule.py:153-158 and its autograd backward (ATen

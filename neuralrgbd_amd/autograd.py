@@ -163,6 +163,38 @@ def batch_norm_act_cl(x_cl, bn, relu, residual=None):
     return y if residual is None else y + residual
 
 
+class BiasLeakyReLUCL(torch.autograd.Function):
+    """y = leaky_relu(x + bias[c], slope) for an NCHW tensor in channels_last memory (the R-Net's conv2d_leakyRelu /
+    conv2dTranspose_leakyRelu tails, models/m_submodule.py:18-27,36-45; slope = 1: a plain bias), forward and backward in one
+    pass each on csrc/bn_train.hip."""
+
+    @staticmethod
+    def forward(ctx, x, bias, slope):
+        x_cl = x.permute(0, 2, 3, 1).contiguous()
+        C = x_cl.shape[-1]
+        y = ops.bias_lrelu_cl_fwd(x_cl.view(-1, C), bias, slope)
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        ctx.shape = x_cl.shape
+        return y.view(x_cl.shape).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, = ctx.saved_tensors
+        C = y.shape[-1]
+        gx, gb = ops.bias_lrelu_cl_bwd(y, gy.permute(0, 2, 3, 1).contiguous().view(-1, C), ctx.slope)
+        return gx.view(ctx.shape).permute(0, 3, 1, 2), gb, None
+
+
+def _bias_act(y, bias, slope):
+    """+ bias, then LeakyReLU(slope) if slope is given: fused when there is a bias and the tensor is on the device."""
+    if bias is not None and y.is_cuda and y.dtype == torch.float32 and y.shape[1] % 4 == 0 and y.shape[1] <= 1024:
+        return BiasLeakyReLUCL.apply(y, bias, 1.0 if slope is None else float(slope))
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    return y if slope is None else torch.nn.functional.leaky_relu(y, slope)
+
+
 class UpsampleBilinearCL(torch.autograd.Function):
     """F.upsample(bilinear, align_corners=True) of the tiny SPP maps (models/psm_submodule.py:153-158) under autograd, both
     directions on csrc/spp.hip.  x is an NCHW tensor (channels_last memory: the NHWC view is free); so is the result."""
@@ -286,7 +318,7 @@ def _tap_select(kind, device):
     return hit
 
 
-def _conv3x3_cl(x, w, dil, bias, keep_width=False):
+def _conv3x3_cl(x, w, dil, bias, keep_width=False, act_slope=None):
     """3x3 stride-1 convolution through Conv2dCL, the channel counts zero-padded to widths the kernels have (67 -> 96 for the
     R-Net's full-resolution layers, 12 -> 16 for the space-to-depth image).  None if no width fits.
     x may already carry MORE channels than w reads (the padded output of the previous layer: its extra channels are zero).
@@ -306,14 +338,14 @@ def _conv3x3_cl(x, w, dil, bias, keep_width=False):
     if co != cout:
         w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, co - cout))
     y = Conv2dCL.apply(x, w, dil)
-    if bias is not None:            # on the full-width channels-last tensor: the bias gradient is a contiguous column sum
-        y = y + (bias if co == cout else F.pad(bias, (0, co - cout))).view(1, -1, 1, 1)
+    # bias (+ LeakyReLU) on the full-width channels-last tensor (the padded channels stay exactly zero: zero weights, zero bias)
+    y = _bias_act(y, None if bias is None else (bias if co == cout else F.pad(bias, (0, co - cout))), act_slope)
     if co != cout and not keep_width:
         y = y[:, :cout]
     return y
 
 
-def conv2d_module(conv, x, _any_device=False, keep_width=False):
+def conv2d_module(conv, x, _any_device=False, keep_width=False, act_slope=None):
     """nn.Conv2d forward for the module (autograd) paths, on the hand-written kernels in all three directions:
       * 3x3, stride 1, padding = dilation: Conv2dCL (channels zero-padded to a width the kernels have when needed: the R-Net's
         67-channel layers run as 96-wide ones);
@@ -328,25 +360,25 @@ def conv2d_module(conv, x, _any_device=False, keep_width=False):
     k, st, pd, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
     if not ((x.is_cuda or _any_device) and x.dtype == torch.float32 and conv.groups == 1 and k[0] == k[1] and st[0] == st[1] and d[0] == d[1]
             and pd[0] == pd[1] and conv.padding_mode == "zeros"):
-        return conv(x)
+        return _bias_act(conv(x), None, act_slope)
     w, y = conv.weight, None
     if k == (3, 3) and st == (1, 1) and pd == d:
-        y = _conv3x3_cl(x, w, d[0], conv.bias, keep_width)
+        y = _conv3x3_cl(x, w, d[0], conv.bias, keep_width, act_slope)
     elif k == (1, 1) and pd == (0, 0) and st[0] in (1, 2):
         xs = x if st[0] == 1 else x[:, :, ::2, ::2]
-        y = _conv3x3_cl(xs, F.pad(w, (1, 1, 1, 1)), 1, conv.bias)
+        y = _conv3x3_cl(xs, F.pad(w, (1, 1, 1, 1)), 1, conv.bias, False, act_slope)
     elif k == (3, 3) and st == (2, 2) and pd == (1, 1) and d == (1, 1) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
         idx, msk = _tap_select("s2", w.device)
         cout, cin = w.shape[:2]
         # pixel_unshuffle orders its channels c * 4 + py * 2 + px
         w2 = (w.reshape(cout, cin, 9).index_select(2, idx) * msk).reshape(cout, cin * 4, 3, 3)
-        y = _conv3x3_cl(F.pixel_unshuffle(x, 2), w2, 1, conv.bias)
+        y = _conv3x3_cl(F.pixel_unshuffle(x, 2), w2, 1, conv.bias, False, act_slope)
     if y is None:
-        return conv(x[:, :conv.in_channels] if x.shape[1] != conv.in_channels else x)
+        return _bias_act(conv(x[:, :conv.in_channels] if x.shape[1] != conv.in_channels else x), None, act_slope)
     return y
 
 
-def conv_transpose2d_module(conv, x, _any_device=False):
+def conv_transpose2d_module(conv, x, _any_device=False, act_slope=None):
     """nn.ConvTranspose2d(kernel 4, stride 2, padding 1) of the R-Net (models/Refine.py:51-77, m_submodule.py:36-45) under autograd
     on the hand-written kernels: its four sub-pixel phases are 2x2-tap convolutions of the input (`_T2_TAP`); embedded in 3x3
     kernels and stacked along the output channels (4 Cout, ordered co * 4 + a * 2 + b) they are ONE Conv2dCL launch per direction,
@@ -354,14 +386,16 @@ def conv_transpose2d_module(conv, x, _any_device=False):
     F = torch.nn.functional
     if not ((x.is_cuda or _any_device) and x.dtype == torch.float32 and conv.groups == 1 and conv.kernel_size == (4, 4) and conv.stride == (2, 2)
             and conv.padding == (1, 1) and conv.output_padding == (0, 0) and conv.dilation == (1, 1)):
-        return conv(x)
+        return _bias_act(conv(x), None, act_slope)
     w = conv.weight                                  # [Cin, Cout, 4, 4]
     cin, cout = w.shape[:2]
     idx, msk = _tap_select("t2", w.device)
     w4 = (w.permute(1, 0, 2, 3).reshape(cout, cin, 16).index_select(2, idx) * msk)       # [Cout, Cin, (a, b, r, c)]
     w4 = w4.reshape(cout, cin, 4, 9).permute(0, 2, 1, 3).reshape(cout * 4, cin, 3, 3)   # rows co * 4 + (a * 2 + b)
-    y = _conv3x3_cl(x, w4, 1, None)
+    # bias + LeakyReLU commute with the interleave: applied to the four phases at once (bias of output channel co on its rows
+    # co * 4 .. co * 4 + 3) BEFORE pixel_shuffle, on the channels-last tensor the convolution wrote
+    b4 = None if conv.bias is None else conv.bias.repeat_interleave(4)
+    y = _conv3x3_cl(x, w4, 1, b4, False, act_slope)
     if y is None:
-        return conv(x)
-    y = F.pixel_shuffle(y, 2)
-    return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
+        return _bias_act(conv(x), None, act_slope)
+    return F.pixel_shuffle(y, 2)

@@ -159,6 +159,69 @@ __global__ __launch_bounds__(kBnclThreads) void bn_cl_bwd_apply_kernel(const flo
     *reinterpret_cast<float4*>(gx + 4 * i) = o;
 }
 
+// ---- bias + LeakyReLU of the R-Net's conv2d_leakyRelu / conv2dTranspose_leakyRelu blocks (models/m_submodule.py:18-27,36-45)
+// under autograd, channels-last [rows][C]: ONE pass forward (y = lrelu(x + b)), ONE pass backward (gx = gy * lrelu'(y), the bias
+// gradient's per-workgroup partial sums in the same pass) instead of torch's add / leaky_relu / leaky_relu_backward / sum.
+// slope = 1: the plain bias add of Refine.py:71.  Lane = (row slot, channel quad): Q = C / 4 quads, S = 256 / Q slots (floor:
+// widths like 96 leave 256 - S Q lanes idle).
+__global__ __launch_bounds__(kBnclThreads) void bias_lrelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                                      float slope, float* __restrict__ y, long n4, int C) {
+    const long i = (long)blockIdx.x * kBnclThreads + threadIdx.x;
+    if (i >= n4) return;
+    const int q = (int)(i % (C >> 2));
+    const float4 b = ld4(bias + 4 * q), v = ld4(x + 4 * i);
+    float4 o = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+    o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
+    o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+    *reinterpret_cast<float4*>(y + 4 * i) = o;
+}
+
+__global__ __launch_bounds__(kBnclThreads) void bias_lrelu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                                                      float slope, float* __restrict__ gx, float* __restrict__ partial,
+                                                                      long rows, int C) {
+    __shared__ float4 sh1[kBnclThreads];
+    const int Q = C >> 2, S = kBnclThreads / Q, tid = threadIdx.x;
+    const int q = tid % Q, slot = tid / Q;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (slot < S) {
+        const long step = (long)gridDim.x * S;
+#pragma unroll 4
+        for (long r = (long)blockIdx.x * S + slot; r < rows; r += step) {
+            const float4 v = ld4(y + r * C + 4 * q);
+            float4 g = ld4(gy + r * C + 4 * q);
+            g.x = v.x > 0.f ? g.x : g.x * slope; g.y = v.y > 0.f ? g.y : g.y * slope;
+            g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
+            *reinterpret_cast<float4*>(gx + r * C + 4 * q) = g;
+            a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+        }
+    }
+    sh1[tid] = a;
+    __syncthreads();
+    if (tid < Q) {
+        for (int s = 1; s < S; ++s) {
+            const float4 u = sh1[s * Q + tid];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        }
+        *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * C + 4 * tid) = a;
+    }
+}
+
+// g_bias[c] = sum over the workgroups' partials, in double, fixed order
+__global__ __launch_bounds__(kBnclThreads) void bias_lrelu_finalize_kernel(const float* __restrict__ partial, int G, int C,
+                                                                           float* __restrict__ g_bias) {
+    const int c = blockIdx.x * kBnclThreads + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) s += (double)partial[(size_t)g * C + c];
+    g_bias[c] = (float)s;
+}
+
+static int bias_lrelu_groups(long rows, int C) {
+    const int S = kBnclThreads / (C >> 2);
+    const long g = (rows + (long)S * 24 - 1) / ((long)S * 24);
+    return (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
+}
+
 static bool bn_cl_shape_ok(long rows, int C) {
     return rows > 0 && C >= 4 && C <= 1024 && (C & 3) == 0 && kBnclThreads % (C >> 2) == 0;
 }
@@ -207,6 +270,36 @@ extern "C" int nrgbd_bn_cl_bwd(const float* x, const float* gy, const float* coe
     const long n4 = rows * (C >> 2);
     hipLaunchKernelGGL(bn_cl_bwd_apply_kernel, dim3((unsigned)ceil_div(n4, (long)kBnclThreads)), dim3(kBnclThreads), 0, s, x, gy, coef,
                        coef2, relu, gx, n4, C);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+/* bias + LeakyReLU on channels-last rows (autograd path of the R-Net): see the kernels above. */
+extern "C" int nrgbd_bias_lrelu_cl_workgroups(long rows, int C) {
+    if (rows <= 0 || C < 4 || C > 1024 || (C & 3)) return NRGBD_E_SHAPE;
+    return nrgbd::bias_lrelu_groups(rows, C);
+}
+
+extern "C" int nrgbd_bias_lrelu_cl_fwd(const float* x, const float* bias, float slope, float* y, long rows, int C, void* stream) {
+    using namespace nrgbd;
+    if (!x || !bias || !y) return NRGBD_E_NULL;
+    if (rows <= 0 || C < 4 || C > 1024 || (C & 3)) return NRGBD_E_SHAPE;
+    const long n4 = rows * (C >> 2);
+    hipLaunchKernelGGL(bias_lrelu_fwd_kernel, dim3((unsigned)ceil_div(n4, (long)kBnclThreads)), dim3(kBnclThreads), 0, (hipStream_t)stream,
+                       x, bias, slope, y, n4, C);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
+extern "C" int nrgbd_bias_lrelu_cl_bwd(const float* y, const float* gy, float slope, float* gx, float* g_bias, float* partial,
+                                       long rows, int C, void* stream) {
+    using namespace nrgbd;
+    if (!y || !gy || !gx || !g_bias || !partial) return NRGBD_E_NULL;
+    if (rows <= 0 || C < 4 || C > 1024 || (C & 3)) return NRGBD_E_SHAPE;
+    const int G = bias_lrelu_groups(rows, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bias_lrelu_bwd_kernel, dim3(G), dim3(kBnclThreads), 0, s, y, gy, slope, gx, partial, rows, C);
+    hipLaunchKernelGGL(bias_lrelu_finalize_kernel, dim3((C + kBnclThreads - 1) / kBnclThreads), dim3(kBnclThreads), 0, s, partial, G, C, g_bias);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -881,17 +881,17 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         quarter, half, full = img_features
         from .autograd import conv2d_module, conv_transpose2d_module
 
-        def cl(m, x):   # conv2d_leakyRelu block: the convolution on the hand-written kernels where they apply
-            return F.leaky_relu(conv2d_module(m[0], x), 0.01)
+        def cl(m, x):   # conv2d_leakyRelu block: convolution + fused bias / LeakyReLU(0.01) on the hand-written kernels
+            return conv2d_module(m[0], x, act_slope=0.01)
 
         def tl(m, x):   # conv2dTranspose_leakyRelu block (four sub-pixel phases as one 3x3 launch per direction)
-            return F.leaky_relu(conv_transpose2d_module(m[0], x), 0.01)
+            return conv_transpose2d_module(m[0], x, act_slope=0.01)
         x = cl(self.conv0_1, cl(self.conv0, torch.cat([dpv_raw, quarter], dim=1)))
         x = tl(self.trans_conv0, x)
         x = cl(self.conv1_1, cl(self.conv1, torch.cat([x, half], dim=1)))
         x = tl(self.trans_conv1, x)
         # conv2 (67 -> 67) runs 96 wide; its padded output (29 exact zeros: zero weights, zero bias, LeakyReLU(0) = 0) feeds
         # conv2_1 as it is — no channel slice, no re-padding at full resolution
-        x = F.leaky_relu(conv2d_module(self.conv2[0], torch.cat([x, full], dim=1), keep_width=True), 0.01)
+        x = conv2d_module(self.conv2[0], torch.cat([x, full], dim=1), keep_width=True, act_slope=0.01)
         x = conv2d_module(self.conv2_2, cl(self.conv2_1, x))
         return F.log_softmax(x, dim=1)

@@ -737,6 +737,34 @@ def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, 
     return ss
 
 
+def bias_lrelu_cl_fwd(x, bias, slope):
+    """y = leaky_relu(x + bias, slope) on channels-last rows x [rows, C] (nrgbd_bias_lrelu_cl_fwd)."""
+    x = _need(x, "x")
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_bias_lrelu_cl_fwd(_p(x), _p(_need(bias, "bias", (C,))), float(slope), _p(y), rows, C, _stream(x))
+    _lib.check(rc, "nrgbd_bias_lrelu_cl_fwd")
+    return y
+
+
+def bias_lrelu_cl_bwd(y, gy, slope):
+    """Backward of bias_lrelu_cl_fwd from its OUTPUT y: (gx [rows, C], g_bias [C])."""
+    y = _need(y, "y")
+    rows, C = y.shape
+    gy = _need(gy, "gy", (rows, C))
+    gx = torch.empty_like(y)
+    gb = torch.empty((C,), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        lib = _lib.load()
+        G = lib.nrgbd_bias_lrelu_cl_workgroups(rows, C)
+        _lib.check(min(G, 0), "nrgbd_bias_lrelu_cl_workgroups")
+        partial = torch.empty((G, C), dtype=torch.float32, device=y.device)
+        rc = lib.nrgbd_bias_lrelu_cl_bwd(_p(y), _p(gy), float(slope), _p(gx), _p(gb), _p(partial), rows, C, _stream(y))
+    _lib.check(rc, "nrgbd_bias_lrelu_cl_bwd")
+    return gx, gb
+
+
 def upsample_bilinear_ac(x, H, W, backward=False):
     """Bilinear up-sampling (align_corners=True) of a channels-last map x [N,bh,bw,C] -> [N,H,W,C] (nrgbd_upsample_bilinear_ac);
     backward=True: x is the gradient of the output [N,H2,W2,C] and (H, W) the INPUT size -> gradient of the input [N,H,W,C]."""

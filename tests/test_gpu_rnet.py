@@ -140,3 +140,22 @@ def test_rnet_block_in_the_winograd_domain(N, H, W, Cin, Cout):
     err = (got.permute(0, 3, 1, 2).double() - want).abs().max().item()
     print("[parity] R-Net block (Winograd) N%d %dx%d %d->%d: max|d vs fp64|=%.2e" % (N, H, W, Cin, Cout, err))
     assert err < 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("N,C,H,W,slope", [(1, 128, 16, 24, 0.01), (2, 96, 32, 48, 0.01), (1, 64, 64, 96, 1.0), (1, 256, 9, 11, 0.01), (1, 8, 5, 7, 0.01)])
+def test_bias_leaky_relu_fused_forward_and_backward(N, C, H, W, slope):
+    """autograd.BiasLeakyReLUCL (the bias + LeakyReLU tail of the R-Net blocks under autograd, m_submodule.py:18-27,36-45; slope 1 =
+    the plain bias of Refine.py:71) against torch's add + leaky_relu and their autograd in float64."""
+    from neuralrgbd_amd.autograd import BiasLeakyReLUCL
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn(C, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(N, C, H, W, generator=g).to(DEV)
+    y = BiasLeakyReLUCL.apply(x, b, slope)
+    gx, gb = torch.autograd.grad(y, (x, b), gy)
+    xd, bd = x.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    yd = F.leaky_relu(xd + bd.view(1, -1, 1, 1), slope)
+    gxd, gbd = torch.autograd.grad(yd, (xd, bd), gy.double())
+    assert (y.double() - yd).abs().max().item() < 1e-6
+    assert (gx.double() - gxd).abs().max().item() < 1e-6
+    assert (gb.double() - gbd).abs().max().item() < 2e-5 * max(1.0, gbd.abs().max().item())
