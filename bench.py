@@ -19,7 +19,7 @@ The JSON line carries
                 algorithmic bytes 4[(V+1)*67*hw + D*hw] per launch / its mean launch duration, measured
                 with HIP events on the launch stream inside the timed steps (peak 8.0 TB/s);
                 `traffic` = HBM-side bytes per launch from a committed rocprofv3 --pmc measurement of this bench's
-                own windows (tools/pmc_traffic.sh -> profiles/r3_costvol_traffic.json), reported only while the kernel's
+                own windows (tools/pmc_traffic.sh -> profiles/r4_costvol_traffic.json), reported only while the kernel's
                 sources still hash to what the measurement recorded;
   cpu_baseline  the CPU oracle (oracle/kvnet_oracle.py: the reference algorithm restated on torch-CPU
                 + the C sampling oracle) timed on this node's host cores on update frames of the same
@@ -53,7 +53,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (256
 # `bench.py --no-graph` under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) and writes the per-launch mean of
 # the costvol kernel's dispatches to profiles/r2_costvol_traffic.json (FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
 # prescribes for gfx950).  Configs without an entry report null.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_costvol_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r4_costvol_traffic.json")
 COSTVOL_SOURCES = ("costvol_quad.hip", "costvol.hip", "costvol.hpp", "common.hpp")   # what the measured kernel is built from
 
 
