@@ -120,3 +120,80 @@ def test_two_replicas_of_the_real_training_step_stay_bit_identical():
     assert a["hash"] == b["hash"]
     assert a["losses"] != b["losses"]
     assert a["n_buckets"] >= 3 and max(a["hooks"]) >= 2
+
+
+def _graph_replica(rank, world, port, q):
+    """One data-parallel replica of the hipGraph training step in its SPLIT form (train_step.TrainGraph with a gradient reducer and
+    accum_steps = 2): graph 1 (forward + backward + PREDICT) replayed per window, the bucketed all-reduce between the graphs (gloo
+    on device tensors: both replicas share the box's GPU), graph 2 (Adam).  What bench.py --mode train runs at N > 1."""
+    import hashlib
+    import os
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    import neuralrgbd_amd
+    from neuralrgbd_amd import camera, distributed as nd, synth
+    from neuralrgbd_amd.test_step import test as infer
+    from neuralrgbd_amd.train_step import TrainGraph
+    try:
+        nd.init_from_env("gloo")
+        H, W, D, A = 256, 256, 8, 2
+        cam = camera.scannet_intrinsics(W // 4, H // 4)
+        d_candi = np.linspace(0.1, 5, D)
+        model = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+        model.load_state_dict(synth.seeded_state_dict(model, 0))
+        model = model.to(DEV)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(.9, .999), capturable=True)
+        reducer = nd.GradAllReduce(model, bucket_mb=4.0)
+        tg = TrainGraph(model, opt, 2, d_candi, cam, warmup=1, grad_reducer=reducer, accum_steps=A)
+        rng = np.random.RandomState(20 + rank)
+
+        def window(i):
+            r, s, p = synth.noise_window(2000 * rank + i, H, W)          # different windows on each replica
+            return (r.to(DEV), s.to(DEV), p.to(DEV), torch.from_numpy(rng.randint(0, D, (1, H // 4, W // 4))).to(DEV),
+                    torch.from_numpy(rng.randint(0, D, (1, H, W))).to(DEV))
+        preds = []
+        with torch.no_grad():
+            for k in range(A):
+                r, s, p, _, _ = window(100 + k)
+                preds.append(infer(model, d_candi, [cam], 2, [{"img": r}], [[{"img": s[0, v:v + 1]} for v in range(4)]], p, None)[1])
+        losses = []
+        for it in range(3):                                  # eager warm-up step, capture step, replay step
+            wins = [window(10 * it + k) + (preds[k],) for k in range(A)]
+            loss, preds = tg.step_windows(wins)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for _, prm in sorted(model.named_parameters()):
+            h.update(prm.detach().cpu().numpy().tobytes())
+        q.put((rank, {"hash": h.hexdigest(), "losses": losses, "captured": tg._graph is not None and tg._g_opt is not None,
+                      "adam_steps": float(opt.state[next(iter(model.kv_net.parameters()))]["step"])}))
+        dist.barrier()
+    except Exception as e:          # report instead of hanging the parent
+        q.put((rank, {"error": repr(e)}))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_replicas_of_the_split_train_graph_stay_bit_identical():
+    """the training path benchmarked at N > 1 — hipGraph kept, gradients accumulated over 2 windows, ONE
+    bucketed all-reduce between the forward/backward graph and the optimizer graph — on two ranks with different windows: every
+    parameter bit-identical afterwards, three Adam steps taken, different losses per rank."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_graph_replica, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    for r in range(world):
+        assert "error" not in res[r], res[r]
+    a, b = res[0], res[1]
+    print("[dist] split train graph replicas: losses %s vs %s" % (a["losses"], b["losses"]))
+    assert a["captured"] and b["captured"] and a["adam_steps"] == b["adam_steps"] == 3.0
+    assert a["hash"] == b["hash"]
+    assert a["losses"] != b["losses"]
