@@ -293,7 +293,7 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         """Bilinear up-sampling (align_corners=True) of the tiny SPP maps.  Under autograd both directions run on csrc/spp.hip
         (autograd.UpsampleBilinearCL): the backward of F.interpolate scatters every output gradient into a handful of inputs
         with atomics (0.82 ms per branch at the ScanNet grid), the hand-written adjoint sums each input in a fixed order."""
-        if y.is_cuda and torch.is_grad_enabled() and y.dtype == torch.float32 and y.shape[1] % 4 == 0:
+        if y.is_cuda and torch.is_grad_enabled() and y.dtype == torch.float32 and y.shape[1] % 4 == 0 and y.shape[1] <= 256:
             from .autograd import UpsampleBilinearCL
             return UpsampleBilinearCL.apply(y, int(size[0]), int(size[1]))
         return F.interpolate(y, size=size, mode="bilinear", align_corners=True)
