@@ -500,6 +500,12 @@ int nrgbd_spp_concat(const float* quarter, int Cq, const float* deep, int Cd,
                      const float* bz2, const float* bss2, int bh2, int bw2, const float* bz3, const float* bss3, int bh3, int bw3,
                      int Cb, float* out, int N, int h, int w, void* stream);
 /*
+ * nrgbd_logsoftmax_rows — log_softmax over the channels of channels-last rows x [rows][C] (y may be x), C in {64, 128}.
+ * Replaces: F.log_softmax(conv2_2_out, dim=1) of models/Refine.py:104 once the last R-Net convolution runs on the Winograd kernel
+ * (nrgbd_conv_wino_rnet_ex_f32), whose pixels are channels-last; the refined DPV is then an [N, D, H, W] VIEW of that memory.
+ */
+int nrgbd_logsoftmax_rows(const float* x, float* y, long rows, int C, void* stream);
+/*
  * nrgbd_bias_lrelu_cl_fwd / _bwd — y = leaky_relu(x + bias[c], slope) on channels-last rows [rows][C] and its backward
  * (training path of the R-Net).  Replaces: the bias add + nn.LeakyReLU of m_submodule.conv2d_leakyRelu /
  * conv2dTranspose_leakyRelu (models/m_submodule.py:18-27,36-45; slope = 1: the bias of Refine.py:71) and, in backward, ATen's

@@ -150,6 +150,41 @@ __global__ __launch_bounds__(256) void export_depth_u16_kernel(const float* __re
 
 }  // namespace nrgbd
 
+namespace nrgbd {
+// log_softmax over the channels of channels-last rows x [rows][C] (C = 64: 16 lanes x 16 bytes per row; C = 128: 32 lanes): the
+// R-Net's last layer (models/Refine.py:104 F.log_softmax(conv2_2_out, dim=1)) after its convolution moved to the Winograd kernel,
+// whose epilogue writes pixels channels-last.  One HBM pass (read + write, in place allowed); the reduction over a row is a
+// butterfly of DPP / swizzle shuffles inside its lane group, in a fixed order.
+template <int LPR>      // lanes per row
+__global__ __launch_bounds__(256) void logsoftmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long rows) {
+    const long r = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int q = threadIdx.x % LPR;
+    const bool live = r < rows;
+    const long rr = live ? r : rows - 1;
+    const float4 v = *reinterpret_cast<const float4*>(x + (rr * LPR + q) * 4);
+    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float s = (expf(v.x - m) + expf(v.y - m)) + (expf(v.z - m) + expf(v.w - m));
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float ls = logf(s);
+    if (live) *reinterpret_cast<float4*>(y + (r * LPR + q) * 4) = make_float4((v.x - m) - ls, (v.y - m) - ls, (v.z - m) - ls, (v.w - m) - ls);
+}
+}  // namespace nrgbd
+
+extern "C" int nrgbd_logsoftmax_rows(const float* x, float* y, long rows, int C, void* stream) {
+    using namespace nrgbd;
+    if (!x || !y) return NRGBD_E_NULL;
+    if (rows <= 0 || (C != 64 && C != 128)) return NRGBD_E_SHAPE;
+    const long threads = rows * (C / 4);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (C == 64) hipLaunchKernelGGL(logsoftmax_rows_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, y, rows);
+    else hipLaunchKernelGGL(logsoftmax_rows_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, y, rows);
+    NRGBD_CHECK_LAUNCH();
+    return NRGBD_OK;
+}
+
 extern "C" int nrgbd_logsoftmax_d(const float* a, const float* b, float scale, float* out, int D,
                                   long n, void* stream) {
     if (!a || !out) return NRGBD_E_NULL;

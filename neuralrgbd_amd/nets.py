@@ -793,7 +793,7 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         def wino(m):
             """Winograd-domain stream of a conv2d_leakyRelu layer for the persistent kernel's R-Net form, widths padded with zero
             weights to Cin % 32 == 0 (the buffer it reads) and Cout % 64 == 0; (stream, bias, packed columns, valid columns)."""
-            c = m[0]
+            c = m[0] if isinstance(m, nn.Sequential) else m
             w, b = c.weight.detach(), c.bias.detach()
             cin_p, cout_p = pad32(w.shape[1]), (w.shape[0] + 63) // 64 * 64
             wp = w.new_zeros(cout_p, cin_p, 3, 3)
@@ -806,7 +806,8 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                "conv0_w": wino(self.conv0), "conv0_1_w": wino(self.conv0_1), "conv1_w": wino(self.conv1),
                "conv1_1_w": wino(self.conv1_1), "conv2_w": wino(self.conv2), "conv2_1_w": wino(self.conv2_1),
                "conv1": conv(self.conv1), "conv1_1": conv(self.conv1_1), "t1": deconv(self.trans_conv1),
-               "conv2": conv(self.conv2), "conv2_1": conv(self.conv2_1), "conv2_2": conv(self.conv2_2)}
+               "conv2": conv(self.conv2), "conv2_1": conv(self.conv2_1), "conv2_2": conv(self.conv2_2),
+               "conv2_2_w": wino(self.conv2_2)}
         cache["key"], cache["val"] = key, val
         return val
 
@@ -871,6 +872,13 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         conv(x, pk["t1"]["all"], c2, mode=3)
         c2[..., D:D + 3].copy_(full.permute(0, 2, 3, 1))
         x = conv_w(conv_w(c2, "conv2", buf["g2"]), "conv2_1", buf["h2"])
+        if D in (64, 128) and x.shape[-1] == D:
+            # conv2_2 + bias on the Winograd kernel (pixels channels-last), then log-softmax over the D channels of every pixel in
+            # place: the refined DPV is handed out as an [n, D, H, W] VIEW of that channels-last memory (round 4; the direct kernel
+            # with the log-softmax epilogue and a planar store took 1.0 ms at config B)
+            w = pk["conv2_2_w"]
+            z = ops.conv_wino_rnet(x, w[0], w[2], bias=w[1], lrelu=False, cout_valid=w[3])
+            return ops.logsoftmax_rows(z).permute(0, 3, 1, 2)
         wp, bias, wdt, _, _ = pk["conv2_2"][0]
         return ops.conv2d_rnet(x, wp, wdt, bias=bias, lrelu=False, mode=2)
 

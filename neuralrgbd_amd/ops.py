@@ -737,6 +737,17 @@ def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, 
     return ss
 
 
+def logsoftmax_rows(x, inplace=True):
+    """log_softmax over the last (channel) axis of a contiguous channels-last tensor [..., C], C in {64, 128} (nrgbd_logsoftmax_rows)."""
+    x = _need(x, "x")
+    C = x.shape[-1]
+    y = x if inplace else torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_logsoftmax_rows(_p(x), _p(y), x.numel() // C, int(C), _stream(x))
+    _lib.check(rc, "nrgbd_logsoftmax_rows")
+    return y
+
+
 def bias_lrelu_cl_fwd(x, bias, slope):
     """y = leaky_relu(x + bias, slope) on channels-last rows x [rows, C] (nrgbd_bias_lrelu_cl_fwd)."""
     x = _need(x, "x")
