@@ -326,128 +326,150 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv3d_mfma_kernel(const Conv
 }
 
 // Last K-Net layer (models/basic.py:92-94: Conv3d(64, 1, 3, padding=1, bias=False), no BatchNorm).
-// One output channel leaves 31 of 32 MFMA columns empty if the taps are the K dimension, so the sum is re-associated:
+// One output channel leaves the MFMA columns empty if the taps are the K dimension, so the sum is re-associated:
 //     P[u][tap] = sum_c w[tap][c] * in[u][c]          a [halo voxels x 64] x [64 x 27(->32)] GEMM on the matrix cores
 //     out[v]    = sum_tap P[v + tap][tap]             27 scalar LDS reads per output voxel
-// i.e. every halo voxel is projected onto the 27 tap weights once (instead of 27 x 64 FMAs per output voxel fed by
-// 108 16-B LDS reads).  Tile and staging as in the main kernel; wave w owns the 32-voxel row tiles w, w+4, ...
-// of the 720-voxel halo (6 tiles = 96 accumulator VGPRs); P goes to LDS as [voxel][27] (odd stride: conflict-free for
-// lanes along x) over the staging buffer.  w1 is [27][64] (tap-major): a lane's B operand is 16 contiguous bytes of it.
-__global__ __launch_bounds__(256, 2) void conv3d_cout1_kernel(const Conv3dArgs a, const float* __restrict__ w1) {
-    constexpr int CIN = 64, NCBLK = CIN / kCB, G4 = kCB / 8;
-    constexpr int NT = (kHaloVox + 31) / 32;       // 23 row tiles
-    constexpr int TPW = (NT + 3) / 4;              // 6 per wave
-    constexpr int PS = 27;                         // P row stride (floats)
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // staging [kHaloVox][kSV], then P [kHaloVox][PS]
+// i.e. every input voxel is projected onto the 27 tap weights once.  The layer is a pure stream over an 805 MB tensor, so
+// the organisation is chosen for bytes, not for the (small) matrix work: a workgroup owns an 8x16-pixel column of `dz`
+// output slices and MARCHES along the depth axis — every input slice of its column is loaded, activated and projected
+// ONCE (the previous form projected a 2-slice tile's 4-slice halo: 2.8x the input per launch, 0.62 ms at the 192x256x64
+// grid); what is left is the 10x18 / 8x16 halo in the plane (neighbours share it in their XCD's L2) and two slices per
+// depth chunk.  Per slice: the 180 halo pixels x 64 channels of slice z+1 are in flight (12 16-B words per thread) while
+// slice z is projected (v_mfma_f32_16x16x4_f32: wave w owns pixel rows 48w .. 48w+47 x 32 tap columns), P goes to LDS as
+// [pixel][27] (odd stride: conflict-free along x) and 128 threads add the slice's three depth-tap sums to the running
+// outputs z+1 (kd = 0), z (kd = 1), z-1 (kd = 2, which completes and stores it).
+// w1 is [27][64] (tap-major): a lane's B operand is 16 contiguous bytes of it.
+constexpr int kC1TH = 8, kC1TW = 16, kC1HW = kC1TW + 2, kC1Pix = (kC1TH + 2) * kC1HW;   // 180 halo pixels per slice
+constexpr int kC1Img = kC1Pix * kSV + 16;      // floats of one channel block's LDS image (+16: the four images start in different banks)
+constexpr int kC1PS = 27;                      // P row stride (floats)
+constexpr int kC1NPF = 12;                     // 16-B words per thread and slice: pixel (tid >> 4) + 16 u, channels 4 (tid & 15) ..
+constexpr size_t kC1Lds = (size_t)(4 * kC1Img + kC1Pix * kC1PS) * sizeof(float);
+
+__global__ __launch_bounds__(256, 2) void conv3d_cout1_kernel(const Conv3dArgs a, const float* __restrict__ w1, int dz) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* stage = lds;                         // [4 channel blocks][180 pixels][16] (swizzled 16-B slots)
+    float* P = lds + 4 * kC1Img;                // [180 pixels][27 taps]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tiles_x = (a.W + kTW - 1) / kTW, tiles_y = (a.H + kTH - 1) / kTH;
-    int tx, ty, tz;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x, a.xcd), tiles_x, tiles_y, (a.D + kTD - 1) / kTD, a.xcd, tx, ty, tz);
-    const int x0 = tx * kTW, y0 = ty * kTH, z0 = tz * kTD;
+    const int tiles_x = (a.W + kC1TW - 1) / kC1TW, tiles_y = (a.H + kC1TH - 1) / kC1TH;
+    int t = xcd_tile(blockIdx.x, gridDim.x, 1);  // an XCD works on a contiguous run of columns: in-plane halos meet in its L2
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y, cz = t / tiles_y;
+    const int x0 = tx * kC1TW, y0 = ty * kC1TH, zc0 = cz * dz, zc1 = min(zc0 + dz, a.D);
 
-    const int i = lane & 31, khalf = lane >> 5;
-    int dy, px;
-    row_to_yx(i, dy, px);                          // MFMA row i <-> voxel 32*tile + 16*dy + px (16 consecutive voxels per lane group)
-    f32x16 acc[TPW];
+    // ---- loader role: word u of this thread = halo pixel (tid >> 4) + 16 u, channels 4 c16 .. 4 c16 + 3
+    const int c16 = tid & 15;
+    unsigned pf_off[kC1NPF], pf_ok = 0;
 #pragma unroll
-    for (int k = 0; k < TPW; ++k)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
-
-    // input words of a channel block: thread word u = halo voxel (tid>>2) + 64u, 16-B word tid&3 — all 12 loads of the
-    // next block are issued together right after the barrier and land while this block's MFMAs run
-    constexpr int NPF = (kHaloVox * (kCB / 4) + 255) / 256;
-    const int c4 = tid & 3;
-    unsigned pf_off[NPF], pf_ok = 0;
-    f32x4 pre[NPF];
-#pragma unroll
-    for (int u = 0; u < NPF; ++u) {
-        const int hv = (tid >> 2) + 64 * u;
-        const int hz = hv / (kHH * kHW), rem = hv - hz * (kHH * kHW);
-        const int hy = rem / kHW, hx = rem - hy * kHW;
-        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        const bool ok = hv < kHaloVox && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        pf_off[u] = ok ? (unsigned)((((size_t)gz * a.H + gy) * a.W + gx) * CIN + c4 * 4) : (unsigned)(c4 * 4);
+    for (int u = 0; u < kC1NPF; ++u) {
+        const int p = (tid >> 4) + 16 * u;
+        const int hy = p / kC1HW, hx = p - hy * kC1HW;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = p < kC1Pix && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        pf_off[u] = (ok ? (unsigned)(gy * a.W + gx) * 64u : 0u) + (unsigned)(c16 * 4);   // an outside word reads a harmless in-tensor one
         if (ok) pf_ok |= 1u << u;
     }
+    float ss[8] = {1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f};
+    if (a.x_ss) {
 #pragma unroll
-    for (int u = 0; u < NPF; ++u) pre[u] = *reinterpret_cast<const f32x4*>(a.x + pf_off[u]);
+        for (int e = 0; e < 8; ++e) ss[e] = a.x_ss[8 * c16 + e];
+    }
+    const size_t plane = (size_t)a.H * a.W * 64;
+    f32x4 pre[kC1NPF];
+    auto fetch = [&](int z) __attribute__((always_inline)) {
+        const float* xs = a.x + (size_t)z * plane;
+#pragma unroll
+        for (int u = 0; u < kC1NPF; ++u) pre[u] = *reinterpret_cast<const f32x4*>(xs + pf_off[u]);
+    };
 
-    for (int cblk = 0; cblk < NCBLK; ++cblk) {
-        {
-            const int c = cblk * kCB + c4 * 4;
-            float ss[8] = {1.f, 0.f, 1.f, 0.f, 1.f, 0.f, 1.f, 0.f};
-            if (a.x_ss) {
+    // ---- matrix role: pixel rows 16 (3 wv + rt) + (lane & 15), channel word kq of a block, tap columns 16 ct + (lane & 15)
+    const int kq = lane >> 4, n = lane & 15;
+    f32x4 B[4][2];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ss[e] = a.x_ss[2 * c + e];
-            }
+    for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int u = 0; u < NPF; ++u) {
-                const int hv = (tid >> 2) + 64 * u;
-                if (hv >= kHaloVox) continue;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((pf_ok >> u) & 1u) {   // zero padding applies to the ACTIVATED tensor
-                    v = pre[u];
-                    v.x = __builtin_fmaf(v.x, ss[0], ss[1]); v.y = __builtin_fmaf(v.y, ss[2], ss[3]);
-                    v.z = __builtin_fmaf(v.z, ss[4], ss[5]); v.w = __builtin_fmaf(v.w, ss[6], ss[7]);
-                    if (a.x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                }
-                *reinterpret_cast<f32x4*>(lds + lds_slot(hv, c4)) = v;
-            }
+        for (int ct = 0; ct < 2; ++ct) {
+            const int tap = 16 * ct + n;
+            B[cb][ct] = tap < 27 ? *reinterpret_cast<const f32x4*>(w1 + tap * 64 + cb * kCB + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        f32x4 B[G4];
+    int arow[3];
 #pragma unroll
-        for (int g = 0; g < G4; ++g)
-            B[g] = (i < 27) ? *reinterpret_cast<const f32x4*>(w1 + i * CIN + cblk * kCB + khalf * 8 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-        if (cblk + 1 < NCBLK) {
-#pragma unroll
-            for (int u = 0; u < NPF; ++u) pre[u] = *reinterpret_cast<const f32x4*>(a.x + pf_off[u] + (cblk + 1) * kCB);
-        }
-#pragma unroll
-        for (int k = 0; k < TPW; ++k) {
-            const int tile = wv + 4 * k;
-            if (tile < NT) {   // wave-uniform
-                int hv = tile * 32 + dy * 16 + px;
-                hv = hv < kHaloVox ? hv : kHaloVox - 1;   // rows beyond the halo (last tile) are computed and dropped
-#pragma unroll
-                for (int g = 0; g < G4; ++g) {
-                    const f32x4 A = *reinterpret_cast<const f32x4*>(lds + lds_slot(hv, khalf * 2 + g));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[e], B[g][e], acc[k], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
+    for (int rt = 0; rt < 3; ++rt) {
+        const int p = min(16 * (3 * wv + rt) + n, kC1Pix - 1);   // rows 180..191 of the last tile are computed and dropped
+        arow[rt] = p;
     }
+    // ---- gather role (threads 0..127): output pixel (oy, ox) of the column
+    const int ox = tid & 15, oy = (tid >> 4) & 7;
+    const float* pg = P + (oy * kC1HW + ox) * kC1PS;
+    const bool store_ok = tid < 128 && y0 + oy < a.H && x0 + ox < a.W;
+    float* yo = a.y + (size_t)(y0 + oy) * a.W + (x0 + ox);
+    float run_a = 0.f, run_b = 0.f;             // partial sums of outputs zz - 1 (kd = 0, 1 done) and zz (kd = 0 done)
 
-    // P -> LDS [voxel][27]
+    if (zc0 - 1 >= 0) fetch(zc0 - 1);
+    for (int zz = zc0 - 1; zz <= zc1; ++zz) {
+        const bool valid = zz >= 0 && zz < a.D;   // uniform; an outside slice is zero padding: it contributes nothing
+        if (valid) {
 #pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-        const int tile = wv + 4 * k;
-        if (tile < NT && i < 27) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                int ry, rx;
-                row_to_yx(row, ry, rx);
-                const int hv = tile * 32 + ry * 16 + rx;
-                if (hv < kHaloVox) lds[hv * PS + i] = acc[k][r];
+            for (int u = 0; u < kC1NPF; ++u) {
+                const int p = (tid >> 4) + 16 * u;
+                if (p >= kC1Pix) continue;
+                f32x4 v = pre[u];
+                v.x = __builtin_fmaf(v.x, ss[0], ss[1]); v.y = __builtin_fmaf(v.y, ss[2], ss[3]);
+                v.z = __builtin_fmaf(v.z, ss[4], ss[5]); v.w = __builtin_fmaf(v.w, ss[6], ss[7]);
+                if (a.x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (!((pf_ok >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding applies to the ACTIVATED tensor
+                *reinterpret_cast<f32x4*>(stage + (c16 >> 2) * kC1Img + lds_slot(p, c16 & 3)) = v;
             }
         }
-    }
-    __syncthreads();
-    const int ox = tid & 15, oy = (tid >> 4) & 7, oz = tid >> 7;
-    const int hv_base = (oz * kHH + oy) * kHW + ox;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        __syncthreads();
+        if (zz + 1 <= zc1 && zz + 1 < a.D) fetch(zz + 1);   // lands while this slice is projected and summed
+        if (valid) {
+            f32x4 acc[3][2];
 #pragma unroll
-    for (int tap = 0; tap < 27; tap += 3) {
-        const int kd = tap / 9, kh = (tap / 3) % 3;
-        const float* p = lds + (hv_base + (kd * kHH + kh) * kHW) * PS + tap;
-        s0 += p[0]; s1 += p[PS + 1]; s2 += p[2 * PS + 2];
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) {
+                    const f32x4 A = *reinterpret_cast<const f32x4*>(stage + cb * kC1Img + lds_slot(arow[rt], kq));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[e], B[cb][0][e], acc[rt][0], 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[e], B[cb][1][e], acc[rt][1], 0, 0, 0);
+                    }
+                }
+            }
+            // accumulator register r of a 16x16 block = row 4 kq + r, column n
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int p = 16 * (3 * wv + rt) + 4 * kq + r;
+                    if (p < kC1Pix) {
+                        P[p * kC1PS + n] = acc[rt][0][r];
+                        if (n < 27 - 16) P[p * kC1PS + 16 + n] = acc[rt][1][r];
+                    }
+                }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (valid) {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float* q = pg + (kh * kC1HW + kw) * kC1PS + kh * 3 + kw;
+                        g0 += q[0]; g1 += q[9]; g2 += q[18];
+                    }
+            }
+            const float done = run_a + g2;        // output zz - 1: its kd = 2 tap reads slice zz
+            if (store_ok && zz - 1 >= zc0 && zz - 1 < zc1) yo[(size_t)(zz - 1) * a.H * a.W] = done;
+            run_a = run_b + g1;
+            run_b = g0;
+        }
     }
-    const int gz = z0 + oz, gy = y0 + oy, gx = x0 + ox;
-    if (gz < a.D && gy < a.H && gx < a.W) a.y[((size_t)gz * a.H + gy) * a.W + gx] = (s0 + s1) + s2;
 }
 
 // weights [64][Cin][3][3][3] (torch layout) -> packed [tap][cblk][g][nfrag][lane = khalf*32 + j][4]
@@ -559,15 +581,20 @@ extern "C" int nrgbd_conv3d_3x3x3_cout1_f32(const float* x, const float* x_ss, i
     // the tap-projection kernel has no residual operand (the reference's classify branch has none, basic.py:92-94):
     // refuse one instead of silently ignoring it
     if (res || res_ss || res_relu) return NRGBD_E_ARG;
-    Conv3dArgs a{x, x_ss, res, res_ss, nullptr, nullptr, y, nullptr, x_relu, res_relu, D, H, W, dev_env_int("NRGBD_XCD")};
-    const int nwg = ceil_div(W, kTW) * ceil_div(H, kTH) * ceil_div(D, kTD);
-    const size_t lds = (size_t)kHaloVox * 27 * sizeof(float);  // P [720][27] (77.8 KB) over the 46 KB staging buffer
+    Conv3dArgs a{x, x_ss, res, res_ss, nullptr, nullptr, y, nullptr, x_relu, res_relu, D, H, W, 1};
+    // depth chunks: enough workgroups for ~3 rounds of the 512 resident ones, at least 8 slices each (a chunk re-reads 2)
+    const int cols = ceil_div(W, kC1TW) * ceil_div(H, kC1TH);
+    int nz = dev_env_int("NRGBD_C1_NZ");
+    if (nz <= 0) nz = ceil_div(1536, cols);
+    nz = nz < 1 ? 1 : (nz > ceil_div(D, 8) ? ceil_div(D, 8) : nz);
+    const int dz = ceil_div(D, nz);
+    nz = ceil_div(D, dz);
     // > 64 KB of dynamic LDS needs the opt-in; it is idempotent and costs ~1 us, so it is simply repeated per call
     // (no process-global flag: re-entrant from any thread on any device)
     hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_cout1_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC1Lds);
     if (ea != hipSuccess) return (int)ea;
-    hipLaunchKernelGGL(conv3d_cout1_kernel, dim3(nwg), dim3(256), lds, (hipStream_t)stream, a, w_tap_major);
+    hipLaunchKernelGGL(conv3d_cout1_kernel, dim3(cols * nz), dim3(256), kC1Lds, (hipStream_t)stream, a, w_tap_major, dz);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     const int NS = (a.Cin / kCB) * KD;         // stages per tile
 #ifdef NRGBD_DEV
     const int abl = a.abl;
+    const long t_entry = wall_clock64();
 #else
     constexpr int abl = 0;
 #endif
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         int buf = 0;
 #ifdef NRGBD_DEV
         long t_mfma = 0, t_bar = 0, t_epi = 0;
+        const long t_loop = wall_clock64();
 #endif
         for (int it = 0; it < count; ++it) {
             const int tnext = first + (it + 1 < count ? it + 1 : it) * step;
@@ -271,6 +273,8 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         if ((abl & 64) && a.stats && wv == 0 && lane == 0) {   // timing record over the first statistics rows (results invalid)
             float* o = a.stats + (size_t)blockIdx.x * 8;
             o[0] = (float)t_mfma; o[1] = (float)t_bar; o[2] = (float)t_epi; o[3] = (float)count;
+            float* o3 = a.stats + 8192 + (size_t)blockIdx.x * 4;   // absolute 100 MHz ticks (low 24 bits: exact in a float)
+            o3[0] = (float)(t_entry & 0xFFFFFF); o3[1] = (float)(t_loop & 0xFFFFFF); o3[2] = (float)(wall_clock64() & 0xFFFFFF); o3[3] = 0.f;
         }
 #endif
     } else {

@@ -67,6 +67,14 @@ def test_cout1_and_bn_finalize():
     want = F.conv3d(act[None], w1, padding=1)[0, 0]
     got = ops.conv3d_cout1(_cl(x), w1[0].reshape(C, 27).t().contiguous(), x_ss=ss, x_relu=True)
     assert (got - want).abs().max().item() < 1e-4
+    # the depth-marching form: several depth chunks (the last one ragged), ragged plane tiles, one slice, no activation
+    for (d2, h2, w2, act_on) in ((37, 24, 40, True), (20, 9, 16, False), (1, 8, 16, True), (9, 50, 70, True)):
+        x2 = torch.randn(C, d2, h2, w2, generator=g).to(DEV)
+        a2 = torch.relu(x2 * ss[:, 0, None, None, None] + ss[:, 1, None, None, None]) if act_on else x2
+        want2 = F.conv3d(a2.double()[None], w1.double(), padding=1)[0, 0]
+        got2 = ops.conv3d_cout1(_cl(x2), w1[0].reshape(C, 27).t().contiguous(), x_ss=ss if act_on else None, x_relu=act_on)
+        assert got2.shape == (d2, h2, w2)
+        assert (got2.double() - want2).abs().max().item() < 2e-5 * max(1.0, want2.abs().max().item()), (d2, h2, w2)
     # BatchNorm finalize: scale/shift reproduce F.batch_norm(training=True); running stats follow torch
     w = (torch.randn(64, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
     y, stats, _ = ops.conv3d(_cl(x), ops.conv3d_pack_weights(w))

@@ -24,3 +24,14 @@ print("tiles per workgroup: min %d max %d" % (tiles.min().item(), tiles.max().it
 per_tile = rec[:, [0, 1, 2, 4, 5, 6]] / tiles[:, None]
 names = ("mfma", "c-barrier", "epilogue", "publish", "transform", "p-barrier")
 print("10 ns ticks per TILE (%d stages), median over workgroups: " % ns + "  ".join("%s %.0f" % (n, v) for n, v in zip(names, per_tile.median(0).values.tolist())))
+ab = st.reshape(-1)[8192:8192 + 256 * 4].reshape(256, 4).double().cpu()
+t0 = ab[:, 0].min()
+rel = (ab[:, :3] - t0) % float(1 << 24)
+print("absolute 10 ns ticks from the first workgroup's entry: entry min/med/max %d/%d/%d  loop start %d/%d/%d  loop end %d/%d/%d"
+      % tuple(v for c in range(3) for v in (rel[:, c].min().item(), rel[:, c].median().item(), rel[:, c].max().item())))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ops.conv_wino(x, ww, Cout, 1, 1, x_ss=ss, x_relu=True)
+e1.record(); torch.cuda.synchronize()
+print("launch-to-launch %.1f us (developer build)" % (e0.elapsed_time(e1) * 50))
