@@ -506,6 +506,28 @@ int nrgbd_spp_concat(const float* quarter, int Cq, const float* deep, int Cd,
  */
 int nrgbd_logsoftmax_rows(const float* x, float* y, long rows, int C, void* stream);
 /*
+ * nrgbd_logsoftmax_d_bwd / nrgbd_logsoftmax_rows_bwd — backward of nrgbd_logsoftmax_d / nrgbd_logsoftmax_rows (training path):
+ * with out = log_softmax(z), g_z = g - exp(out) * sum_k g (the _d form returns scale * g_z = the gradient of its operand a;
+ * scale = 1 gives the gradient of b).  Replaces: autograd through torch.log_softmax at models/basic.py:299-300,
+ * models/KVNET.py:172-173 and models/Refine.py:104 (ATen's SpatialSoftMaxBackward).
+ *   _d:    logp, g, gz [D][n];   _rows: y, g, gx [rows][C], C in {64, 128}
+ */
+int nrgbd_logsoftmax_d_bwd(const float* logp, const float* g, float scale, float* gz, int D, long n, void* stream);
+int nrgbd_logsoftmax_rows_bwd(const float* y, const float* g, float* gx, long rows, int C, void* stream);
+/*
+ * nrgbd_nll_fwd / nrgbd_nll_bwd — F.nll_loss(logp [1, D, h, w], target [1, h, w], ignore_index) with mean reduction and its
+ * backward.  Replaces: the four loss terms of train_utils/train_KVNet.py:103-120 (ignore_index = 0: pixels without ground truth).
+ *   logp: planar [D][n] (channels_last = 0) or channels-last [n][D] (= 1: the refined DPV as the R-Net writes it); target [n] int64.
+ *   fwd:  partial [nrgbd_nll_workgroups(n)][2] scratch; out[0] = mean over the counted pixels (NaN when there is none, as ATen),
+ *         out[1] = their number.  A target outside [0, D) is not counted (ATen asserts).  Fixed summation order.
+ *   bwd:  g_out [1] (device), stat = fwd's out; g_logp in logp's layout, every element written (zeros off the target).
+ */
+int nrgbd_nll_workgroups(long n);
+int nrgbd_nll_fwd(const float* logp, const long long* target, long ignore_index, int D, long n, int channels_last,
+                  float* partial, float* out, void* stream);
+int nrgbd_nll_bwd(const long long* target, long ignore_index, const float* g_out, const float* stat, float* g_logp, int D,
+                  long n, int channels_last, void* stream);
+/*
  * nrgbd_bias_lrelu_cl_fwd / _bwd — y = leaky_relu(x + bias[c], slope) on channels-last rows [rows][C] and its backward
  * (training path of the R-Net).  Replaces: the bias add + nn.LeakyReLU of m_submodule.conv2d_leakyRelu /
  * conv2dTranspose_leakyRelu (models/m_submodule.py:18-27,36-45; slope = 1: the bias of Refine.py:71) and, in backward, ATen's

@@ -74,6 +74,11 @@ SIGNATURES = {
     "nrgbd_rnet_pack": (_I, [_P, _P, _I, _P, _I, _I, _L, _P]),
     "nrgbd_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P]),
     "nrgbd_logsoftmax_rows": (_I, [_P, _P, _L, _I, _P]),
+    "nrgbd_logsoftmax_d_bwd": (_I, [_P, _P, _F, _P, _I, _L, _P]),
+    "nrgbd_logsoftmax_rows_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
+    "nrgbd_nll_workgroups": (_I, [_L]),
+    "nrgbd_nll_fwd": (_I, [_P, _P, _L, _I, _L, _I, _P, _P, _P]),
+    "nrgbd_nll_bwd": (_I, [_P, _L, _P, _P, _P, _I, _L, _I, _P]),
     "nrgbd_bias_lrelu_cl_workgroups": (_I, [_L, _I]),
     "nrgbd_bias_lrelu_cl_fwd": (_I, [_P, _P, _F, _P, _L, _I, _P]),
     "nrgbd_bias_lrelu_cl_bwd": (_I, [_P, _P, _F, _P, _P, _P, _L, _I, _P]),

@@ -399,3 +399,78 @@ def conv_transpose2d_module(conv, x, _any_device=False, act_slope=None):
     if y is None:
         return _bias_act(conv(x), None, act_slope)
     return F.pixel_shuffle(y, 2)
+
+
+class LogSoftmaxD(torch.autograd.Function):
+    """log_softmax over the depth axis of scale * a (+ b), planar volumes [..., D, h, w] with leading dimensions of size 1
+    (models/basic.py:299-300: scale = -1; models/KVNET.py:172-173: a = K-Net gain, b = BV_predict), on softmax.hip in both directions."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        D = a.shape[-3]
+        if a.numel() != D * a.shape[-2] * a.shape[-1]:
+            raise ValueError("LogSoftmaxD: one volume per call, got %s" % (tuple(a.shape),))
+        out = ops.logsoftmax_d(a.reshape(a.shape[-3:]), None if b is None else b.reshape(a.shape[-3:]), float(scale))
+        ctx.save_for_backward(out)
+        ctx.scale, ctx.shape = float(scale), a.shape
+        return out.reshape(a.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = g.reshape(out.shape)
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = ops.logsoftmax_d_bwd(out, g, ctx.scale).reshape(ctx.shape)
+        if ctx.needs_input_grad[1]:
+            gb = ga if (ga is not None and ctx.scale == 1.0) else ops.logsoftmax_d_bwd(out, g, 1.0).reshape(ctx.shape)
+        return ga, gb, None
+
+
+class LogSoftmaxCL(torch.autograd.Function):
+    """F.log_softmax(x, dim=1) of an [N, C, H, W] tensor that lives in channels-last memory (the R-Net's last layer under autograd,
+    models/Refine.py:104): rows kernel in both directions, the result stays an NCHW view of channels-last memory."""
+
+    @staticmethod
+    def supported(x):
+        return x.dim() == 4 and x.shape[1] in (64, 128) and x.is_cuda and x.dtype == torch.float32
+
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.logsoftmax_rows(x.permute(0, 2, 3, 1).contiguous(), inplace=False)
+        ctx.save_for_backward(y)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return ops.logsoftmax_rows_bwd(y, g.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+
+
+class NLLLossD(torch.autograd.Function):
+    """F.nll_loss(logp [1, D, h, w], target [1, h, w], ignore_index) with mean reduction (train_utils/train_KVNet.py:103-120), in
+    logp's own layout (planar, or the channels-last memory the R-Net writes): one gather + fixed-order reduction forward, one
+    pass that writes the whole gradient backward."""
+
+    @staticmethod
+    def forward(ctx, logp, target, ignore_index):
+        cl = logp.permute(0, 2, 3, 1).is_contiguous() and not logp.is_contiguous()
+        vol = logp.permute(0, 2, 3, 1)[0] if cl else logp.contiguous()[0]
+        stat = ops.nll_fwd(vol, target, ignore_index, cl)
+        ctx.save_for_backward(target, stat)
+        ctx.args = (int(ignore_index), tuple(vol.shape), cl)
+        return stat[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        target, stat = ctx.saved_tensors
+        ignore_index, shape, cl = ctx.args
+        gl = ops.nll_bwd(target, ignore_index, g.to(torch.float32), stat, shape, cl).unsqueeze(0)
+        return (gl.permute(0, 3, 1, 2) if cl else gl), None, None
+
+
+def nll_loss_d(logp, target, ignore_index=0):
+    """F.nll_loss for one [1, D, h, w] log-probability volume on the hand-written kernels; anything else goes to ATen."""
+    if logp.dim() == 4 and logp.shape[0] == 1 and logp.is_cuda and logp.dtype == torch.float32 and target.dtype == torch.int64:
+        return NLLLossD.apply(logp, target, ignore_index)
+    return torch.nn.functional.nll_loss(logp, target, ignore_index=ignore_index)

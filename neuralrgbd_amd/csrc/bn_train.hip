@@ -206,14 +206,24 @@ __global__ __launch_bounds__(kBnclThreads) void bias_lrelu_bwd_kernel(const floa
     }
 }
 
-// g_bias[c] = sum over the workgroups' partials, in double, fixed order
+// g_bias[c] = sum over the workgroups' partials, in double, fixed order: a workgroup owns 16 channels, its 16 row slots walk
+// the partial list 16 apart and a fixed-order LDS pass adds the slots (one thread per channel walking all G <= 512 partials
+// was a 512-deep dependent chain of loads: 40 us per layer)
 __global__ __launch_bounds__(kBnclThreads) void bias_lrelu_finalize_kernel(const float* __restrict__ partial, int G, int C,
                                                                            float* __restrict__ g_bias) {
-    const int c = blockIdx.x * kBnclThreads + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sh[kBnclThreads];
+    const int tid = threadIdx.x, cc = tid & 15, slot = tid >> 4;
+    const int c = blockIdx.x * 16 + cc;
     double s = 0.0;
-    for (int g = 0; g < G; ++g) s += (double)partial[(size_t)g * C + c];
-    g_bias[c] = (float)s;
+    if (c < C)
+        for (int g = slot; g < G; g += kBnclThreads / 16) s += (double)partial[(size_t)g * C + c];
+    sh[tid] = s;
+    __syncthreads();
+    if (tid < 16 && c < C) {
+        double t = sh[tid];
+        for (int k = 1; k < kBnclThreads / 16; ++k) t += sh[k * 16 + tid];
+        g_bias[c] = (float)t;
+    }
 }
 
 static int bias_lrelu_groups(long rows, int C) {
@@ -299,7 +309,7 @@ extern "C" int nrgbd_bias_lrelu_cl_bwd(const float* y, const float* gy, float sl
     const int G = bias_lrelu_groups(rows, C);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bias_lrelu_bwd_kernel, dim3(G), dim3(kBnclThreads), 0, s, y, gy, slope, gx, partial, rows, C);
-    hipLaunchKernelGGL(bias_lrelu_finalize_kernel, dim3((C + kBnclThreads - 1) / kBnclThreads), dim3(kBnclThreads), 0, s, partial, G, C, g_bias);
+    hipLaunchKernelGGL(bias_lrelu_finalize_kernel, dim3((C + 15) / 16), dim3(kBnclThreads), 0, s, partial, G, C, g_bias);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -77,12 +77,12 @@ class DNet(nn.Module):
         rgb = frames if self.use_img_intensity else None
         if torch.is_grad_enabled() and feats.requires_grad:
             # training: same kernels behind autograd.Function (backward = csrc/costvol_bwd.hip)
-            from .autograd import PackNHWC, PlaneSweepCost
+            from .autograd import LogSoftmaxD, PackNHWC, PlaneSweepCost
             texels = PackNHWC.apply(feats, rgb)
             cost = PlaneSweepCost.apply(texels, KR, Kt, rays, d_dev, cx, cy, self.sigma_soft_max, C,
                                         self.feat_dist, self.align_corners)
             self.texels = texels.detach()
-            BV = (torch.log_softmax(-cost, dim=0) if self.BV_log else torch.softmax(-cost, dim=0)).unsqueeze(0)
+            BV = (LogSoftmaxD.apply(cost, None, -1.0) if self.BV_log else torch.softmax(-cost, dim=0)).unsqueeze(0)
         else:
             texels = ops.pack_nhwc(feats, rgb, channels_last=feats_cl)
             self.texels = texels
@@ -213,7 +213,11 @@ class KVNET(nn.Module):
                 gain = self.kv_net.forward_channels_last_autograd(volume.permute(1, 2, 3, 0).contiguous()).unsqueeze(0)
             else:
                 gain = torch.squeeze(self.kv_net(volume.unsqueeze(0)), dim=1)   # torch modules
-            DPV = torch.log_softmax(gain + BV_predict, dim=1)
+            if gain.is_cuda and gain.dtype == torch.float32:
+                from .autograd import LogSoftmaxD
+                DPV = LogSoftmaxD.apply(gain, BV_predict, 1.0)                  # UPDATE, softmax.hip in both directions
+            else:
+                DPV = torch.log_softmax(gain + BV_predict, dim=1)
 
         if batch_refine:
             both = self.r_net.forward_log(torch.cat((BV_cur, DPV), dim=0), features)     # [2,D,H,W]

@@ -887,7 +887,7 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 and (dpv_raw.shape[2] * dpv_raw.shape[3]) % 4 == 0:
             return self._forward_fused_tail(dpv_raw, img_features)
         quarter, half, full = img_features
-        from .autograd import conv2d_module, conv_transpose2d_module
+        from .autograd import LogSoftmaxCL, conv2d_module, conv_transpose2d_module
 
         def cl(m, x):   # conv2d_leakyRelu block: convolution + fused bias / LeakyReLU(0.01) on the hand-written kernels
             return conv2d_module(m[0], x, act_slope=0.01)
@@ -902,4 +902,6 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         # conv2_1 as it is — no channel slice, no re-padding at full resolution
         x = conv2d_module(self.conv2[0], torch.cat([x, full], dim=1), keep_width=True, act_slope=0.01)
         x = conv2d_module(self.conv2_2, cl(self.conv2_1, x))
+        if LogSoftmaxCL.supported(x) and x.permute(0, 2, 3, 1).is_contiguous():
+            return LogSoftmaxCL.apply(x)           # channels-last rows kernel; the result stays an NCHW view of that memory
         return F.log_softmax(x, dim=1)

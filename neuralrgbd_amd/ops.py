@@ -748,6 +748,70 @@ def logsoftmax_rows(x, inplace=True):
     return y
 
 
+def logsoftmax_d_bwd(logp, g, scale=1.0):
+    """Backward of logsoftmax_d: scale * (g - exp(logp) * sum_k g) on planar [D, ...] volumes (nrgbd_logsoftmax_d_bwd)."""
+    logp = _need(logp, "logp")
+    g = _need(g, "g", logp.shape)
+    D = logp.shape[0]
+    gz = torch.empty_like(logp)
+    with torch.cuda.device(logp.device):
+        rc = _lib.load().nrgbd_logsoftmax_d_bwd(_p(logp), _p(g), float(scale), _p(gz), D, logp.numel() // D, _stream(logp))
+    _lib.check(rc, "nrgbd_logsoftmax_d_bwd")
+    return gz
+
+
+def logsoftmax_rows_bwd(y, g):
+    """Backward of logsoftmax_rows on contiguous channels-last tensors [..., C], C in {64, 128} (nrgbd_logsoftmax_rows_bwd)."""
+    y = _need(y, "y")
+    g = _need(g, "g", y.shape)
+    C = y.shape[-1]
+    gx = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        rc = _lib.load().nrgbd_logsoftmax_rows_bwd(_p(y), _p(g), _p(gx), y.numel() // C, int(C), _stream(y))
+    _lib.check(rc, "nrgbd_logsoftmax_rows_bwd")
+    return gx
+
+
+def _nll_target(target, n):
+    if not (isinstance(target, torch.Tensor) and target.is_cuda and target.dtype == torch.int64):
+        raise TypeError("target must be an int64 tensor on the GPU")
+    if target.numel() != n:
+        raise ValueError("target has %d elements, the volume %d pixels" % (target.numel(), n))
+    return target if target.is_contiguous() else target.contiguous()
+
+
+def nll_fwd(logp, target, ignore_index, channels_last):
+    """Mean NLL of a [D, n] (planar) or [n, D] (channels_last) log-probability volume -> stat [2] = (loss, counted pixels)
+    (nrgbd_nll_fwd; a device tensor: no host synchronisation)."""
+    logp = _need(logp, "logp")
+    D = logp.shape[-1] if channels_last else logp.shape[0]
+    n = logp.numel() // D
+    target = _nll_target(target, n)
+    lib = _lib.load()
+    partial = torch.empty((lib.nrgbd_nll_workgroups(n), 2), dtype=torch.float32, device=logp.device)
+    stat = torch.empty(2, dtype=torch.float32, device=logp.device)
+    with torch.cuda.device(logp.device):
+        rc = lib.nrgbd_nll_fwd(_p(logp), ctypes.c_void_p(target.data_ptr()), int(ignore_index), int(D), n, int(bool(channels_last)),
+                               _p(partial), _p(stat), _stream(logp))
+    _lib.check(rc, "nrgbd_nll_fwd")
+    return stat
+
+
+def nll_bwd(target, ignore_index, g_out, stat, shape, channels_last):
+    """Gradient of nll_fwd w.r.t. logp, in logp's layout `shape` ([D, ...] or [..., D]) (nrgbd_nll_bwd)."""
+    g_out = _need(g_out, "g_out").reshape(1)
+    stat = _need(stat, "stat", (2,))
+    D = shape[-1] if channels_last else shape[0]
+    g = torch.empty(tuple(shape), dtype=torch.float32, device=stat.device)
+    n = g.numel() // D
+    target = _nll_target(target, n)
+    with torch.cuda.device(stat.device):
+        rc = _lib.load().nrgbd_nll_bwd(ctypes.c_void_p(target.data_ptr()), int(ignore_index), _p(g_out), _p(stat), _p(g), int(D), n,
+                                       int(bool(channels_last)), _stream(stat))
+    _lib.check(rc, "nrgbd_nll_bwd")
+    return g
+
+
 def bias_lrelu_cl_fwd(x, bias, slope):
     """y = leaky_relu(x + bias, slope) on channels-last rows x [rows, C] (nrgbd_bias_lrelu_cl_fwd)."""
     x = _need(x, "x")

@@ -16,17 +16,18 @@ import torch.nn.functional as F
 
 from . import homography as warp_homo
 from . import ops
+from .autograd import nll_loss_d
 from .misc import depth_val_regression, valid_dpv
 
 
 def _nll_terms(d_dpv, dmap_cur_refined, kv_dpv, dmap_refined, depth_ref, depth_ref_imgsize, valid):
     """train_KVNet.py:103-120: NLL on the 1/4-res DPV and on its R-Net refinement, for the measurement and (update branch)
     for the filtered volume."""
-    loss = F.nll_loss(d_dpv, depth_ref, ignore_index=0)
-    loss = loss + F.nll_loss(dmap_cur_refined, depth_ref_imgsize, ignore_index=0)
+    loss = nll_loss_d(d_dpv, depth_ref, ignore_index=0)
+    loss = loss + nll_loss_d(dmap_cur_refined, depth_ref_imgsize, ignore_index=0)
     if valid:
-        loss = loss + F.nll_loss(kv_dpv, depth_ref, ignore_index=0)
-        loss = loss + F.nll_loss(dmap_refined, depth_ref_imgsize, ignore_index=0)
+        loss = loss + nll_loss_d(kv_dpv, depth_ref, ignore_index=0)
+        loss = loss + nll_loss_d(dmap_refined, depth_ref_imgsize, ignore_index=0)
     return loss
 
 

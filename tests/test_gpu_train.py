@@ -564,3 +564,54 @@ def test_split_train_graph_with_accumulation_equals_eager_accumulation():
     assert (wa - wb).abs().max().item() < 5e-4
     st = opt2.state[next(iter(twin.kv_net.parameters()))]
     assert float(st["step"]) == 3.0
+
+
+def test_logsoftmax_and_nll_training_kernels_vs_torch_fp64():
+    """softmax.hip's training entries against torch in float64: log-softmax backward (planar with scale / second operand, and
+    channels-last rows), NLL forward / backward in both layouts with ignored pixels (train_KVNet.py:103-120)."""
+    from neuralrgbd_amd.autograd import LogSoftmaxCL, LogSoftmaxD, nll_loss_d
+    g = torch.Generator().manual_seed(11)
+    for D, h, w in ((64, 24, 40), (128, 9, 13), (32, 7, 5)):
+        a = torch.randn(1, D, h, w, generator=g).to(DEV).requires_grad_(True)
+        b = torch.randn(1, D, h, w, generator=g).to(DEV).requires_grad_(True)
+        gout = torch.randn(1, D, h, w, generator=g).to(DEV)
+        for scale, use_b in ((-1.0, False), (1.0, True), (0.5, True)):
+            a.grad = b.grad = None
+            out = LogSoftmaxD.apply(a, b if use_b else None, scale)
+            out.backward(gout)
+            a64, b64 = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+            ref = torch.log_softmax(scale * a64 + (b64 if use_b else 0.0), dim=1)
+            ref.backward(gout.double())
+            assert (out.double() - ref).abs().max().item() < 5e-6
+            assert (a.grad.double() - a64.grad).abs().max().item() < 1e-5
+            if use_b:
+                assert (b.grad.double() - b64.grad).abs().max().item() < 1e-5
+        # NLL on the planar volume, ~30 % of the pixels ignored (index 0)
+        tgt = torch.randint(0, D, (1, h, w), generator=g)
+        tgt[torch.rand(1, h, w, generator=g) < 0.3] = 0
+        tgt = tgt.to(DEV)
+        lp = torch.log_softmax(torch.randn(1, D, h, w, generator=g), dim=1).to(DEV).requires_grad_(True)
+        loss = nll_loss_d(lp, tgt, ignore_index=0)
+        (3.0 * loss).backward()
+        lp64 = lp.detach().double().requires_grad_(True)
+        ref = F.nll_loss(lp64, tgt, ignore_index=0)
+        (3.0 * ref).backward()
+        assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+        assert (lp.grad.double() - lp64.grad).abs().max().item() < 1e-7
+        if D in (64, 128):   # channels-last: the R-Net's layout
+            x = torch.randn(1, h, w, D, generator=g).to(DEV).permute(0, 3, 1, 2).requires_grad_(True)
+            assert LogSoftmaxCL.supported(x)
+            y = LogSoftmaxCL.apply(x)
+            assert y.permute(0, 2, 3, 1).is_contiguous()
+            l2 = nll_loss_d(y, tgt, ignore_index=0) + (y * gout).sum()
+            l2.backward()
+            x64 = x.detach().double().requires_grad_(True)
+            y64 = torch.log_softmax(x64, dim=1)
+            r2 = F.nll_loss(y64, tgt, ignore_index=0) + (y64 * gout.double()).sum()
+            r2.backward()
+            assert (y.double() - y64).abs().max().item() < 5e-6
+            assert abs(l2.item() - r2.item()) < 1e-4 * max(1.0, abs(r2.item()))
+            assert (x.grad.double() - x64.grad).abs().max().item() < 2e-5
+    # every pixel ignored: NaN like ATen
+    tz = torch.zeros(1, 7, 5, dtype=torch.long, device=DEV)
+    assert torch.isnan(nll_loss_d(torch.zeros(1, 32, 7, 5, device=DEV), tz, ignore_index=0))
