@@ -426,6 +426,7 @@ def train_main(args):
     ranks = verified_ranks(world, dev)
     import neuralrgbd_amd
     from neuralrgbd_amd import camera, distributed as nd, ops, synth
+    from neuralrgbd_amd.optim import FusedAdam
     from neuralrgbd_amd.train_step import TrainGraph, train
     H, W, D, A = 256, 384, 64, max(1, args.accum)
     cam = camera.scannet_intrinsics(W // 4, H // 4)
@@ -434,7 +435,7 @@ def train_main(args):
     model.load_state_dict(synth.seeded_state_dict(model, 0))
     model = model.to(dev)
     use_graph = not args.no_graph
-    opt = torch.optim.Adam(model.parameters(), lr=1e-5, betas=(.9, .999), capturable=use_graph)      # local_train_scanNet.sh
+    opt = FusedAdam(model.parameters(), lr=1e-5, betas=(.9, .999))      # local_train_scanNet.sh's optim.Adam on csrc/optim.hip
     reducer = nd.GradAllReduce(model) if world > 1 else None
     tg = TrainGraph(model, opt, 2, d_candi, cam, warmup=0, grad_reducer=reducer, accum_steps=A) if use_graph else None
     rng = np.random.RandomState(rank)

@@ -528,6 +528,19 @@ int nrgbd_nll_fwd(const float* logp, const long long* target, long ignore_index,
 int nrgbd_nll_bwd(const long long* target, long ignore_index, const float* g_out, const float* stat, float* g_logp, int D,
                   long n, int channels_last, void* stream);
 /*
+ * nrgbd_adam_step — torch.optim.Adam's update (no amsgrad) of a LIST of fp32 tensors, 48 tensors per launch with their pointers passed
+ * by value (nothing is uploaded: the launches can be captured into a hipGraph).  Replaces: optimizer_KV.step() of
+ * train_utils/train_KVNet.py:153 for the optim.Adam of train_KVNet.py:228-232 (ATen: ~50 _foreach_ launches per step).
+ *   params / grads / exp_avg / exp_avg_sq / steps: HOST arrays of `ntensors` DEVICE pointers; numel: host array of element counts.
+ *   steps[i] points to tensor i's step counter (a device float: completed steps), read as t = *steps[i] + 1 and then incremented.
+ *   Arithmetic = torch.optim.adam._single_tensor_adam, fp32, scalar factors formed in double:
+ *     g' = (maximize ? -g : g) + weight_decay * p;  m += (g' - m)(1 - beta1);  v = v beta2 + (1 - beta2) g'^2;
+ *     p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ */
+int nrgbd_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    float* const* steps, const long* numel, int ntensors, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int maximize, void* stream);
+/*
  * nrgbd_bias_lrelu_cl_fwd / _bwd — y = leaky_relu(x + bias[c], slope) on channels-last rows [rows][C] and its backward
  * (training path of the R-Net).  Replaces: the bias add + nn.LeakyReLU of m_submodule.conv2d_leakyRelu /
  * conv2dTranspose_leakyRelu (models/m_submodule.py:18-27,36-45; slope = 1: the bias of Refine.py:71) and, in backward, ATen's

@@ -14,6 +14,7 @@ _P = _c.c_void_p
 _F = _c.c_float
 _I = _c.c_int
 _L = _c.c_long
+_D = _c.c_double
 _Z = _c.c_size_t
 
 # name -> (restype, argtypes); one entry per function of include/nrgbd.h
@@ -79,6 +80,7 @@ SIGNATURES = {
     "nrgbd_nll_workgroups": (_I, [_L]),
     "nrgbd_nll_fwd": (_I, [_P, _P, _L, _I, _L, _I, _P, _P, _P]),
     "nrgbd_nll_bwd": (_I, [_P, _L, _P, _P, _P, _I, _L, _I, _P]),
+    "nrgbd_adam_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _D, _D, _D, _D, _D, _I, _P]),
     "nrgbd_bias_lrelu_cl_workgroups": (_I, [_L, _I]),
     "nrgbd_bias_lrelu_cl_fwd": (_I, [_P, _P, _F, _P, _L, _I, _P]),
     "nrgbd_bias_lrelu_cl_bwd": (_I, [_P, _P, _F, _P, _P, _P, _L, _I, _P]),

@@ -114,7 +114,8 @@ class TrainGraph:
         (RCCL; eager, between the graphs — replays run no autograd hooks, so every bucket is launched by `reducer()` in index
         order; 21 MB over xGMI is ~0.3 ms of a ~150 ms step, there is nothing worth overlapping) and the division by
         A x world; graph 2 = the optimizer step.  `step_windows()` drives this form.
-    The optimizer must be built with `capturable=True`.  Inputs are copied into static buffers; the pose inverse for PREDICT
+    The optimizer is neuralrgbd_amd.optim.FusedAdam (one multi-tensor kernel, capturable as it is) or a torch optimizer built
+    with `capturable=True`.  Inputs are copied into static buffers; the pose inverse for PREDICT
     is computed outside the graph.  Outputs are static tensors that the next replay overwrites.
 
     Capture needs state that only an executed iteration creates: Adam's exp_avg / exp_avg_sq / step (created inside a
@@ -142,6 +143,8 @@ class TrainGraph:
     def _optimizer_ready(self):
         """Every trainable parameter has populated optimizer state (else capture would record its creation)."""
         names = {p: n for n, p in self.model.named_parameters()}
+        if hasattr(self.opt, "init_state"):     # neuralrgbd_amd.optim.FusedAdam: the state can simply be created now
+            self.opt.init_state()
         for group in self.opt.param_groups:
             for p in group["params"]:
                 if p.requires_grad and not self.opt.state.get(p):

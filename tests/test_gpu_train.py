@@ -615,3 +615,52 @@ def test_logsoftmax_and_nll_training_kernels_vs_torch_fp64():
     # every pixel ignored: NaN like ATen
     tz = torch.zeros(1, 7, 5, dtype=torch.long, device=DEV)
     assert torch.isnan(nll_loss_d(torch.zeros(1, 32, 7, 5, device=DEV), tz, ignore_index=0))
+
+
+def test_fused_adam_vs_torch_adam_and_under_a_hipgraph():
+    """optim.FusedAdam (csrc/optim.hip) against torch.optim.Adam over six steps: tensors from 1 to 300k elements (more than one
+    48-tensor slab), a parameter group with weight decay, parameters without a gradient in some steps (their step count must
+    lag, as in torch), then the same update captured into a hipGraph and replayed."""
+    from neuralrgbd_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1,), (7,), (64,), (64, 64, 3, 3), (300000,), (2049,), (2048,), (33, 5)] + [(17 + i,) for i in range(60)]
+    pa = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    half = len(shapes) // 2
+    groups = lambda ps: [{"params": ps[:half]}, {"params": ps[half:], "weight_decay": 0.01, "lr": 3e-3}]
+    oa = FusedAdam(groups(pa), lr=1e-3, betas=(.9, .999), eps=1e-8)
+    ob = torch.optim.Adam(groups(pb), lr=1e-3, betas=(.9, .999), eps=1e-8)
+    for it in range(6):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if (i + it) % 5 == 0:                 # no gradient this step
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(*a.shape, generator=g).to(DEV) * (10.0 ** ((i % 7) - 3))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), (i, shapes[i])
+        assert int(oa.state[a]["step"].item()) == int(ob.state[b]["step"].item())
+        assert (oa.state[a]["exp_avg_sq"] - ob.state[b]["exp_avg_sq"]).abs().max().item() <= 1e-6 * max(1e-30, ob.state[b]["exp_avg_sq"].abs().max().item())
+    # state names interchange with torch.optim.Adam
+    assert set(oa.state[pa[3]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    ob2 = torch.optim.Adam(groups(pb), lr=1e-3)
+    ob2.load_state_dict(oa.state_dict())
+    # captured: static gradients, two replays = two more steps
+    for a, b in zip(pa, pb):
+        gr = torch.randn(*a.shape, generator=g).to(DEV)
+        a.grad, b.grad = gr.clone(), gr.clone()
+    oa.step(); ob.step()                          # pointer tables for these gradient tensors exist now
+    s_ = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s_):
+        with torch.cuda.graph(graph, stream=s_):
+            oa.step()
+    graph.replay()                                # the capture itself executes nothing
+    graph.replay()
+    ob.step(); ob.step()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert (a - b).abs().max().item() <= 4e-6 * max(1.0, b.abs().max().item()), (i, shapes[i])
+        assert int(oa.state[a]["step"].item()) == int(ob.state[b]["step"].item())
