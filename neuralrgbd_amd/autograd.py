@@ -360,7 +360,7 @@ def conv2d_module(conv, x, _any_device=False, keep_width=False, act_slope=None):
     k, st, pd, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
     if not ((x.is_cuda or _any_device) and x.dtype == torch.float32 and conv.groups == 1 and k[0] == k[1] and st[0] == st[1] and d[0] == d[1]
             and pd[0] == pd[1] and conv.padding_mode == "zeros"):
-        return _bias_act(conv(x), None, act_slope)
+        return _bias_act(conv(x[:, :conv.in_channels] if x.shape[1] != conv.in_channels else x), None, act_slope)
     w, y = conv.weight, None
     if k == (3, 3) and st == (1, 1) and pd == d:
         y = _conv3x3_cl(x, w, d[0], conv.bias, keep_width, act_slope)
@@ -391,14 +391,37 @@ def conv_transpose2d_module(conv, x, _any_device=False, act_slope=None):
     cin, cout = w.shape[:2]
     idx, msk = _tap_select("t2", w.device)
     w4 = (w.permute(1, 0, 2, 3).reshape(cout, cin, 16).index_select(2, idx) * msk)       # [Cout, Cin, (a, b, r, c)]
-    w4 = w4.reshape(cout, cin, 4, 9).permute(0, 2, 1, 3).reshape(cout * 4, cin, 3, 3)   # rows co * 4 + (a * 2 + b)
-    # bias + LeakyReLU commute with the interleave: applied to the four phases at once (bias of output channel co on its rows
-    # co * 4 .. co * 4 + 3) BEFORE pixel_shuffle, on the channels-last tensor the convolution wrote
-    b4 = None if conv.bias is None else conv.bias.repeat_interleave(4)
+    w4 = w4.reshape(cout, cin, 4, 9).permute(2, 0, 1, 3).reshape(4 * cout, cin, 3, 3)   # rows (a * 2 + b) * Cout + co: phase-major
+    # bias + LeakyReLU commute with the interleave: applied to the four phases at once BEFORE it, on the channels-last tensor
+    # the convolution wrote
+    b4 = None if conv.bias is None else conv.bias.repeat(4)
     y = _conv3x3_cl(x, w4, 1, b4, False, act_slope)
     if y is None:
         return _bias_act(conv(x), None, act_slope)
-    return F.pixel_shuffle(y, 2)
+    # sub-pixel interleave on the channels-last tensor: pixel (Y, X) holds its four output pixels as four runs of Cout channels,
+    # so ONE copy of 4 Cout-float runs builds the channels-last result (F.pixel_shuffle would gather single floats into a planar
+    # tensor that the next layer converts back)
+    N, _, H, W = y.shape
+    out = y.permute(0, 2, 3, 1).reshape(N, H, W, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * H, 2 * W, cout)
+    return out.permute(0, 3, 1, 2)
+
+
+def padded_in_width(conv, need_dgrad=True):
+    """Input width Conv2dCL runs a 3x3 stride-1 module at (its channel count zero-padded to a width the kernels have)."""
+    pw = _padded_widths(conv.in_channels, conv.out_channels, conv.dilation[0], need_dgrad)
+    return conv.in_channels if pw is None else pw[0]
+
+
+def cat_cl(tensors, width=None):
+    """torch.cat(tensors, dim=1) built in channels-last memory, optionally zero-padded to `width` channels: every operand is
+    copied once, straight to its channel range of the [N, H, W, C] result (a planar cat of mixed layouts followed by F.pad and the
+    convolution's own layout change were three full-resolution copies in front of the R-Net's 67-channel layer).  Returns the
+    NCHW view."""
+    parts = [t.permute(0, 2, 3, 1) for t in tensors]
+    have = sum(t.shape[3] for t in parts)
+    if width is not None and width > have and parts[0].is_cuda and parts[0].dtype == torch.float32:   # the padding serves Conv2dCL only
+        parts.append(parts[0].new_zeros(parts[0].shape[:3] + (width - have,)))
+    return torch.cat(parts, dim=3).permute(0, 3, 1, 2)
 
 
 class LogSoftmaxD(torch.autograd.Function):

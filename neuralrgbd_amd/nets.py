@@ -887,20 +887,20 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 and (dpv_raw.shape[2] * dpv_raw.shape[3]) % 4 == 0:
             return self._forward_fused_tail(dpv_raw, img_features)
         quarter, half, full = img_features
-        from .autograd import LogSoftmaxCL, conv2d_module, conv_transpose2d_module
+        from .autograd import LogSoftmaxCL, cat_cl, conv2d_module, conv_transpose2d_module, padded_in_width
 
         def cl(m, x):   # conv2d_leakyRelu block: convolution + fused bias / LeakyReLU(0.01) on the hand-written kernels
             return conv2d_module(m[0], x, act_slope=0.01)
 
         def tl(m, x):   # conv2dTranspose_leakyRelu block (four sub-pixel phases as one 3x3 launch per direction)
             return conv_transpose2d_module(m[0], x, act_slope=0.01)
-        x = cl(self.conv0_1, cl(self.conv0, torch.cat([dpv_raw, quarter], dim=1)))
+        x = cl(self.conv0_1, cl(self.conv0, cat_cl([dpv_raw, quarter], padded_in_width(self.conv0[0]))))
         x = tl(self.trans_conv0, x)
-        x = cl(self.conv1_1, cl(self.conv1, torch.cat([x, half], dim=1)))
+        x = cl(self.conv1_1, cl(self.conv1, cat_cl([x, half], padded_in_width(self.conv1[0]))))
         x = tl(self.trans_conv1, x)
         # conv2 (67 -> 67) runs 96 wide; its padded output (29 exact zeros: zero weights, zero bias, LeakyReLU(0) = 0) feeds
         # conv2_1 as it is — no channel slice, no re-padding at full resolution
-        x = conv2d_module(self.conv2[0], torch.cat([x, full], dim=1), keep_width=True, act_slope=0.01)
+        x = conv2d_module(self.conv2[0], cat_cl([x, full], padded_in_width(self.conv2[0])), keep_width=True, act_slope=0.01)
         x = conv2d_module(self.conv2_2, cl(self.conv2_1, x))
         if LogSoftmaxCL.supported(x) and x.permute(0, 2, 3, 1).is_contiguous():
             return LogSoftmaxCL.apply(x)           # channels-last rows kernel; the result stays an NCHW view of that memory
