@@ -372,6 +372,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         long t_pub = 0, t_tr = 0, t_pbar = 0, t_q0 = 0, t_q1 = 0, t_q2 = 0;
 #endif
         bool has_next = false;
+        bool interior = false;   // the current tile's whole halo lies inside the image (set per tile below)
         // one stage: publish set r (stage s of the current tile), refill it for stage s+2, transform, barrier
         auto stage = [&](int s, Regs& r) __attribute__((always_inline)) {
 #ifdef NRGBD_DEV
@@ -404,8 +405,9 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                         // its predecessor's result loses the issue port to the next MFMA (32 cycles), an independent one
                         // issues back to back.
                         // (with a residual operand: in two groups of items, which keeps the phase inside the register budget)
-                        auto group = [&](auto u0_tag, auto u1_tag) __attribute__((always_inline)) {
+                        auto group = [&](auto u0_tag, auto u1_tag, auto interior_tag) __attribute__((always_inline)) {
                             constexpr int U0 = decltype(u0_tag)::value, U1 = decltype(u1_tag)::value, NU = U1 - U0;
+                            constexpr bool INTERIOR = decltype(interior_tag)::value;   // every item of every lane inside the image: no padding mask
                             f32x2 lo[NU], hi[NU];
 #pragma unroll
                             for (int i = 0; i < NU; ++i) {
@@ -437,12 +439,14 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                             }
                             // zero padding applies to the ACTIVATED tensor: out-of-image lanes (their loads read a harmless
                             // in-tensor word) are multiplied by 0
+                            if constexpr (!INTERIOR) {
 #pragma unroll
-                            for (int i = 0; i < NU; ++i) {
-                                const f32x2 kk = {cur_keep[U0 + i], cur_keep[U0 + i]};
-                                lo[i] = lo[i] * kk; hi[i] = hi[i] * kk;
+                                for (int i = 0; i < NU; ++i) {
+                                    const f32x2 kk = {cur_keep[U0 + i], cur_keep[U0 + i]};
+                                    lo[i] = lo[i] * kk; hi[i] = hi[i] * kk;
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
                             }
-                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int i = 0; i < NU; ++i) {
                                 const int u = U0 + i;
@@ -455,11 +459,20 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                                 *reinterpret_cast<f32x4*>(raw + wr_off[u]) = v;
                             }
                         };
-                        if constexpr (RES) {
-                            group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-                            group(std::integral_constant<int, 3>{}, std::integral_constant<int, kPcNPF>{});
+                        // a tile whose halo lies inside the image needs no zero-padding mask (its pad pixels of the strip — the
+                        // fifth item of lanes 32..63 — are never read by the transform)
+                        if (interior) {
+                            if constexpr (RES) {
+                                group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, std::true_type{});
+                                group(std::integral_constant<int, 3>{}, std::integral_constant<int, kPcNPF>{}, std::true_type{});
+                            } else {
+                                group(std::integral_constant<int, 0>{}, std::integral_constant<int, kPcNPF>{}, std::true_type{});
+                            }
+                        } else if constexpr (RES) {
+                            group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, std::false_type{});
+                            group(std::integral_constant<int, 3>{}, std::integral_constant<int, kPcNPF>{}, std::false_type{});
                         } else {
-                            group(std::integral_constant<int, 0>{}, std::integral_constant<int, kPcNPF>{});
+                            group(std::integral_constant<int, 0>{}, std::integral_constant<int, kPcNPF>{}, std::false_type{});
                         }
                     }
                 }
@@ -515,6 +528,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         };
         for (int it = 0; it < count; ++it) {
             has_next = it + 1 < count;
+            interior = tl.y0 + tl.py - DIL >= 0 && tl.y0 + tl.py + DIL * kPcTH < a.H && tl.x0 + tl.px - DIL >= 0 && tl.x0 + tl.px + DIL * kPcTW < a.W;
             if constexpr (!ODD) {   // stages in pairs: the register set of a stage is static
                 for (int s = 0; s < NS; s += 2) {
                     // the book of the next tile is needed from the first refill that reaches into it (stage NS-2 refills stage 0)
