@@ -237,6 +237,10 @@ class Conv2dCL(torch.autograd.Function):
         cout, cin = (w.shape[1], w.shape[0]) if transposed else w.shape[:2]
         if cin % 32 == 0 and cout % 64 == 0:
             return ops.conv_wino(x_cl, ops.conv_wino_pack(w, transposed) if packed is None else packed, cout, 1, dil, want_stats=False)[0]
+        if cout == 32 and cin % 32 == 0 and dil == 1 and ops.conv_wino_supported(x_cl.shape[0], x_cl.shape[1], x_cl.shape[2], cin, 32, 1):
+            # the HALF form of wino_pc.hip (the trunk's 32 -> 32 layers): its stream is the 64-column one, upper half zero
+            wp = ops.conv_wino_pack(torch.cat((w, torch.zeros_like(w)), 1 if transposed else 0), transposed)
+            return ops.conv_wino(x_cl, wp, 32, 1, 1, want_stats=False)[0]
         if transposed:
             w = w.transpose(0, 1).flip(2, 3)                          # [Cin, Cout, 3, 3]: correlation with the flipped kernel
         return ops.conv2d(x_cl, ops.conv_pack_weights(w.contiguous()), cout, dil, want_stats=False)[0]

@@ -39,7 +39,13 @@ namespace nrgbd {
 // WITHOUT them (round 3, learnt on wino_dw.hip): once loads and stores of one wave can both be pending the
 // compiler turns every s_waitcnt on a prefetched register into vmcnt(0), which also waits for the refill issued a moment
 // earlier.  For the same reason the refills are unconditional and the (scale, shift) pairs come from an LDS copy.
-template <int KD, int DIL, bool RES, bool ODD = false, int EPI = 0, bool MAT = false>
+// HALF: Cout = 32 (the feature CNN's half-resolution layers, psm_submodule.py:90-99,103: firstconv.1/.2 and layer1).  The four
+// consumer waves split the tile as (row block m = wave >> 1: 16 of the 32 Winograd tiles) x (16-column group = wave & 1): 64
+// accumulators and 64 MFMAs per stage and wave, transform points taken in PAIRS so that MFMAs on one accumulator still
+// alternate with another's; the weight stream is the 64-column one with the upper 32 columns zero (waves 0 / 1 read their two
+// lines of it); statistics rows are (tile, row block).  The producers are unchanged — they now set the pace (a stage's MFMAs
+// take 0.85 us): 2.25x fewer multiplies than conv2d.hip's direct form of these layers.
+template <int KD, int DIL, bool RES, bool ODD = false, int EPI = 0, bool MAT = false, bool HALF = false>
 __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Vb = lds;                           // [3][16 xi][32 tiles][16]
@@ -85,24 +91,36 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     if (wave >= 4) {
         // =========================================== consumer: 16 output channels x 16 xi x 32 tiles ====================
         const int kq = lane >> 4, jj = lane & 15;
-        f32x4 acc[16][2];                      // written by the first stage of every tile (C operand = 0): never cleared
-        const int a0 = pc_slot(0, jj, kq), a1 = pc_slot(0, 16 + jj, kq);   // + xi * 512 floats + buffer
-        const f32x4* wbase = reinterpret_cast<const f32x4*>(a.wp) + wv * 64 + lane;
+        constexpr int NM = HALF ? 1 : 2;       // row blocks (16 Winograd tiles each) of this wave
+        const int msel = HALF ? (wv >> 1) : 0; // HALF: the one row block this wave owns
+        const int cwv = HALF ? (wv & 1) : wv;  // the wave's 16-column group
+        f32x4 acc[16][NM];                     // written by the first stage of every tile (C operand = 0): never cleared
+        const int a0 = pc_slot(0, 16 * msel + jj, kq), a1 = pc_slot(0, 16 + jj, kq);   // + xi * 512 floats + buffer
+        const f32x4* wbase = reinterpret_cast<const f32x4*>(a.wp) + cwv * 64 + lane;
         const unsigned ldy = (EPI == 1 && a.ldy) ? (unsigned)a.ldy : (unsigned)a.Cout;   // pixel stride of the output
         const unsigned lane_yoff = (unsigned)jj + (unsigned)((DIL * 2 * (kq >> 1)) * a.W + 8 * (kq & 1) * DIL) * ldy;
         const size_t wgroup = (size_t)NS * 16 * 256;                        // f32x4 per 64-column output group
 
         PcTile tl = pc_decode<KD, DIL>(first, a);
         const f32x4* wt = wbase + (size_t)tl.cg * wgroup;
+        constexpr int BD = HALF ? 6 : kPcBD;   // weight lines in flight (HALF requests two per pair of points: an even distance)
         f32x4 Bn[kPcNB], An[4][2];             // A operands run TWO transform points ahead (one point = 256 MFMA cycles < a loaded LDS's latency)
+                                               // HALF: An[pair & 3][point of the pair], two PAIRS ahead
 #pragma unroll
-        for (int b = 0; b < kPcBD; ++b) Bn[b] = wt[b * 256];
+        for (int b = 0; b < BD; ++b) Bn[b] = wt[b * 256];
         __syncthreads();                       // producers finish stage 0
         __syncthreads();                       // ... and stage 1
-        An[0][0] = *reinterpret_cast<const f32x4*>(Vb + a0);
-        An[0][1] = *reinterpret_cast<const f32x4*>(Vb + a1);
-        An[1][0] = *reinterpret_cast<const f32x4*>(Vb + a0 + kPcTiles * kCB);
-        An[1][1] = *reinterpret_cast<const f32x4*>(Vb + a1 + kPcTiles * kCB);
+        if constexpr (HALF) {
+            An[0][0] = *reinterpret_cast<const f32x4*>(Vb + a0);
+            An[0][1] = *reinterpret_cast<const f32x4*>(Vb + a0 + kPcTiles * kCB);
+            An[1][0] = *reinterpret_cast<const f32x4*>(Vb + a0 + 2 * kPcTiles * kCB);
+            An[1][1] = *reinterpret_cast<const f32x4*>(Vb + a0 + 3 * kPcTiles * kCB);
+        } else {
+            An[0][0] = *reinterpret_cast<const f32x4*>(Vb + a0);
+            An[0][1] = *reinterpret_cast<const f32x4*>(Vb + a1);
+            An[1][0] = *reinterpret_cast<const f32x4*>(Vb + a0 + kPcTiles * kCB);
+            An[1][1] = *reinterpret_cast<const f32x4*>(Vb + a1 + kPcTiles * kCB);
+        }
         int buf = 0;
 #ifdef NRGBD_DEV
         long t_mfma = 0, t_bar = 0, t_epi = 0;
@@ -126,6 +144,28 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                 auto body = [&](auto first_tag) __attribute__((always_inline)) {
                     constexpr bool FIRST = decltype(first_tag)::value;
                     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (HALF) {
+                        // a step = the PAIR of transform points (2 xp, 2 xp + 1): 2 A reads (two pairs ahead), 8 MFMAs alternating
+                        // between the two accumulators, the weight lines of points 2 xp + 6 and 2 xp + 7 requested in two MFMA gaps
+#pragma unroll
+                        for (int xp = 0; xp < 8; ++xp) {
+                            const int cur = xp & 3, nxt = (xp + 2) & 3;
+                            const float* Vs = xp + 2 < 8 ? Vc : Vn;   // pairs 0, 1 of the next stage: its buffer was completed two barriers ago
+                            const int pn = (xp + 2) & 7;
+                            An[nxt][0] = *reinterpret_cast<const f32x4*>(Vs + a0 + (2 * pn) * (kPcTiles * kCB));
+                            An[nxt][1] = *reinterpret_cast<const f32x4*>(Vs + a0 + (2 * pn + 1) * (kPcTiles * kCB));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc[2 * xp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[cur][0][e], Bn[(2 * xp) % kPcNB][e],
+                                                                                      FIRST && e == 0 ? zero4 : acc[2 * xp][0], 0, 0, 0);
+                                acc[2 * xp + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[cur][1][e], Bn[(2 * xp + 1) % kPcNB][e],
+                                                                                          FIRST && e == 0 ? zero4 : acc[2 * xp + 1][0], 0, 0, 0);
+                                if (e == 1) Bn[(2 * xp + 6) % kPcNB] = 2 * xp + 6 < 16 ? wcur[(2 * xp + 6) * 256] : wnx[(2 * xp + 6 - 16) * 256];
+                                if (e == 3) Bn[(2 * xp + 7) % kPcNB] = 2 * xp + 7 < 16 ? wcur[(2 * xp + 7) * 256] : wnx[(2 * xp + 7 - 16) * 256];
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int xi = 0; xi < 16; ++xi) {
                         const int cur = xi & 3, nxt = (xi + 2) & 3;
@@ -151,6 +191,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                    }
                 };
                 if (!(abl & 1)) {
                     if (s == 0) body(std::true_type{}); else body(std::false_type{});
@@ -172,8 +213,8 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
             // lane (kq, jj): output channel co = 16 wv + jj; register r of row block m = tile 16 m + 4 kq + r, i.e. tile row
             // 2m + (kq >> 1), tile column 4 (kq & 1) + r: the lane part of an output's address is loop-invariant (lane_yoff),
             // the (m, r, a) part is uniform -> scalar base + 32-bit lane offset stores, no per-store address arithmetic
-            const int co = tl.cg * 64 + wv * 16 + jj;
-            float* ybase = a.y + (((size_t)tl.n * a.H + tl.y0 + tl.py) * a.W + tl.x0 + tl.px) * ldy + (EPI == 1 ? a.ycoff : 0) + tl.cg * 64 + wv * 16;
+            const int co = tl.cg * 64 + cwv * 16 + jj;
+            float* ybase = a.y + (((size_t)tl.n * a.H + tl.y0 + tl.py) * a.W + tl.x0 + tl.px) * ldy + (EPI == 1 ? a.ycoff : 0) + tl.cg * 64 + cwv * 16;
             const bool cok = EPI != 1 || a.cout_valid == 0 || co < a.cout_valid;   // EPI = 1: a padded output column is not stored
             const bool inside = tl.y0 + tl.py + DIL * (kPcTH - 1) < a.H && tl.x0 + tl.px + DIL * (kPcTW - 1) < a.W;
             float s1 = 0.f, s2 = 0.f;
@@ -189,14 +230,15 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                 const f32x2 bias2 = {bval, bval};
                 f32x2 S1 = {0.f, 0.f}, S2 = {0.f, 0.f};
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int mi = 0; mi < NM; ++mi) {
+                    const int m = HALF ? msel : mi;   // row block: address arithmetic uses m, the register index is mi
 #pragma unroll
                     for (int rp = 0; rp < 2; ++rp) {
                         f32x2 tr[2][4];   // t[a][xi_x] = sum_xi_y A^T[a][xi_y] M[xi_y][xi_x]
 #pragma unroll
                         for (int xx = 0; xx < 4; ++xx) {
-                            const f32x2 m0 = rp ? acc[0 + xx][m].hi : acc[0 + xx][m].lo, m1 = rp ? acc[4 + xx][m].hi : acc[4 + xx][m].lo;
-                            const f32x2 m2 = rp ? acc[8 + xx][m].hi : acc[8 + xx][m].lo, m3 = rp ? acc[12 + xx][m].hi : acc[12 + xx][m].lo;
+                            const f32x2 m0 = rp ? acc[0 + xx][mi].hi : acc[0 + xx][mi].lo, m1 = rp ? acc[4 + xx][mi].hi : acc[4 + xx][mi].lo;
+                            const f32x2 m2 = rp ? acc[8 + xx][mi].hi : acc[8 + xx][mi].lo, m3 = rp ? acc[12 + xx][mi].hi : acc[12 + xx][mi].lo;
                             tr[0][xx] = (m0 + m1) + m2;
                             tr[1][xx] = __builtin_elementwise_fma(m3, n1, __builtin_elementwise_fma(m2, n1, m1));   // (m1 - m2) - m3
                         }
@@ -225,13 +267,14 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                 s1 = S1.x + S1.y; s2 = S2.x + S2.y;
             } else {
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int mi = 0; mi < NM; ++mi) {
+                    const int m = HALF ? msel : mi;   // row block: address arithmetic uses m, the register index is mi
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float tr[2][4];
 #pragma unroll
                         for (int xx = 0; xx < 4; ++xx) {
-                            const float m0 = acc[0 + xx][m][r], m1 = acc[4 + xx][m][r], m2 = acc[8 + xx][m][r], m3 = acc[12 + xx][m][r];
+                            const float m0 = acc[0 + xx][mi][r], m1 = acc[4 + xx][mi][r], m2 = acc[8 + xx][mi][r], m3 = acc[12 + xx][mi][r];
                             tr[0][xx] = (m0 + m1) + m2;
                             tr[1][xx] = (m1 - m2) - m3;
                         }
@@ -259,8 +302,9 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                 s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
                 if (kq == 0) {
                     // column-major partials [2 Cout][rows]: nrgbd_bn_finalize_cm reads a channel's partials as one run
-                    a.stats[(size_t)co * a.rows + tl.row] = s1;
-                    a.stats[(size_t)(a.Cout + co) * a.rows + tl.row] = s2;
+                    const int srow = HALF ? 2 * tl.row + msel : tl.row;   // HALF: two waves share a channel -> a row per (tile, row block)
+                    a.stats[(size_t)co * a.rows + srow] = s1;
+                    a.stats[(size_t)(a.Cout + co) * a.rows + srow] = s2;
                 }
             }
             tl = tn;
@@ -671,15 +715,17 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
                                    int H, int W, int Cin, int Cout, int kd, int dilation, void* stream) {
     using namespace nrgbd;
     if (!x || !w_wino || !y) return NRGBD_E_NULL;
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cin > 2048 || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
+    const bool half = Cout == 32;               // the HALF form: 2-D, dilation 1 only
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cin > 2048 || Cout <= 0 || (Cout % 64 && !half)) return NRGBD_E_SHAPE;
     if ((kd != 1 && kd != 3) || (dilation != 1 && dilation != 2) || (kd == 3 && dilation != 1)) return NRGBD_E_ARG;
+    if (half && (kd != 1 || dilation != 1)) return NRGBD_E_SHAPE;
     if ((Cin / kCB) * kd < 2) return NRGBD_E_SHAPE;      // two stages are always in flight (two register sets)
     // 32-bit BYTE offsets in the loader: inside one slice when kd = 3 (the slice is a 64-bit base), inside the tensor otherwise
     if ((long)(kd == 3 ? 1 : N) * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;
     const int rows = nrgbd_conv_wino_tiles(N, H, W, dilation);
-    const long nt = (long)rows * (Cout / 64);
-    if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
-    WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt, rows,
+    const long nt = (long)rows * (half ? 1 : Cout / 64);
+    if (nt >= (1L << 30)) return NRGBD_E_SHAPE;
+    WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt, half ? 2 * rows : rows,
                  nullptr, 0, 0, 0, 0, dev_env_int("NRGBD_WINO_ABL")};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -701,7 +747,19 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     } while (0)
     const bool odd = (((Cin / kCB) * kd) & 1) != 0;
     if (odd && (kd != 3 || res || materialized)) return NRGBD_E_SHAPE;   // an odd stage count is instantiated for the K-Net's first layer only
-    if (kd == 3 && odd) {
+#define NRGBD_WINO_PC_LAUNCH_H(RES_, MAT_)                                                                          \
+    do {                                                                                                            \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, RES_, false, 0, MAT_, true>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        if (e != hipSuccess) return (int)e;                                                                         \
+        hipLaunchKernelGGL((conv_wino_pc_kernel<1, 1, RES_, false, 0, MAT_, true>), dim3(nwg), dim3(512), lds, st, a); \
+    } while (0)
+    if (half) {
+        if (res && materialized) NRGBD_WINO_PC_LAUNCH_H(true, true);
+        else if (res) NRGBD_WINO_PC_LAUNCH_H(true, false);
+        else if (materialized) NRGBD_WINO_PC_LAUNCH_H(false, true);
+        else NRGBD_WINO_PC_LAUNCH_H(false, false);
+    } else if (kd == 3 && odd) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<3, 1, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -715,6 +773,7 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     }
 #undef NRGBD_WINO_PC_LAUNCH
 #undef NRGBD_WINO_PC_LAUNCH_M
+#undef NRGBD_WINO_PC_LAUNCH_H
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -33,7 +33,7 @@ struct WinoPcArgs {
     int x_relu, res_relu;
     int N, H, W, Cin, Cout;
     int ntiles;           // spatial tiles x Cout/64
-    int rows;             // spatial tiles (statistics rows)
+    int rows;             // statistics rows: spatial tiles (x 2 in wino_pc.hip's HALF form: one per (tile, row block))
     const float* bias;    // EPI = 1 (R-Net form): [Cout] added to the output, then LeakyReLU(0.01) if out_lrelu; no statistics
     int out_lrelu;
     int ldy, ycoff, cout_valid;   // EPI = 1 only: pixel stride of y (0 = Cout), first output column, columns that exist (0 = Cout):
@@ -47,7 +47,7 @@ struct PcTile { int n, y0, x0, py, px, cg, row; };
 template <int KD, int DIL>
 __device__ __forceinline__ PcTile pc_decode(int t, const WinoPcArgs& a) {
     PcTile r;
-    const int ncg = a.Cout >> 6;
+    const int ncg = (a.Cout + 63) >> 6;          // Cout = 32 (wino_pc.hip's HALF form): one column group
     const int tiles_x = (a.W + kPcTW * DIL - 1) / (kPcTW * DIL), tiles_y = (a.H + kPcTH * DIL - 1) / (kPcTH * DIL);
     r.row = t / ncg;
     r.cg = t - r.row * ncg;

@@ -91,7 +91,7 @@ def _packed_wino(owner, conv):
     key = (w.data_ptr(), w._version, str(w.device), "wino")
     hit = cache.get(("wino", id(conv)))
     if hit is None or hit[0] != key:
-        hit = (key, ops.conv_wino_pack(w.detach().contiguous()))
+        hit = (key, ops.conv_wino_pack32(w.detach().contiguous()) if w.shape[0] == 32 and w.dim() == 4 else ops.conv_wino_pack(w.detach().contiguous()))
         cache[("wino", id(conv))] = hit
     return hit[1]
 
@@ -309,11 +309,11 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         d = conv.dilation[0]
         mfma = (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (d, d)
                 and conv.in_channels % 16 == 0 and (conv.out_channels, d) in self._MFMA_SHAPES)
-        # Winograd-domain kernel (csrc/wino_pc.hip) for every layer it covers (Cin % 32 == 0, Cout % 64 == 0: all but the
-        # 32-channel half-resolution layers): 0.116 vs 0.193 ms (64 -> 64), 0.37 vs 0.69 ms (128 -> 128), 0.80 vs 1.62 ms
+        # Winograd-domain kernel (csrc/wino_pc.hip) for every layer it covers (Cin % 32 == 0, Cout % 64 == 0, and its HALF form
+        # for the 32 -> 32 half-resolution layers): 0.116 vs 0.193 ms (64 -> 64), 0.37 vs 0.69 ms (128 -> 128), 0.80 vs 1.62 ms
         # (320 -> 128) at config B, and 2.4-3x at the 64x96 grid where 16x16 tiles under-fill the chip; conv2d.hip (direct) serves
-        # the 32-channel half-resolution layers.
-        wino = (mfma and d in (1, 2) and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
+        # what is left (16-channel inputs, 1x1 and stride-2 forms).
+        wino = (mfma and conv.in_channels % 32 == 0 and ((d in (1, 2) and conv.out_channels % 64 == 0) or (d == 1 and conv.out_channels == 32))
                 and ops.conv_wino_supported(a.z.shape[0], a.z.shape[1], a.z.shape[2], conv.in_channels, conv.out_channels, 1))
         if wino:
             z, st, mat = ops.conv_wino(a.z, _packed_wino(self, conv), conv.out_channels, 1, d, x_ss=a.ss, x_relu=a.relu,

@@ -378,7 +378,18 @@ def conv_wino_supported(N, H, W, Cin, Cout, kd):
     two stages, an even stage count except for the 16-channel 3-D first layer, 32-bit byte offsets in the loader."""
     stages = (Cin // 16) * kd
     span = (1 if kd == 3 else N) * H * W * Cin
+    if Cout == 32:      # the HALF form of wino_pc.hip: 2-D, dilation 1 (the caller's business), weights packed by conv_wino_pack32
+        return kd == 1 and Cin % 16 == 0 and stages >= 2 and stages % 2 == 0 and span < (1 << 30)
     return Cin % 16 == 0 and Cout % 64 == 0 and stages >= 2 and (stages % 2 == 0 or (kd == 3 and Cin == 16)) and span < (1 << 30)
+
+
+def conv_wino_pack32(w):
+    """Weight stream of a 32-output-channel 3x3 layer for the HALF form of nrgbd_conv_wino_f32 (Cout = 32): the 64-column stream
+    with the upper 32 columns zero (the kernel's waves read the two 16-column lines that exist)."""
+    w = _need(w, "w")
+    if w.dim() != 4 or w.shape[0] != 32 or tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("conv_wino_pack32 expects [32, Cin, 3, 3], got %s" % (tuple(w.shape),))
+    return conv_wino_pack(torch.cat((w.detach(), torch.zeros_like(w)), 0))
 
 
 def conv_wino_tiles(N, H, W, dilation=1):
@@ -393,11 +404,14 @@ def conv_wino(x, w_wino, Cout, kd, dilation=1, x_ss=None, x_relu=False, res=None
     x = _need(x, "x")
     N, H, W, Cin = x.shape
     y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
-    stats = torch.empty((2 * Cout, conv_wino_tiles(N, H, W, dilation)), dtype=torch.float32, device=x.device) if want_stats else None
+    half = Cout == 32     # HALF form: one statistics row per (tile, row block); the weight stream is the zero-padded 64-column one
+    if half and (kd != 1 or dilation != 1):
+        raise ValueError("conv_wino: Cout = 32 is the 2-D, dilation-1 form only")
+    stats = torch.empty((2 * Cout, (2 if half else 1) * conv_wino_tiles(N, H, W, dilation)), dtype=torch.float32, device=x.device) if want_stats else None
     mat = torch.empty_like(x) if materialize else None
     if res is not None:
         res = _need(res, "res", x.shape)
-    if w_wino.numel() != (Cout // 64) * (Cin // 16) * kd * 16 * 1024:
+    if w_wino.numel() != max(1, Cout // 64) * (Cin // 16) * kd * 16 * 1024:
         raise ValueError("conv_wino: packed weights do not match Cin=%d Cout=%d kd=%d" % (Cin, Cout, kd))
     with torch.cuda.device(x.device):
         rc = _lib.load().nrgbd_conv_wino_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(mat),

@@ -193,6 +193,43 @@ def test_conv_wino_pc_2d_fused_prologue_materialize(Cin, Cout, dil):
     assert torch.allclose(s[:Cout], want.double().sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("N,H,W,fused", [(1, 16, 16, False), (3, 21, 37, False), (5, 48, 64, True), (2, 19, 35, True), (5, 96, 128, False)])
+def test_conv_wino_pc_half_form_32_channels(N, H, W, fused):
+    """The HALF form of wino_pc.hip (Cout = 32: firstconv.1/.2 and layer1 of the trunk, psm_submodule.py:90-103) vs F.conv2d in
+    float64 — plain, and with the fused prologue (BatchNorm apply + ReLU, residual, materialise); statistics = two rows per tile."""
+    from neuralrgbd_amd import ops
+    C = 32
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV)
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.08).to(DEV)
+    wp = ops.conv_wino_pack32(w)
+    assert ops.conv_wino_supported(N, H, W, C, C, 1)
+    if fused:
+        r = torch.randn(N, C, H, W, generator=g).to(DEV)
+        ss, rs = torch.randn(C, 2, generator=g).to(DEV), torch.randn(C, 2, generator=g).to(DEV)
+        inp = torch.relu(x * ss[:, 0].view(1, -1, 1, 1) + ss[:, 1].view(1, -1, 1, 1)) + (r * rs[:, 0].view(1, -1, 1, 1) + rs[:, 1].view(1, -1, 1, 1))
+        y, stats, mat = ops.conv_wino(_cl(x), wp, C, 1, 1, x_ss=ss, x_relu=True, res=_cl(r), res_ss=rs, materialize=True)
+        assert (mat.permute(0, 3, 1, 2) - inp).abs().max().item() < 1e-5
+        y2, _, _ = ops.conv_wino(_cl(x), wp, C, 1, 1, x_ss=ss, x_relu=True, res=_cl(r), res_ss=rs, want_stats=False)   # RES without MAT
+        assert torch.equal(y, y2)
+    else:
+        inp = x
+        y, stats, mat = ops.conv_wino(_cl(x), wp, C, 1, 1)
+        ym, _, mat2 = ops.conv_wino(_cl(x), wp, C, 1, 1, materialize=True)                                              # MAT without RES
+        assert torch.equal(y, ym) and torch.equal(mat2.permute(0, 3, 1, 2), x)
+    want = F.conv2d(inp.double(), w.double(), padding=1)
+    err = (y.permute(0, 3, 1, 2).double() - want).abs().max().item()
+    print("[parity] conv_wino_pc HALF N%d %dx%d fused=%s max|d vs fp64|=%.3e (|y|max %.2f)" % (N, H, W, fused, err, want.abs().max().item()))
+    assert y.shape == (N, H, W, C) and err < 2e-5 * max(1.0, want.abs().max().item())
+    assert stats.shape == (2 * C, 2 * ops.conv_wino_tiles(N, H, W, 1))
+    s = stats.double().sum(1)
+    assert torch.allclose(s[:C], want.sum((0, 2, 3)), rtol=1e-5, atol=2e-3)
+    assert torch.allclose(s[C:], (want ** 2).sum((0, 2, 3)), rtol=1e-5, atol=2e-3)
+    # and against the direct kernel it replaces in the trunk
+    yd, _, _ = ops.conv2d(_cl(inp), ops.conv_pack_weights(w), C, 1, want_stats=False)
+    assert (yd - y).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
 def test_bn_finalize_cm_matches_row_major_finaliser():
     """Column-major partials (the Winograd kernel's) through nrgbd_bn_finalize_cm == the same partials through nrgbd_bn_finalize."""
     from neuralrgbd_amd import ops

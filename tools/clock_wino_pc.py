@@ -13,7 +13,7 @@ g = torch.Generator().manual_seed(0)
 x = torch.randn(N, H, W, Cin, generator=g).cuda()
 w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).cuda()
 ss = torch.rand(Cin, 2, generator=g).cuda()
-ww = ops.conv_wino_pack(w)
+ww = ops.conv_wino_pack32(w) if Cout == 32 else ops.conv_wino_pack(w)
 for _ in range(3):
     st = ops.conv_wino(x, ww, Cout, 1, 1, x_ss=ss, x_relu=True)[1]
 torch.cuda.synchronize()
