@@ -403,6 +403,16 @@ int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_relu, const 
                            int res_relu, float* materialized, const float* w_wino, float* y, float* stats,
                            int N, int H, int W, int Cin, int Cout, void* stream);
 int nrgbd_conv_wino_dw_workgroups(int N, int H, int W, int Cout);
+/*
+ * nrgbd_conv_wino_dw_unit_f32 — nrgbd_conv_wino_dw_f32's plain form for an input relu(x * scale + shift) (no residual, no
+ * materialise) with the ReLU taken by the producers' FMA itself (its [0, 1] clamp) instead of one v_max_f32 per element:
+ *   x_unit = 2^-k: the kernel multiplies (scale, shift) by it; the caller guarantees |x * scale + shift| < 2^k everywhere (for a
+ *   BatchNorm with batch statistics over n values: |gamma| sqrt(n) + |beta| bounds it, whatever the data) and packs the weight
+ *   stream from 2^k * w.  Powers of two commute with every rounding on the way, so y and stats have the bits of the plain form.
+ * Same layer as nrgbd_conv_wino_dw_f32 (models/basic.py:53-68,71-94: conv3d + BatchNorm3d + ReLU feeding the next conv3d).
+ */
+int nrgbd_conv_wino_dw_unit_f32(const float* x, const float* x_ss, float x_unit, const float* w_wino, float* y, float* stats,
+                                int N, int H, int W, int Cin, int Cout, void* stream);
 
 /*
  * R-Net (DPV up-sampler) on the same matrix-core kernel.  Replaces, per layer of models/Refine.py:51-107:

@@ -66,6 +66,9 @@ __device__ __forceinline__ DwTile dw_decode(int t, const WinoPcArgs& a) {
 // first read, and the 32 workgroups of an XCD stream 1.5 MB (3 MB with a residual operand) per stage through their 4 MB L2 beside
 // the 1 MB weight stream — every re-read missed (profiles/r3_pmc_wino.txt: the residual variant fetched ALL its reads).  Turning
 // round at the phase boundary puts the most recently read units first.
+#ifndef NRGBD_DW_IDENT
+#define NRGBD_DW_IDENT 1   // 0: experimental A/B builds only (tools/knet_ab.py)
+#endif
 #ifndef NRGBD_DW_SERP
 #define NRGBD_DW_SERP 1
 #endif
@@ -81,7 +84,15 @@ __device__ __forceinline__ int dw_zB(int t) { return t == 2 ? 0 : (t == 3 ? 2 : 
 // waits for the refill issued a few instructions earlier, i.e. exposes a full memory latency per stage.
 // RSID: the residual operand comes with identity (scale, shift) and no ReLU (the K-Net's four residual layers: a materialised
 // skip tensor) — its normalisation FMAs are dropped.
-template <bool RES, bool MAT, bool RSID>
+// IDENT: x needs no (scale, shift) and no ReLU (an input some earlier pass materialised: the K-Net's residual layers behind
+// nrgbd_nhwc_act, every layer of the training path) — the producers' 10 packed FMAs per unit are dropped (instantiated for the
+// plain form only).
+// CLAMP: x = relu(x * s + t) with the ReLU taken by the FMA's own [0, 1] clamp: the (scale, shift) pairs are multiplied by
+// a.x_unit = 2^-k on their way to LDS (k chosen by the caller so that no activated value can reach 2^k: |BatchNorm(y)| <=
+// |gamma| sqrt(n) + |beta| for batch statistics over n values) and the weight stream carries 2^k.  Scaling by a power of two
+// commutes with every rounding of the path, so the output bits are those of the plain form; the producers lose the 20
+// v_max_f32 per unit (instantiated for the plain form only).
+template <bool RES, bool MAT, bool RSID, bool IDENT = false, bool CLAMP = false>
 __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Vb = lds;                                   // [2][16 xi][32 tiles][16]
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
     // global memory with its raw words — as wino_pc.hip does — puts them FIRST in the refill's queue, and the compiler moves them
     // into their home registers immediately: an s_waitcnt right behind the loads, i.e. one exposed L2 round trip per unit.
     for (int i = tid; i < 2 * a.Cin; i += 512) {
-        ssl[i] = a.x_ss ? a.x_ss[i] : ((i & 1) ? 0.f : 1.f);
+        ssl[i] = (a.x_ss ? a.x_ss[i] : ((i & 1) ? 0.f : 1.f)) * (CLAMP ? a.x_unit : 1.f);
         ssl[2 * a.Cin + i] = (RES && a.res_ss) ? a.res_ss[i] : ((i & 1) ? 0.f : 1.f);
     }
     __syncthreads();
@@ -331,8 +342,10 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
         // raw words of one unit = (slice zrel of stage s, channel block of stage s) -> registers
         auto issue = [&](bool nx, int t, int cb, bool unitB, Regs& r) __attribute__((always_inline)) {
             r.rs[0] = r.rs[1] = f32x4{1.f, 0.f, 1.f, 0.f};
-            r.ss[0] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4));
-            r.ss[1] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4) + 4);
+            if constexpr (!IDENT) {
+                r.ss[0] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4));
+                r.ss[1] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4) + 4);
+            }
             if constexpr (RES && !RSID) {
                 r.rs[0] = *reinterpret_cast<const f32x4*>(ssl + 2 * a.Cin + 2 * (cb * kCB + w4 * 4));
                 r.rs[1] = *reinterpret_cast<const f32x4*>(ssl + 2 * a.Cin + 2 * (cb * kCB + w4 * 4) + 4);
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
             constexpr bool INTERIOR = decltype(interior_tag)::value;   // every item of every lane inside the image: no padding mask
             // the (scale, shift) words are re-paired for the packed FMAs HERE and not where they were loaded: without this the
             // compiler hoists the eight moves to right behind the loads, i.e. waits for the prefetch the moment it is issued
-            asm volatile("" : "+v"(r.ss[0]), "+v"(r.ss[1]));
+            if constexpr (!IDENT) asm volatile("" : "+v"(r.ss[0]), "+v"(r.ss[1]));
             if constexpr (RES && !RSID) asm volatile("" : "+v"(r.rs[0]), "+v"(r.rs[1]));
             const f32x2 sc01 = {r.ss[0].x, r.ss[0].z}, sh01 = {r.ss[0].y, r.ss[0].w}, sc23 = {r.ss[1].x, r.ss[1].z}, sh23 = {r.ss[1].y, r.ss[1].w};
             const f32x2 rc01 = {r.rs[0].x, r.rs[0].z}, rh01 = {r.rs[0].y, r.rs[0].w}, rc23 = {r.rs[1].x, r.rs[1].z}, rh23 = {r.rs[1].y, r.rs[1].w};
@@ -378,17 +391,29 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
 #pragma unroll
                     for (int i = 0; i < NU; ++i) old[i] = *reinterpret_cast<const f32x4*>(raw + wr_off[U0 + i]);
                 }
+                if constexpr (IDENT) {
 #pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    lo[i] = __builtin_elementwise_fma(r.pre[U0 + i].lo, sc01, sh01);
-                    hi[i] = __builtin_elementwise_fma(r.pre[U0 + i].hi, sc23, sh23);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (a.x_relu) {
+                    for (int i = 0; i < NU; ++i) { lo[i] = r.pre[U0 + i].lo; hi[i] = r.pre[U0 + i].hi; }
+                } else if constexpr (CLAMP) {
 #pragma unroll
-                    for (int i = 0; i < NU; ++i) { lo[i].x = relu1(lo[i].x); lo[i].y = relu1(lo[i].y); hi[i].x = relu1(hi[i].x); hi[i].y = relu1(hi[i].y); }
+                    for (int i = 0; i < NU; ++i) {
+                        lo[i] = pk_fma_clamp01(r.pre[U0 + i].lo, sc01, sh01);
+                        hi[i] = pk_fma_clamp01(r.pre[U0 + i].hi, sc23, sh23);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) {
+                        lo[i] = __builtin_elementwise_fma(r.pre[U0 + i].lo, sc01, sh01);
+                        hi[i] = __builtin_elementwise_fma(r.pre[U0 + i].hi, sc23, sh23);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (a.x_relu) {
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) { lo[i].x = relu1(lo[i].x); lo[i].y = relu1(lo[i].y); hi[i].x = relu1(hi[i].x); hi[i].y = relu1(hi[i].y); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 if constexpr (RES && RSID) {
 #pragma unroll
                     for (int i = 0; i < NU; ++i) { lo[i] = lo[i] + r.prer[U0 + i].lo; hi[i] = hi[i] + r.prer[U0 + i].hi; }
@@ -597,7 +622,7 @@ extern "C" int nrgbd_conv_wino_dw_workgroups(int N, int H, int W, int Cout) {
 
 static int conv_wino_dw_launch(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
                                int res_relu, float* materialized, const float* w_wino, float* y, float* stats, int N,
-                               int H, int W, int Cin, int Cout, void* stream) {
+                               int H, int W, int Cin, int Cout, void* stream, float x_unit = 0.f) {
     using namespace nrgbd;
     if (!x || !w_wino || !y) return NRGBD_E_NULL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB || Cin > kDwMaxCin || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
@@ -608,7 +633,7 @@ static int conv_wino_dw_launch(const float* x, const float* x_ss, int x_relu, co
     const long nt = (long)(rows / 2) * (Cout / 64);
     if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
     WinoPcArgs a{x, x_ss, res, res_ss, materialized, w_wino, y, stats, x_relu, res_relu, N, H, W, Cin, Cout, (int)nt, rows,
-                 nullptr, 0, 0, 0, 0, dev_env_int("NRGBD_WINO_ABL")};
+                 nullptr, 0, 0, 0, 0, dev_env_int("NRGBD_WINO_ABL"), x_unit};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -625,9 +650,20 @@ static int conv_wino_dw_launch(const float* x, const float* x_ss, int x_relu, co
         hipLaunchKernelGGL((conv_wino_dw_kernel<RES_, MAT_, RSID_>), dim3(nwg), dim3(512), lds, st, a);                        \
     } while (0)
     const bool rsid = res && !res_ss && !res_relu;
-    if (res && rsid) { if (materialized) NRGBD_WINO_DW_LAUNCH(true, true, true); else NRGBD_WINO_DW_LAUNCH(true, false, true); }
+    if (x_unit != 0.f) {            // the CLAMP instantiation (nrgbd_conv_wino_dw_unit_f32 checked its preconditions)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw_kernel<false, false, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((conv_wino_dw_kernel<false, false, false, false, true>), dim3(nwg), dim3(512), lds, st, a);
+    } else if (res && rsid) { if (materialized) NRGBD_WINO_DW_LAUNCH(true, true, true); else NRGBD_WINO_DW_LAUNCH(true, false, true); }
     else if (res) { if (materialized) NRGBD_WINO_DW_LAUNCH(true, true, false); else NRGBD_WINO_DW_LAUNCH(true, false, false); }
-    else { if (materialized) NRGBD_WINO_DW_LAUNCH(false, true, false); else NRGBD_WINO_DW_LAUNCH(false, false, false); }
+    else if (materialized) NRGBD_WINO_DW_LAUNCH(false, true, false);
+    else if (NRGBD_DW_IDENT && !x_ss && !x_relu) {   // the IDENT instantiation: nothing to apply to x
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw_kernel<false, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((conv_wino_dw_kernel<false, false, false, true>), dim3(nwg), dim3(512), lds, st, a);
+    } else NRGBD_WINO_DW_LAUNCH(false, false, false);
 #undef NRGBD_WINO_DW_LAUNCH
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
@@ -637,4 +673,14 @@ extern "C" int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_r
                                       int res_relu, float* materialized, const float* w_wino, float* y, float* stats, int N,
                                       int H, int W, int Cin, int Cout, void* stream) {
     return conv_wino_dw_launch(x, x_ss, x_relu, res, res_ss, res_relu, materialized, w_wino, y, stats, N, H, W, Cin, Cout, stream);
+}
+
+// The plain form with relu(x * s + t) as a clamped FMA (the CLAMP instantiation): x_unit = 2^-k, the weight stream packed from
+// 2^k * w; see include/nrgbd.h.
+extern "C" int nrgbd_conv_wino_dw_unit_f32(const float* x, const float* x_ss, float x_unit, const float* w_wino, float* y, float* stats,
+                                           int N, int H, int W, int Cin, int Cout, void* stream) {
+    if (!x_ss) return NRGBD_E_NULL;
+    int ex = 0;
+    if (!(x_unit > 0.f) || x_unit > 1.f || frexpf(x_unit, &ex) != 0.5f) return NRGBD_E_ARG;   // a power of two in (0, 1]
+    return conv_wino_dw_launch(x, x_ss, 1, nullptr, nullptr, 0, nullptr, w_wino, y, stats, N, H, W, Cin, Cout, stream, x_unit);
 }

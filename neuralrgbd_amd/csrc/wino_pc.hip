@@ -453,13 +453,18 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                             constexpr int U0 = decltype(u0_tag)::value, U1 = decltype(u1_tag)::value, NU = U1 - U0;
                             constexpr bool INTERIOR = decltype(interior_tag)::value;   // every item of every lane inside the image: no padding mask
                             f32x2 lo[NU], hi[NU];
+                            if constexpr (EPI == 1) {   // the R-Net form has no prologue: no identity FMAs (x * 1 + 0 is not folded: -0)
 #pragma unroll
-                            for (int i = 0; i < NU; ++i) {
-                                lo[i] = __builtin_elementwise_fma(r.pre[U0 + i].lo, sc01, sh01);
-                                hi[i] = __builtin_elementwise_fma(r.pre[U0 + i].hi, sc23, sh23);
+                                for (int i = 0; i < NU; ++i) { lo[i] = r.pre[U0 + i].lo; hi[i] = r.pre[U0 + i].hi; }
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < NU; ++i) {
+                                    lo[i] = __builtin_elementwise_fma(r.pre[U0 + i].lo, sc01, sh01);
+                                    hi[i] = __builtin_elementwise_fma(r.pre[U0 + i].hi, sc23, sh23);
+                                }
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            if (a.x_relu) {
+                            if (EPI == 0 && a.x_relu) {
 #pragma unroll
                                 for (int i = 0; i < NU; ++i) { lo[i].x = relu1(lo[i].x); lo[i].y = relu1(lo[i].y); hi[i].x = relu1(hi[i].x); hi[i].y = relu1(hi[i].y); }
                             }

@@ -40,6 +40,8 @@ struct WinoPcArgs {
                                   // the R-Net writes into concat buffers and pads 67 / 96 outputs to the 64-column groups
     int abl;              // developer ablation bits, honoured by -DNRGBD_DEV builds only: 1 = producers only, 2 = consumers only,
                           // 4 = no transform, 8 = no publish, 16 / 32 = s_setprio 2 for the consumers / producers
+    float x_unit;         // CLAMP instantiations only: 2^-k; (scale, shift) of x are multiplied by it and the ReLU is the [0, 1]
+                          // clamp of the packed FMA; the weight stream carries the factor 2^k (see nrgbd_conv_wino_dw_unit_f32)
 };
 
 struct PcTile { int n, y0, x0, py, px, cg, row; };
@@ -85,6 +87,13 @@ __device__ __forceinline__ float relu1(float x) {
     float r;
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
     return r;
+}
+// a * b + c clamped to [0, 1] in the same instruction (the VOP3P clamp bit): with operands pre-scaled so that the result cannot
+// exceed 1 this IS the ReLU — no v_max_f32 per element
+__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
 }
 __device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) {
     const f32x2 lo = a.lo + b.lo, hi = a.hi + b.hi;

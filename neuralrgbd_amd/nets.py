@@ -96,16 +96,34 @@ def _packed_wino(owner, conv):
     return hit[1]
 
 
-def _packed_wino_dw(owner, conv):
-    """Weight stream of csrc/wino_dw.hip (Winograd along depth as well): U_t = sum_kd G[t][kd] (G g_kd G^T)."""
+def _packed_wino_dw(owner, conv, mult=1.0):
+    """Weight stream of csrc/wino_dw.hip (Winograd along depth as well): U_t = sum_kd G[t][kd] (G g_kd G^T), of mult * w
+    (mult = 2^k: the clamped-FMA form of the kernel, whose input arrives scaled by 2^-k)."""
     from . import ops
     cache = owner.__dict__.setdefault("_wp_cache", {})
     w = conv.weight
-    key = (w.data_ptr(), w._version, str(w.device), "wino_dw")
+    key = (w.data_ptr(), w._version, str(w.device), "wino_dw", float(mult))
     hit = cache.get(("wino_dw", id(conv)))
     if hit is None or hit[0] != key:
-        hit = (key, ops.conv_wino_dw_pack(w.detach().contiguous()))
+        wc = w.detach().contiguous()
+        hit = (key, ops.conv_wino_dw_pack(wc if mult == 1.0 else wc * float(mult)))
         cache[("wino_dw", id(conv))] = hit
+    return hit[1]
+
+
+def _relu_unit(owner, bn, count):
+    """x_unit = 2^-k of the clamped-FMA convolution forms for an input relu(bn(y)), bn with batch statistics over `count` values
+    (ops.relu_unit); 0 when the bound does not apply (running statistics).  Cached per (affine parameters, count): reading
+    the parameters synchronises with the host once."""
+    from . import ops
+    if not (bn.training or not bn.track_running_stats) or not bn.affine:
+        return 0.0
+    cache = owner.__dict__.setdefault("_wp_cache", {})
+    key = (bn.weight.data_ptr(), bn.weight._version, bn.bias.data_ptr(), bn.bias._version, int(count))
+    hit = cache.get(("unit", id(bn)))
+    if hit is None or hit[0] != key:
+        hit = (key, ops.relu_unit(bn.weight, bn.bias, count))
+        cache[("unit", id(bn))] = hit
     return hit[1]
 
 
@@ -580,6 +598,9 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         def run(i, x, x_ss, x_relu, res=None, materialize=False):
             conv, bn = L[i]
             cm = False
+            # relu(bn(previous output)) as a clamped FMA (wino_dw.hip CLAMP): the previous layer's BatchNorm bounds its output
+            unit = _relu_unit(self, L[i - 1][1], count) if (i > 0 and x_ss is not None and x_relu and res is None and not materialize
+                                                              and generation is None) else 0.0
             if res is not None and self._split_residual:
                 # the residual layers as TWO launches: in = bn(x) + res materialised by one HBM-bound pass (nrgbd_nhwc_act), then the
                 # plain form of the convolution on it.  In the fused form the producers of wino_dw.hip load and add the second
@@ -590,8 +611,8 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
                 return y, ss, x
             if (generation is None and conv.in_channels in (16, 64) and conv.out_channels == 64
                     and ops.conv_wino_dw_supported(D, H, W, conv.in_channels, 64)):
-                y, st, mat = ops.conv_wino_dw(x, _packed_wino_dw(self, conv), 64, x_ss=x_ss, x_relu=x_relu, res=res,
-                                              materialize=materialize, want_stats=need_stats(bn))
+                y, st, mat = ops.conv_wino_dw(x, _packed_wino_dw(self, conv, 1.0 / unit if unit else 1.0), 64, x_ss=x_ss, x_relu=x_relu,
+                                              res=res, materialize=materialize, want_stats=need_stats(bn), x_unit=unit)
                 cm = True
             elif generation != "direct" and (conv.in_channels == 64 or (conv.in_channels == 16 and res is None)) \
                     and ops.conv_wino_supported(D, H, W, conv.in_channels, 64, 3):

@@ -452,10 +452,21 @@ def conv_wino_dw_supported(N, H, W, Cin, Cout):
     return N % 2 == 0 and N >= 2 and H % 8 == 0 and W % 16 == 0 and Cin % 16 == 0 and Cout % 64 == 0 and H * W * Cin < (1 << 30)
 
 
+def relu_unit(gamma, beta, n):
+    """2^-k with 2^k > |gamma_c| sqrt(n) + |beta_c| for every channel: a bound on |BatchNorm(y)_c| under batch statistics over n
+    values that holds for ANY data (|y - mean| <= sqrt(n var)), i.e. the x_unit of the clamped-FMA convolution forms.  Reads the
+    affine parameters once (host synchronisation: callers cache it with the packed weights)."""
+    import math
+    bound = float(gamma.detach().abs().max()) * math.sqrt(float(n)) + float(beta.detach().abs().max())
+    return 2.0 ** -max(0, math.floor(math.log2(max(bound, 1e-30))) + 1)
+
+
 def conv_wino_dw(x, w_wino, Cout, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False, materialize=False,
-                 want_stats=True):
+                 want_stats=True, x_unit=0.0):
     """Channels-last 3x3x3 stride-1 convolution over x [D,H,W,Cin] with Winograd in all three dimensions (wino_dw.hip):
-    -> (y [D,H,W,Cout], stats [2*Cout, tiles] (column-major partials for bn_finalize_cm) | None, materialized | None)."""
+    -> (y [D,H,W,Cout], stats [2*Cout, tiles] (column-major partials for bn_finalize_cm) | None, materialized | None).
+    x_unit = 2^-k > 0: the clamped-FMA form (nrgbd_conv_wino_dw_unit_f32) — x_ss and x_relu required, no residual / materialise,
+    and w_wino packed from 2^k * w."""
     x = _need(x, "x")
     N, H, W, Cin = x.shape
     y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
@@ -466,8 +477,14 @@ def conv_wino_dw(x, w_wino, Cout, x_ss=None, x_relu=False, res=None, res_ss=None
     if w_wino.numel() != (Cout // 64) * (Cin // 16) * 4 * 16 * 1024:
         raise ValueError("conv_wino_dw: packed weights do not match Cin=%d Cout=%d" % (Cin, Cout))
     with torch.cuda.device(x.device):
-        rc = _lib.load().nrgbd_conv_wino_dw_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(mat),
-                                                 _p(w_wino), _p(y), _p(stats), N, H, W, Cin, Cout, _stream(x))
+        if x_unit:
+            if x_ss is None or not x_relu or res is not None or materialize:
+                raise ValueError("conv_wino_dw: x_unit is the plain BatchNorm + ReLU form only")
+            rc = _lib.load().nrgbd_conv_wino_dw_unit_f32(_p(x), _p(x_ss), float(x_unit), _p(w_wino), _p(y), _p(stats), N, H, W, Cin,
+                                                          Cout, _stream(x))
+        else:
+            rc = _lib.load().nrgbd_conv_wino_dw_f32(_p(x), _p(x_ss), int(x_relu), _p(res), _p(res_ss), int(res_relu), _p(mat),
+                                                     _p(w_wino), _p(y), _p(stats), N, H, W, Cin, Cout, _stream(x))
     _lib.check(rc, "nrgbd_conv_wino_dw_f32")
     return y, stats, mat
 

@@ -337,3 +337,29 @@ def test_both_weight_streams_in_one_launch(shape):
         assert torch.equal(f, ops.conv_wino_dw_pack(w)) and torch.equal(b, ops.conv_wino_dw_pack(w, True))
     with pytest.raises(ValueError):
         ops.conv_wino_pack(torch.zeros(64, 32, 3, 3, device=DEV), transposed=2)      # 32 inputs cannot be a 64-column output group
+
+
+def test_wino_dw_clamped_fma_relu_has_the_bits_of_the_plain_form():
+    """nrgbd_conv_wino_dw_unit_f32: relu(x * s + t) taken by the producers' FMA clamp on operands scaled by 2^-k, weights packed
+    from 2^k * w — output and statistics bit-identical to the plain form (v_max_f32 per element), for a bound just above the
+    largest activation and for a generous one; ops.relu_unit bounds a BatchNorm's output whatever the data."""
+    from neuralrgbd_amd import ops
+    D, H, W, C = 8, 24, 48, 64
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(D, H, W, C, generator=g) * 3.0).to(DEV)
+    w = (torch.randn(C, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    ss = torch.randn(C, 2, generator=g).to(DEV)
+    y0, st0, _ = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w), C, x_ss=ss, x_relu=True)
+    act_max = torch.relu(x * ss[:, 0] + ss[:, 1]).max().item()
+    import math
+    for k in (math.floor(math.log2(act_max)) + 1, 14):
+        y1, st1, _ = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w * 2.0 ** k), C, x_ss=ss, x_relu=True, x_unit=2.0 ** -k)
+        assert torch.equal(y0, y1) and torch.equal(st0, st1), k
+    with pytest.raises(Exception):
+        ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w), C, x_ss=ss, x_relu=True, x_unit=0.3)      # not a power of two
+    # the bound: a BatchNorm output with batch statistics never exceeds |gamma| sqrt(n) + |beta|, even for one huge outlier
+    n = 4096
+    yv = torch.zeros(n, 4); yv[0] = 1e6
+    gamma, beta = torch.tensor([1.5, -0.3, 2.0, 0.1]), torch.tensor([0.2, -4.0, 0.0, 3.0])
+    z = torch.nn.functional.batch_norm(yv, None, None, gamma, beta, training=True, eps=1e-5)
+    assert z.abs().max().item() < 1.0 / ops.relu_unit(gamma, beta, n)

@@ -45,6 +45,7 @@ def main():
     for name, fn in (("direct plain", lambda: ops.conv3d(x, wd, x_ss=ss, x_relu=True)),
                      ("wino-pc plain", lambda: ops.conv_wino(x, ww, 64, 3, x_ss=ss, x_relu=True)),
                      ("wino-dw plain", lambda: ops.conv_wino_dw(x, wdw, 64, x_ss=ss, x_relu=True)),
+                     ("wino-dw ident", lambda: ops.conv_wino_dw(x, wdw, 64)),
                      ("wino-dw res+mat", lambda: ops.conv_wino_dw(x, wdw, 64, x_ss=ss, res=r, materialize=True)),
                      ("direct res+mat", lambda: ops.conv3d(x, wd, x_ss=ss, res=r, materialize=True)),
                      ("wino-pc res+mat", lambda: ops.conv_wino(x, ww, 64, 3, x_ss=ss, res=r, materialize=True))):
