@@ -129,8 +129,9 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
     // global memory with its raw words — as wino_pc.hip does — puts them FIRST in the refill's queue, and the compiler moves them
     // into their home registers immediately: an s_waitcnt right behind the loads, i.e. one exposed L2 round trip per unit.
     for (int i = tid; i < 2 * a.Cin; i += 512) {
-        ssl[i] = (a.x_ss ? a.x_ss[i] : ((i & 1) ? 0.f : 1.f)) * (CLAMP ? a.x_unit : 1.f);
-        ssl[2 * a.Cin + i] = (RES && a.res_ss) ? a.res_ss[i] : ((i & 1) ? 0.f : 1.f);
+        const int j = pc_ss_slot(i);      // pairs as the packed FMAs take them: (s0, s1, t0, t1 | s2, s3, t2, t3) per 4 channels
+        ssl[j] = (a.x_ss ? a.x_ss[i] : ((i & 1) ? 0.f : 1.f)) * (CLAMP ? a.x_unit : 1.f);
+        ssl[2 * a.Cin + j] = (RES && a.res_ss) ? a.res_ss[i] : ((i & 1) ? 0.f : 1.f);
     }
     __syncthreads();
 
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
         DwTile tl = dw_decode(first, a), tn = tl;
         // raw words of one unit = (slice zrel of stage s, channel block of stage s) -> registers
         auto issue = [&](bool nx, int t, int cb, bool unitB, Regs& r) __attribute__((always_inline)) {
-            r.rs[0] = r.rs[1] = f32x4{1.f, 0.f, 1.f, 0.f};
+            r.rs[0] = r.rs[1] = f32x4{1.f, 1.f, 0.f, 0.f};
             if constexpr (!IDENT) {
                 r.ss[0] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4));
                 r.ss[1] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4) + 4);
@@ -351,15 +352,17 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                 r.rs[1] = *reinterpret_cast<const f32x4*>(ssl + 2 * a.Cin + 2 * (cb * kCB + w4 * 4) + 4);
             }
             const int tz = (nx ? tn.z0 : tl.z0) + (unitB ? dw_zB(t) : dw_zA(t));
-            const int z = min(max(tz, 0), a.N - 1);    // clamped: an outside slice is not used when published
-            const size_t base = ((size_t)z * plane + (size_t)(cb * kCB)) * sizeof(float);
-            const char* xb = reinterpret_cast<const char*>(a.x) + base;
-            const char* rb = reinterpret_cast<const char*>(a.res) + base;
+            // (z, cb) are wave-uniform; saying so keeps the base in SGPRs and the loads in their saddr form (uniform 64-bit base +
+            // 32-bit lane offset) — otherwise every load of the stage loop pays a v_lshl_add_u64
+            const int z = __builtin_amdgcn_readfirstlane(min(max(tz, 0), a.N - 1));    // clamped: an outside slice is not used when published
+            const size_t base = ((size_t)z * plane + (size_t)(__builtin_amdgcn_readfirstlane(cb) * kCB)) * sizeof(float);
+            const __amdgpu_buffer_rsrc_t xb = pc_rsrc(reinterpret_cast<const char*>(a.x) + base);
+            const __amdgpu_buffer_rsrc_t rb = pc_rsrc(reinterpret_cast<const char*>(RES ? a.res : a.x) + base);
 #pragma unroll
             for (int u = 0; u < kPcNPF; ++u) {
                 const unsigned o = nx ? nxt_off[u] : cur_off[u];
-                r.pre[u] = *reinterpret_cast<const f32x4*>(xb + o);
-                if constexpr (RES) r.prer[u] = *reinterpret_cast<const f32x4*>(rb + o);
+                r.pre[u] = pc_bload(xb, o);
+                if constexpr (RES) r.prer[u] = pc_bload(rb, o);
             }
         };
         setup(tl, cur_off, cur_keep, cur_own);
@@ -377,8 +380,8 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
             // compiler hoists the eight moves to right behind the loads, i.e. waits for the prefetch the moment it is issued
             if constexpr (!IDENT) asm volatile("" : "+v"(r.ss[0]), "+v"(r.ss[1]));
             if constexpr (RES && !RSID) asm volatile("" : "+v"(r.rs[0]), "+v"(r.rs[1]));
-            const f32x2 sc01 = {r.ss[0].x, r.ss[0].z}, sh01 = {r.ss[0].y, r.ss[0].w}, sc23 = {r.ss[1].x, r.ss[1].z}, sh23 = {r.ss[1].y, r.ss[1].w};
-            const f32x2 rc01 = {r.rs[0].x, r.rs[0].z}, rh01 = {r.rs[0].y, r.rs[0].w}, rc23 = {r.rs[1].x, r.rs[1].z}, rh23 = {r.rs[1].y, r.rs[1].w};
+            const f32x2 sc01 = r.ss[0].lo, sh01 = r.ss[0].hi, sc23 = r.ss[1].lo, sh23 = r.ss[1].hi;   // the LDS table is stored pre-paired (pc_ss_slot)
+            const f32x2 rc01 = r.rs[0].lo, rh01 = r.rs[0].hi, rc23 = r.rs[1].lo, rh23 = r.rs[1].hi;
             const f32x2 sg2 = {sgn, sgn};
             auto group = [&](auto u0_tag, auto u1_tag) __attribute__((always_inline)) {
                 constexpr int U0 = decltype(u0_tag)::value, U1 = decltype(u1_tag)::value, NU = U1 - U0;

@@ -80,8 +80,9 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     const unsigned plane = (unsigned)((size_t)a.H * a.W * a.Cin);
     if constexpr (EPI == 0) {
         for (int i = threadIdx.x; i < 2 * a.Cin; i += 512) {
-            ssl[i] = a.x_ss ? a.x_ss[i] : ((i & 1) ? 0.f : 1.f);
-            ssl[2 * a.Cin + i] = (RES && a.res_ss) ? a.res_ss[i] : ((i & 1) ? 0.f : 1.f);
+            const int j = pc_ss_slot(i);  // pairs as the packed FMAs take them: (s0, s1, t0, t1 | s2, s3, t2, t3) per 4 channels
+            ssl[j] = a.x_ss ? a.x_ss[i] : ((i & 1) ? 0.f : 1.f);
+            ssl[2 * a.Cin + j] = (RES && a.res_ss) ? a.res_ss[i] : ((i & 1) ? 0.f : 1.f);
         }
         __syncthreads();
     }
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         // selected per value, not per pointer: a pointer select would force both books into scratch memory.
         auto issue = [&](bool nx, int s, Regs& r) __attribute__((always_inline)) {
             const int cb = s / KD, kd = s - cb * KD;
-            r.ss[0] = r.ss[1] = r.rs[0] = r.rs[1] = f32x4{1.f, 0.f, 1.f, 0.f};
+            r.ss[0] = r.ss[1] = r.rs[0] = r.rs[1] = f32x4{1.f, 1.f, 0.f, 0.f};
             if constexpr (EPI == 0) {
                 r.ss[0] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4));
                 r.ss[1] = *reinterpret_cast<const f32x4*>(ssl + 2 * (cb * kCB + w4 * 4) + 4);
@@ -398,13 +399,13 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
             const int z = KD == 3 ? min(max(tz + kd - 1, 0), a.N - 1) : 0;   // clamped: an outside slice is zeroed when published
             // uniform 64-bit base + per-lane 32-bit byte offset: the global_load saddr form, no per-lane 64-bit address math
             const size_t base = ((size_t)z * plane + (size_t)(cb * kCB)) * sizeof(float);
-            const char* xb = reinterpret_cast<const char*>(a.x) + base;
-            const char* rb = reinterpret_cast<const char*>(a.res) + base;
+            const __amdgpu_buffer_rsrc_t xb = pc_rsrc(reinterpret_cast<const char*>(a.x) + base);
+            const __amdgpu_buffer_rsrc_t rb = pc_rsrc(reinterpret_cast<const char*>(RES ? a.res : a.x) + base);
 #pragma unroll
             for (int u = 0; u < kPcNPF; ++u) {
                 const unsigned o = nx ? nxt_off[u] : cur_off[u];
-                r.pre[u] = *reinterpret_cast<const f32x4*>(xb + o);
-                if constexpr (RES) r.prer[u] = *reinterpret_cast<const f32x4*>(rb + o);
+                r.pre[u] = pc_bload(xb, o);
+                if constexpr (RES) r.prer[u] = pc_bload(rb, o);
             }
         };
         setup(tl, cur_off, cur_keep, cur_own);
@@ -441,8 +442,8 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                         // (scale, shift) pairs re-paired for the packed FMAs: channels (0,1) and (2,3); identity = (1, 0)
                         asm volatile("" : "+v"(r.ss[0]), "+v"(r.ss[1]));   // re-paired HERE, not behind their loads
                         if constexpr (RES) asm volatile("" : "+v"(r.rs[0]), "+v"(r.rs[1]));
-                        const f32x2 sc01 = {r.ss[0].x, r.ss[0].z}, sh01 = {r.ss[0].y, r.ss[0].w}, sc23 = {r.ss[1].x, r.ss[1].z}, sh23 = {r.ss[1].y, r.ss[1].w};
-                        const f32x2 rc01 = {r.rs[0].x, r.rs[0].z}, rh01 = {r.rs[0].y, r.rs[0].w}, rc23 = {r.rs[1].x, r.rs[1].z}, rh23 = {r.rs[1].y, r.rs[1].w};
+                        const f32x2 sc01 = r.ss[0].lo, sh01 = r.ss[0].hi, sc23 = r.ss[1].lo, sh23 = r.ss[1].hi;   // the LDS table is stored pre-paired (pc_ss_slot)
+                        const f32x2 rc01 = r.rs[0].lo, rh01 = r.rs[0].hi, rc23 = r.rs[1].lo, rh23 = r.rs[1].hi;
                         const bool wmat = MAT && (KD != 3 || kd == 1) && tl.cg == 0;
                         // Breadth-first over the 5 items — all FMAs, then all ReLUs, then all masks, then the stores — and
                         // pinned in that order: beside the consumer's MFMA stream a VALU instruction that has to wait for

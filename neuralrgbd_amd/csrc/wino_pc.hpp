@@ -74,6 +74,27 @@ __device__ __forceinline__ int pc_slot(int xi, int tile, int slot) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// The producers' raw words come in as BUFFER loads: a resource descriptor (uniform base of the stage's slice / channel block,
+// in SGPRs) + the lane's 32-bit byte offset — one instruction per 16-byte word.  As flat-address loads (uniform 64-bit base +
+// zero-extended lane offset) hipcc materialises every address with a v_lshl_add_u64 (+ a v_mov of the zero high half) inside the
+// stage loop: ~10 VALU instructions per unit on SIMDs whose issue slots the matrix pipe needs.  The compiler counts buffer loads in
+// vmcnt like any other load.  num_records = 4 GB - 1: the launchers bound a slice / tensor below that.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pc_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ f32x4 pc_bload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+// Position of element i of a [C][2] (scale, shift) table in the producers' LDS copy: per 4 channels the words are stored
+// (s0, s1, t0, t1 | s2, s3, t2, t3), i.e. as the operand PAIRS of the packed FMAs — a lane's two ds_read_b128 are its
+// (scale pair, shift pair) x 2 with no re-pairing moves (6 v_mov_b32 per unit and stage otherwise).
+__device__ __forceinline__ int pc_ss_slot(int i) {
+    const int c = i >> 1, t = i & 1;
+    return ((c >> 2) << 3) + (((c >> 1) & 1) << 2) + (t << 1) + (c & 1);
+}
+
 // Packed fp32 helpers (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two lanes of a register pair per instruction).  The
 // producers' VALU instructions only get the issue slots the co-resident consumer's MFMA stream leaves (measured: about one
 // per MFMA), so every instruction saved there is stage time saved.  a*s + c with a splat s; s = -1 is the exact c - a.
