@@ -365,13 +365,13 @@ int nrgbd_bias_act_nchw(float* x, const float* bias, float slope, int N, int C, 
  *   batch statistics, running-statistics side effect) for column-major partials [2C][rows]
  */
 int nrgbd_conv_wino_tiles(int N, int H, int W, int dilation);
-/* R-Net form of the same kernel (models/m_submodule.py:18-27 conv2d_leakyRelu where Cin % 32 == 0 and Cout % 64 == 0:
+/* R-Net form of the same kernel (models/m_submodule.py:18-27 conv2d_leakyRelu where Cin % 16 == 0 (>= 32; an odd number of 16-channel stages has its own instantiation) and Cout % 64 == 0:
  * Refine.py:51-56 conv0 / conv0_1): y = leaky_relu(conv3x3(x) + bias, 0.01 if out_lrelu), x [N][H][W][Cin] -> y [N][H][W][Cout] */
 int nrgbd_conv_wino_rnet_f32(const float* x, const float* w_wino, const float* bias, int out_lrelu, float* y,
                              int N, int H, int W, int Cin, int Cout, void* stream);
 /* The same with the R-Net's generalised output addressing (as nrgbd_conv2d_rnet_f32): output column c of a pixel goes to
  * y[pixel * ldy + ycoff + c] for c < cout_valid (ldy = 0: Cout, cout_valid = 0: Cout) — the half- and full-resolution layers
- * (Refine.py:57-70: 96 -> 96 and 67 -> 67 / 64, widths padded to Cin % 32 == 0, Cout % 64 == 0 with zero weights) write into
+ * (Refine.py:57-70: 96 -> 96 and 67 -> 67 / 64, widths padded to Cin % 16 == 0, Cout % 64 == 0 with zero weights) write into
  * 96-wide concat buffers whose padding channels stay zero. */
 int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, const float* bias, int out_lrelu, float* y,
                                 int N, int H, int W, int Cin, int Cout, int ldy, int ycoff, int cout_valid, void* stream);

@@ -784,13 +784,13 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     return NRGBD_OK;
 }
 
-// R-Net form (models/m_submodule.py:18-27 conv2d_leakyRelu at widths with Cin % 32 == 0, Cout % 64 == 0: Refine.py:51-56 conv0,
+// R-Net form (models/m_submodule.py:18-27 conv2d_leakyRelu at widths with Cin % 16 == 0 (>= 32), Cout % 64 == 0: Refine.py:51-56 conv0,
 // conv0_1): 3x3 convolution + bias + LeakyReLU(0.01) in the Winograd domain, no prologue, no statistics
 extern "C" int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, const float* bias, int out_lrelu, float* y, int N,
                                            int H, int W, int Cin, int Cout, int ldy, int ycoff, int cout_valid, void* stream) {
     using namespace nrgbd;
     if (!x || !w_wino || !y) return NRGBD_E_NULL;
-    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;   // >= 2 stages
     if ((long)N * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;
     if (cout_valid < 0 || cout_valid > Cout || ycoff < 0 || (ldy != 0 && ldy < ycoff + (cout_valid ? cout_valid : Cout))) return NRGBD_E_ARG;
     if ((long)N * H * W * (ldy ? ldy : Cout) >= (1L << 32)) return NRGBD_E_SHAPE;   // 32-bit lane offsets into a tile's rows only, but keep it sane
@@ -806,6 +806,14 @@ extern "C" int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, 
     if (ncu <= 0) return NRGBD_E_ARG;
     const int nwg = nt < ncu ? (int)nt : ncu;
     const size_t lds = (size_t)(kPcNBuf * kPcV + 4 * kPcRawWave) * sizeof(float);
+    if ((Cin / kCB) & 1) {   // an odd stage count (the R-Net's 67 -> 80 and 131 -> 144 channel pixels): the register set of a stage = parity of the running count
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, false, true, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((conv_wino_pc_kernel<1, 1, false, true, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
+        NRGBD_CHECK_LAUNCH();
+        return NRGBD_OK;
+    }
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, false, false, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

@@ -771,7 +771,7 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         if cache.get("key") == key:
             return cache["val"]
         pad16 = lambda c: (c + 15) // 16 * 16
-        pad32 = lambda c: (c + 31) // 32 * 32        # pixel width of the concat buffers (a whole number of Winograd stage pairs)
+        pad32 = pad16                                # pixel width of the concat buffers = whole 16-channel Winograd stages (an odd count has its own instantiation)
 
         def slices(cout):
             cp = pad16(cout)
@@ -813,7 +813,7 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
 
         def wino(m):
             """Winograd-domain stream of a conv2d_leakyRelu layer for the persistent kernel's R-Net form, widths padded with zero
-            weights to Cin % 32 == 0 (the buffer it reads) and Cout % 64 == 0; (stream, bias, packed columns, valid columns)."""
+            weights to Cin % 16 == 0 (the buffer it reads) and Cout % 64 == 0; (stream, bias, packed columns, valid columns)."""
             c = m[0] if isinstance(m, nn.Sequential) else m
             w, b = c.weight.detach(), c.bias.detach()
             cin_p, cout_p = pad32(w.shape[1]), (w.shape[0] + 63) // 64 * 64
@@ -842,8 +842,8 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 del cache[k]
             D, C0, C1, C2 = self._widths()
             z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-            p32 = lambda c: (c + 31) // 32 * 32
-            w0, w1, w2 = p32(D + C0), p32(D + C1), p32(D + C2)        # 128, 96, 96 at D = 64
+            p32 = lambda c: (c + 15) // 16 * 16                       # whole 16-channel Winograd stages (_rnet_packed pads its weights to the same widths)
+            w0, w1, w2 = p32(D + C0), p32(D + C1), p32(D + C2)        # 128, 96, 80 at D = 64; 192, 160, 144 at D = 128
             cache[key] = {"x0": z(n, h, w, w0), "a0": z(n, h, w, w0), "b0": z(n, h, w, w0),
                           "c1": z(n, 2 * h, 2 * w, w1), "a1": z(n, 2 * h, 2 * w, w1), "b1": z(n, 2 * h, 2 * w, w1),
                           "c2": z(n, 4 * h, 4 * w, w2), "g2": z(n, 4 * h, 4 * w, w2), "h2": z(n, 4 * h, 4 * w, D)}
