@@ -790,14 +790,15 @@ extern "C" int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, 
                                            int H, int W, int Cin, int Cout, int ldy, int ycoff, int cout_valid, void* stream) {
     using namespace nrgbd;
     if (!x || !w_wino || !y) return NRGBD_E_NULL;
-    if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;   // >= 2 stages
+    const bool half = Cout == 32;               // the HALF form: a 32-column slice (e.g. the 3 columns a 67-wide layer has beyond 64)
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cin % kCB || Cout <= 0 || (Cout % 64 && !half)) return NRGBD_E_SHAPE;   // >= 2 stages
     if ((long)N * H * W * Cin >= (1L << 30)) return NRGBD_E_SHAPE;
     if (cout_valid < 0 || cout_valid > Cout || ycoff < 0 || (ldy != 0 && ldy < ycoff + (cout_valid ? cout_valid : Cout))) return NRGBD_E_ARG;
     if ((long)N * H * W * (ldy ? ldy : Cout) >= (1L << 32)) return NRGBD_E_SHAPE;   // 32-bit lane offsets into a tile's rows only, but keep it sane
     const int rows = nrgbd_conv_wino_tiles(N, H, W, 1);
-    const long nt = (long)rows * (Cout / 64);
-    if (nt >= (1L << 31)) return NRGBD_E_SHAPE;
-    WinoPcArgs a{x, nullptr, nullptr, nullptr, nullptr, w_wino, y, nullptr, 0, 0, N, H, W, Cin, Cout, (int)nt, rows,
+    const long nt = (long)rows * (half ? 1 : Cout / 64);
+    if (nt >= (1L << 30)) return NRGBD_E_SHAPE;
+    WinoPcArgs a{x, nullptr, nullptr, nullptr, nullptr, w_wino, y, nullptr, 0, 0, N, H, W, Cin, Cout, (int)nt, half ? 2 * rows : rows,
                  bias, out_lrelu, ldy, ycoff, cout_valid, 0};
     int dev = 0, ncu = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -806,18 +807,20 @@ extern "C" int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, 
     if (ncu <= 0) return NRGBD_E_ARG;
     const int nwg = nt < ncu ? (int)nt : ncu;
     const size_t lds = (size_t)(kPcNBuf * kPcV + 4 * kPcRawWave) * sizeof(float);
-    if ((Cin / kCB) & 1) {   // an odd stage count (the R-Net's 67 -> 80 and 131 -> 144 channel pixels): the register set of a stage = parity of the running count
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, false, true, 1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((conv_wino_pc_kernel<1, 1, false, true, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
-        NRGBD_CHECK_LAUNCH();
-        return NRGBD_OK;
-    }
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, false, false, 1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv_wino_pc_kernel<1, 1, false, false, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
+#define NRGBD_WINO_RNET_LAUNCH(ODD_, HALF_)                                                                              \
+    do {                                                                                                                 \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, false, ODD_, 1, false, HALF_>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+        if (e != hipSuccess) return (int)e;                                                                              \
+        hipLaunchKernelGGL((conv_wino_pc_kernel<1, 1, false, ODD_, 1, false, HALF_>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a); \
+    } while (0)
+    // an odd stage count (the R-Net's 67 -> 80 and 131 -> 144 channel pixels): the register set of a stage = parity of the running count
+    const bool odd = ((Cin / kCB) & 1) != 0;
+    if (odd && half) NRGBD_WINO_RNET_LAUNCH(true, true);
+    else if (odd) NRGBD_WINO_RNET_LAUNCH(true, false);
+    else if (half) NRGBD_WINO_RNET_LAUNCH(false, true);
+    else NRGBD_WINO_RNET_LAUNCH(false, false);
+#undef NRGBD_WINO_RNET_LAUNCH
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

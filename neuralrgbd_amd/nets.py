@@ -821,6 +821,16 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
             wp[:w.shape[0], :w.shape[1]] = w
             bp = b.new_zeros(cout_p)
             bp[:w.shape[0]] = b
+            extra = w.shape[0] % 64
+            if 0 < extra <= 32 and w.shape[0] > 64:
+                # a few columns beyond a multiple of 64 (67 = 64 + 3, 131 = 128 + 3): the whole groups in one launch, the rest as a
+                # 32-column slice on the kernel's HALF form (its stream: the 64-column one with the upper half zero) instead of a
+                # 64-column group that is 95 % padding
+                full = w.shape[0] - extra
+                tail = wp.new_zeros(64, cin_p, 3, 3)
+                tail[:extra] = wp[full:full + extra]
+                return (ops.conv_wino_pack(wp[:full].contiguous()), bp[:full].contiguous(), full, full,
+                        (ops.conv_wino_pack(tail), bp[full:full + 32].contiguous(), 32, extra, full))
             return (ops.conv_wino_pack(wp.contiguous()), bp.contiguous(), cout_p, w.shape[0])
 
         val = {"conv0": conv(self.conv0), "conv0_1": conv(self.conv0_1), "t0": deconv(self.trans_conv0),
@@ -880,7 +890,11 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
             channel, even after padding 96 / 67 outputs to 128), the direct kernel as the A/B (NRGBD_RNET_WINO=0)."""
             w = pk.get(name + "_w")
             if w is not None:
-                return ops.conv_wino_rnet(x, w[0], w[2], bias=w[1], lrelu=True, out=out, cout_valid=w[3])
+                ops.conv_wino_rnet(x, w[0], w[2], bias=w[1], lrelu=True, out=out, cout_valid=w[3])
+                if len(w) > 4:      # the 32-column tail slice (HALF form) behind the whole 64-column groups
+                    t = w[4]
+                    ops.conv_wino_rnet(x, t[0], t[2], bias=t[1], lrelu=True, out=out, ycoff=t[4], cout_valid=t[3])
+                return out
             return conv(x, pk[name], out)
         x = conv_w(conv_w(x, "conv0", buf["a0"]), "conv0_1", buf["b0"])
         # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..D-1 of the concat buffer; features behind

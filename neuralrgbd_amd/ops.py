@@ -696,7 +696,8 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, run
 
 def conv_wino_rnet(x, w_wino, cout, bias=None, lrelu=True, out=None, ycoff=0, cout_valid=None):
     """R-Net conv2d_leakyRelu block in the Winograd domain: x [N,H,W,Cin] -> leaky_relu(conv3x3(x) + bias).
-    `cout` = columns of the packed weights (% 64); `out` [N,H,W,ldy] may be wider than the layer (a concat buffer): output
+    `cout` = columns of the packed weights (% 64, or 32: the HALF form, whose stream is the 64-column one with the upper half zero);
+    `out` [N,H,W,ldy] may be wider than the layer (a concat buffer): output
     column c < cout_valid of a pixel lands at out[..., ycoff + c], the rest of the pixel is left alone."""
     x = _need(x, "x")
     N, H, W, Cin = x.shape
