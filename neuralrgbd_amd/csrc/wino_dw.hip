@@ -42,6 +42,20 @@ namespace nrgbd {
 constexpr int kDwStashWave = 2 * 8 * 64 * 4;   // floats of one consumer wave's stash: [2 output slices][8 words][64 lanes][4]
 constexpr int kDwMaxCin = 512;                 // (scale, shift) tables of x and res live in LDS: 2 x 2 x Cin floats
 constexpr int kDwNBuf = 2;                     // V buffers (wino_pc.hip: 3; the third one's 32 KB hold the second stash here)
+// SHARED strips (round 4): wino_pc.hip's producer wave p loads the four halo rows 2p .. 2p+3 its tile row needs into a PRIVATE strip
+// — 16 rows for a 10-row halo, i.e. every interior row is loaded, activated and published twice.  Here the 10 x 18 halo of a unit is
+// split once over the 256 producer lanes (3 words per lane instead of 5) into a strip all four waves share, published one stage
+// AHEAD: iteration i publishes stage i into strip[i & 1] and transforms stage i - 1 from strip[(i - 1) & 1] (complete since the
+// stage barrier), so the only synchronisation is the barrier the stage has anyway (one more at the start).  Per stage and
+// producer wave: 6 instead of 10 loads, 18 instead of 30 packed activation / combine FMAs, 9 instead of 15 strip accesses.
+#ifndef NRGBD_DW_SHARED
+#define NRGBD_DW_SHARED 1   // 0: the private-strip producers (experimental A/B builds only)
+#endif
+constexpr int kDwShRows = kPcTH + 2;                       // halo rows of a tile
+constexpr int kDwShStrip = kDwShRows * kPcRawW * kCB;      // floats of one shared strip: [10 rows][20 pixels][16] = 12.8 KB
+constexpr int kDwShItems = kDwShRows * 18 * 4;             // (row, column, 16-byte word) items of a unit: 720
+constexpr int kDwNPF = NRGBD_DW_SHARED ? 3 : kPcNPF;       // items per producer lane and unit
+constexpr int kDwStrips = NRGBD_DW_SHARED ? 2 * kDwShStrip : 4 * kPcRawWave;   // floats of the strip region
 
 struct DwTile { int z0, y0, x0, cg, row0; };   // row0: statistics row of slice z0 (slice z0 + 1: row0 + 1)
 
@@ -96,8 +110,8 @@ template <bool RES, bool MAT, bool RSID, bool IDENT = false, bool CLAMP = false>
 __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Vb = lds;                                   // [2][16 xi][32 tiles][16]
-    float* rawb = lds + kDwNBuf * kPcV;                // [4 producer waves][4 rows][20 pixels][16]
-    float* stashb = rawb + 4 * kPcRawWave;             // [4 consumer waves][2 slices][8][64][4]
+    float* rawb = lds + kDwNBuf * kPcV;                // SHARED: [2][10 rows][20 pixels][16]; else [4 producer waves][4 rows][20 pixels][16]
+    float* stashb = rawb + kDwStrips;                  // [4 consumer waves][2 slices][8][64][4]
     float* ssl = stashb + 4 * kDwStashWave;            // [Cin][2] (scale, shift) of x, then [Cin][2] of res
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -151,6 +165,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
         f32x4 Bn[kPcNB], An[2][2];
 #pragma unroll
         for (int b = 0; b < kPcBD; ++b) Bn[b] = wt[b * 256];
+        if constexpr (NRGBD_DW_SHARED != 0) __syncthreads();   // the producers publish stage 0 (transformed one iteration later)
         __syncthreads();                               // producers finish stage 0
         int buf = 0;
         An[0][0] = *reinterpret_cast<const f32x4*>(Vb + a0);
@@ -303,42 +318,51 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
     } else {
         // =========================================== producer: tile row pw (8 Winograd tiles) ===========================
         const int pw = wv;
-        float* raw = rawb + pw * kPcRawWave;
+        constexpr bool SH = NRGBD_DW_SHARED != 0;
+        constexpr int kItems = SH ? kDwShItems : kPcItems;
+        float* raw = SH ? rawb : rawb + pw * kPcRawWave;   // SH: the strip this iteration PUBLISHES into (set per iteration)
+        const float* rawT = raw;                            // ... and the one it TRANSFORMS from
         const int w4 = lane & 3;
-        auto item_rr = [&](int u) { return ((lane + 64 * u) >> 2) / 18; };
-        auto item_cp = [&](int u) { const int pi = (lane + 64 * u) >> 2; return pi - (pi / 18) * 18; };
+        // item u of this lane: word (item & 3) of halo pixel item >> 2, pixels in (row, de-interleaved column) order.
+        // SH: item = 192 pw + lane + 64 u over the whole 10-row halo; else lane + 64 u over the wave's own 4 rows
+        auto item_id = [&](int u) { return (SH ? 192 * pw : 0) + lane + 64 * u; };
+        auto item_rr = [&](int u) { return (item_id(u) >> 2) / 18; };
+        auto item_cp = [&](int u) { const int pi = item_id(u) >> 2; return pi - (pi / 18) * 18; };
         auto item_col = [&](int u) { const int cp = item_cp(u); return cp < 9 ? 2 * cp : 2 * cp - 17; };
-        int wr_off[kPcNPF];
+        int wr_off[kDwNPF];
 #pragma unroll
-        for (int u = 0; u < kPcNPF; ++u) {
-            const int item = lane + 64 * u, e = (item - kPcItems) >> 2;
-            wr_off[u] = item < kPcItems ? (item_rr(u) * kPcRawW + item_cp(u)) * kCB + w4 * 4
-                                        : ((e >> 1) * kPcRawW + 18 + (e & 1)) * kCB + w4 * 4;
+        for (int u = 0; u < kDwNPF; ++u) {
+            const int item = item_id(u), e = (item - kItems) >> 2;   // lanes without an item write a zero into a pad pixel (columns 18, 19)
+            wr_off[u] = item < kItems ? (item_rr(u) * kPcRawW + item_cp(u)) * kCB + w4 * 4
+                                      : ((e >> 1) * kPcRawW + 18 + (e & 1)) * kCB + w4 * 4;
         }
         const int tword = lane & 3, txl = ((lane >> 5) << 2) | ((lane >> 2) & 3), thalf = (lane >> 4) & 1;
         const int ttile = pw * 8 + txl;
-        const int rdc = txl * kCB + tword * 4;
+        const int rdc = txl * kCB + tword * 4 + (SH ? 2 * pw * kPcRawW * kCB : 0);   // SH: the tile row's halo rows start at strip row 2 pw
         const int rdR0 = (thalf ? 2 : 0) * kPcRawW * kCB + rdc, rdR1 = (thalf ? 1 : 2) * kPcRawW * kCB + rdc,
                   rdR2 = (thalf ? 3 : 1) * kPcRawW * kCB + rdc;
         const float sg = thalf ? -1.f : 1.f;
         float m1 = -1.f;
         asm volatile("" : "+v"(m1));
 
-        unsigned cur_off[kPcNPF], cur_own = 0, nxt_off[kPcNPF], nxt_own = 0;   // BYTE offsets inside a slice
-        float cur_keep[kPcNPF], nxt_keep[kPcNPF];
-        auto setup = [&](const DwTile& tt, unsigned (&b_off)[kPcNPF], float (&b_keep)[kPcNPF], unsigned& b_own) __attribute__((always_inline)) {
+        unsigned cur_off[kDwNPF], cur_own = 0, nxt_off[kDwNPF], nxt_own = 0;   // BYTE offsets inside a slice
+        float cur_keep[kDwNPF], nxt_keep[kDwNPF];
+        auto setup = [&](const DwTile& tt, unsigned (&b_off)[kDwNPF], float (&b_keep)[kDwNPF], unsigned& b_own) __attribute__((always_inline)) {
             b_own = 0;
 #pragma unroll
-            for (int u = 0; u < kPcNPF; ++u) {
-                const int rr = item_rr(u), hy = 2 * pw + rr, hx = item_col(u);
+            for (int u = 0; u < kDwNPF; ++u) {
+                const int rr = item_rr(u), hy = SH ? rr : 2 * pw + rr, hx = item_col(u);
                 const int gy = tt.y0 + hy - 1, gx = tt.x0 + hx - 1;
-                const bool in = (lane + 64 * u) < kPcItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const bool in = item_id(u) < kItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 b_off[u] = 4u * (in ? (unsigned)(((size_t)gy * a.W + gx) * a.Cin + w4 * 4) : (unsigned)(w4 * 4));
                 b_keep[u] = in ? 1.f : 0.f;
-                if (in && (rr == 1 || rr == 2) && hx >= 1 && hx <= kPcTW) b_own |= 1u << u;
+                // the materialised input is written once per pixel: SH: every halo pixel has ONE loader, it owns the tile's own 8 x 16;
+                // else the wave whose strip rows 1, 2 are the pixel's tile row
+                const bool mine = SH ? (hy >= 1 && hy <= kPcTH) : (rr == 1 || rr == 2);
+                if (in && mine && hx >= 1 && hx <= kPcTW) b_own |= 1u << u;
             }
         };
-        struct Regs { f32x4 pre[kPcNPF]; f32x4 prer[RES ? kPcNPF : 1]; f32x4 ss[2]; f32x4 rs[2]; };
+        struct Regs { f32x4 pre[kDwNPF]; f32x4 prer[RES ? kDwNPF : 1]; f32x4 ss[2]; f32x4 rs[2]; };
         DwTile tl = dw_decode(first, a), tn = tl;
         // raw words of one unit = (slice zrel of stage s, channel block of stage s) -> registers
         auto issue = [&](bool nx, int t, int cb, bool unitB, Regs& r) __attribute__((always_inline)) {
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
             const __amdgpu_buffer_rsrc_t xb = pc_rsrc(reinterpret_cast<const char*>(a.x) + base);
             const __amdgpu_buffer_rsrc_t rb = pc_rsrc(reinterpret_cast<const char*>(RES ? a.res : a.x) + base);
 #pragma unroll
-            for (int u = 0; u < kPcNPF; ++u) {
+            for (int u = 0; u < kDwNPF; ++u) {
                 const unsigned o = nx ? nxt_off[u] : cur_off[u];
                 r.pre[u] = pc_bload(xb, o);
                 if constexpr (RES) r.prer[u] = pc_bload(rb, o);
@@ -461,13 +485,38 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                     *reinterpret_cast<f32x4*>(raw + wr_off[u]) = v;
                 }
             };
-            if constexpr (RES) {
+            if constexpr (RES && kDwNPF > 3) {
                 group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-                group(std::integral_constant<int, 3>{}, std::integral_constant<int, kPcNPF>{});
+                group(std::integral_constant<int, 3>{}, std::integral_constant<int, kDwNPF>{});
             } else {
-                group(std::integral_constant<int, 0>{}, std::integral_constant<int, kPcNPF>{});
+                group(std::integral_constant<int, 0>{}, std::integral_constant<int, kDwNPF>{});
             }
         };
+
+        // plane transform B^T d B of this lane's (tile, word): rows (2 of the 4 xi_y), then columns; strip rawT -> V[qbuf]
+        auto transform = [&]() __attribute__((always_inline)) {
+            f32x4 ya[4], yb[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int co = ((cc & 1) * 9 + (cc >> 1)) * kCB;
+                const f32x4 R0 = *reinterpret_cast<const f32x4*>(rawT + rdR0 + co);
+                const f32x4 R1 = *reinterpret_cast<const f32x4*>(rawT + rdR1 + co);
+                const f32x4 R2 = *reinterpret_cast<const f32x4*>(rawT + rdR2 + co);
+                ya[cc] = pk_fma_s(R1, m1, R0);
+                yb[cc] = pk_fma_s(R2, sg, R1);
+            }
+            float* Vq = Vb + qbuf * kPcV;
+            const int xa = (2 * thalf) * 4, xb = (2 * thalf + 1) * 4;
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 0, ttile, tword)) = pk_fma_s(ya[2], m1, ya[0]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 1, ttile, tword)) = pk_add(ya[1], ya[2]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 2, ttile, tword)) = pk_fma_s(ya[1], m1, ya[2]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 3, ttile, tword)) = pk_fma_s(ya[3], m1, ya[1]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 0, ttile, tword)) = pk_fma_s(yb[2], m1, yb[0]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 1, ttile, tword)) = pk_add(yb[1], yb[2]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 2, ttile, tword)) = pk_fma_s(yb[1], m1, yb[2]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 3, ttile, tword)) = pk_fma_s(yb[3], m1, yb[1]);
+        };
+        int gi = 0;                            // iterations so far (SH: strip parity; the transform lags one iteration)
 
         for (int it = 0; it < count; ++it) {
             has_next = it + 1 < count;
@@ -477,6 +526,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
             for (int s = 0; s < NS; ++s) {
                 // the book of the next tile is needed by the refills of the tile's last stage
                 if (s == NS - 1 && has_next) { tn = dw_decode(first + (it + 1) * step, a); setup(tn, nxt_off, nxt_keep, nxt_own); }
+                if constexpr (SH) { raw = rawb + (gi & 1) * kDwShStrip; rawT = rawb + ((gi & 1) ^ 1) * kDwShStrip; }
                 const int zA = tl.z0 + dw_zA(t), zB = tl.z0 + dw_zB(t);
                 const bool zinA = zA >= 0, zinB = zB < a.N;       // zA <= z0 + 1 < N and zB >= z0 >= 0 always hold
                 const bool wmat = MAT && t == 1 && tl.cg == 0;    // phase 1 publishes slices z0 (unit A) and z0 + 1 (unit B)
@@ -489,7 +539,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                     // refill of set A issued just before it.  So BOTH sets are waited for here, at the one point of the stage where
                     // nothing else is in flight, and passed through an opaque asm: later uses no longer depend on the loads.
 #pragma unroll
-                    for (int u = 0; u < kPcNPF; ++u) {
+                    for (int u = 0; u < kDwNPF; ++u) {
                         asm volatile("" : "+v"(setA.pre[u]), "+v"(setB.pre[u]));
                         if constexpr (RES) asm volatile("" : "+v"(setA.prer[u]), "+v"(setB.prer[u]));
                     }
@@ -500,7 +550,7 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                 if (abl & (2 | 8)) {
                 } else if (!zinA) {
 #pragma unroll
-                    for (int u = 0; u < kPcNPF; ++u) *reinterpret_cast<f32x4*>(raw + wr_off[u]) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int u = 0; u < kDwNPF; ++u) *reinterpret_cast<f32x4*>(raw + wr_off[u]) = f32x4{0.f, 0.f, 0.f, 0.f};
                 } else {
                     if (interior) publish(std::false_type{}, std::true_type{}, setA, zA, cbe, wmat, 1.f);
                     else publish(std::false_type{}, std::false_type{}, setA, zA, cbe, wmat, 1.f);
@@ -514,38 +564,23 @@ __global__ __launch_bounds__(512) void conv_wino_dw_kernel(const WinoPcArgs a) {
                     else publish(std::true_type{}, std::false_type{}, setB, zB, cbe, wmat, t == 1 ? 1.f : -1.f);
                 }
                 if (!(abl & (2 | 32))) issue(nx && has_next, tnx, cbne, true, setB);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // (3) plane transform B^T d B of this lane's (tile, word): rows (2 of the 4 xi_y), then columns
-                if (!(abl & (2 | 4))) {
-                    f32x4 ya[4], yb[4];
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const int co = ((cc & 1) * 9 + (cc >> 1)) * kCB;
-                        const f32x4 R0 = *reinterpret_cast<const f32x4*>(raw + rdR0 + co);
-                        const f32x4 R1 = *reinterpret_cast<const f32x4*>(raw + rdR1 + co);
-                        const f32x4 R2 = *reinterpret_cast<const f32x4*>(raw + rdR2 + co);
-                        ya[cc] = pk_fma_s(R1, m1, R0);
-                        yb[cc] = pk_fma_s(R2, sg, R1);
-                    }
-                    float* Vq = Vb + qbuf * kPcV;
-                    const int xa = (2 * thalf) * 4, xb = (2 * thalf + 1) * 4;
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 0, ttile, tword)) = pk_fma_s(ya[2], m1, ya[0]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 1, ttile, tword)) = pk_add(ya[1], ya[2]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 2, ttile, tword)) = pk_fma_s(ya[1], m1, ya[2]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 3, ttile, tword)) = pk_fma_s(ya[3], m1, ya[1]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 0, ttile, tword)) = pk_fma_s(yb[2], m1, yb[0]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 1, ttile, tword)) = pk_add(yb[1], yb[2]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 2, ttile, tword)) = pk_fma_s(yb[1], m1, yb[2]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 3, ttile, tword)) = pk_fma_s(yb[3], m1, yb[1]);
-                }
+                if constexpr (!SH) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // private strip: the transform reads what this wave just wrote
+                // (3) plane transform B^T d B of this lane's (tile, word) — SH: of the stage published one iteration ago
+                if (!(abl & (2 | 4)) && (!SH || gi > 0)) transform();
                 __syncthreads();
-                qbuf ^= 1;
+                if (!SH || gi > 0) qbuf ^= 1;
+                ++gi;
                 if (++cb == ncb) { cb = 0; ++t; }
             }
             tl = tn;
 #pragma unroll
-            for (int u = 0; u < kPcNPF; ++u) { cur_off[u] = nxt_off[u]; cur_keep[u] = nxt_keep[u]; }
+            for (int u = 0; u < kDwNPF; ++u) { cur_off[u] = nxt_off[u]; cur_keep[u] = nxt_keep[u]; }
             cur_own = nxt_own;
+        }
+        if constexpr (SH) {                    // the last published stage
+            rawT = rawb + ((gi & 1) ^ 1) * kDwShStrip;
+            transform();
+            __syncthreads();
         }
         __syncthreads();                       // the consumers' last stage
     }
@@ -643,7 +678,7 @@ static int conv_wino_dw_launch(const float* x, const float* x_ss, int x_relu, co
     if (e != hipSuccess) return (int)e;
     if (ncu <= 0) return NRGBD_E_ARG;
     const int nwg = nt < ncu ? (int)nt : ncu;   // persistent: one workgroup per CU
-    const size_t lds = (size_t)(kDwNBuf * kPcV + 4 * kPcRawWave + 4 * kDwStashWave + 4 * Cin) * sizeof(float);   // 64 + 20 + 64 KB + tables
+    const size_t lds = (size_t)(kDwNBuf * kPcV + kDwStrips + 4 * kDwStashWave + 4 * Cin) * sizeof(float);   // 64 + 25.6 (20) + 64 KB + tables
     hipStream_t st = (hipStream_t)stream;
 #define NRGBD_WINO_DW_LAUNCH(RES_, MAT_, RSID_)                                                                               \
     do {                                                                                                                      \
