@@ -49,8 +49,8 @@ template <int KD, int DIL, bool RES, bool ODD = false, int EPI = 0, bool MAT = f
 __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Vb = lds;                           // [3][16 xi][32 tiles][16]
-    float* rawb = lds + kPcNBuf * kPcV;        // [4 producer waves][4 rows][20 pixels][16]
-    float* ssl = rawb + 4 * kPcRawWave;        // [Cin][2] (scale, shift) of x, then [Cin][2] of res (identity where null)
+    float* rawb = lds + kPcNBuf * kPcV;        // SHARED: [2][10 rows][20 pixels][16]; else [4 producer waves][4 rows][20 pixels][16]
+    float* ssl = rawb + kPcStrips;             // [Cin][2] (scale, shift) of x, then [Cin][2] of res (identity where null)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                                                // HALF: An[pair & 3][point of the pair], two PAIRS ahead
 #pragma unroll
         for (int b = 0; b < BD; ++b) Bn[b] = wt[b * 256];
+        if constexpr (NRGBD_PC_SHARED != 0) __syncthreads();   // the producers publish stage 0 (transformed one iteration later)
         __syncthreads();                       // producers finish stage 0
         __syncthreads();                       // ... and stage 1
         if constexpr (HALF) {
@@ -325,22 +326,27 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
     } else {
         // =========================================== producer: tile row pw (8 Winograd tiles) ===========================
         const int pw = wv;
-        float* raw = rawb + pw * kPcRawWave;
+        constexpr bool SH = NRGBD_PC_SHARED != 0;
+        constexpr int kItems = SH ? kPcShItems : kPcItems;
+        float* raw = SH ? rawb : rawb + pw * kPcRawWave;   // SH: the strip this iteration PUBLISHES into (set per iteration)
+        const float* rawT = raw;                            // ... and the one it TRANSFORMS from
         const int w4 = lane & 3;
         // load / publish items: item = lane + 64u -> strip pixel pi = item >> 2 in (row, de-interleaved column) order
         // item u of this lane -> strip row, image-order column and strip offset (recomputed where needed: a few integer
         // operations instead of 15 live registers)
-        auto item_rr = [&](int u) { return ((lane + 64 * u) >> 2) / 18; };
-        auto item_cp = [&](int u) { const int pi = (lane + 64 * u) >> 2; return pi - (pi / 18) * 18; };
+        // SH: item = 192 pw + lane + 64 u over the whole 10-row halo (every halo word has ONE loader)
+        auto item_id = [&](int u) { return (SH ? 192 * pw : 0) + lane + 64 * u; };
+        auto item_rr = [&](int u) { return (item_id(u) >> 2) / 18; };
+        auto item_cp = [&](int u) { const int pi = item_id(u) >> 2; return pi - (pi / 18) * 18; };
         auto item_col = [&](int u) { const int cp = item_cp(u); return cp < 9 ? 2 * cp : 2 * cp - 17; };   // even columns first, then odd
         // strip offset an item is published at; the 32 lanes without a fifth item (288 = 4.5 x 64) write a zero into the
         // strip's 8 pad pixels (columns 18, 19 of the 20-pixel row pitch) so that the publish loop has no per-lane branch
-        int wr_off[kPcNPF];
+        int wr_off[kPcNPFx];
 #pragma unroll
-        for (int u = 0; u < kPcNPF; ++u) {
-            const int item = lane + 64 * u, e = (item - kPcItems) >> 2;
-            wr_off[u] = item < kPcItems ? (item_rr(u) * kPcRawW + item_cp(u)) * kCB + w4 * 4
-                                        : ((e >> 1) * kPcRawW + 18 + (e & 1)) * kCB + w4 * 4;
+        for (int u = 0; u < kPcNPFx; ++u) {
+            const int item = item_id(u), e = (item - kItems) >> 2;
+            wr_off[u] = item < kItems ? (item_rr(u) * kPcRawW + item_cp(u)) * kCB + w4 * 4
+                                      : ((e >> 1) * kPcRawW + 18 + (e & 1)) * kCB + w4 * 4;
         }
         // transform item of this lane: (tile of the row, 16-byte word, half of the xi rows); 16 consecutive lanes = 4 tiles x 4
         // words: conflict-free strip reads (the four tiles' columns are consecutive strip pixels) and V writes
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         //   half 0 (xi_y 0, 1): R = strip rows (0, 2, 1), sg = +1 ->  d0 - d2,  d2 + d1
         //   half 1 (xi_y 2, 3): R = strip rows (2, 1, 3), sg = -1 ->  d2 - d1,  d1 - d3
         // (strip columns of tile txl: cc = 0 at column pixel txl, cc = 1: +9 pixels, cc = 2: +1, cc = 3: +10)
-        const int rdc = txl * kCB + tword * 4;
+        const int rdc = txl * kCB + tword * 4 + (SH ? 2 * pw * kPcRawW * kCB : 0);   // SH: the tile row's halo rows start at strip row 2 pw
         const int rdR0 = (thalf ? 2 : 0) * kPcRawW * kCB + rdc, rdR1 = (thalf ? 1 : 2) * kPcRawW * kCB + rdc,
                   rdR2 = (thalf ? 3 : 1) * kPcRawW * kCB + rdc;
         const float sg = thalf ? -1.f : 1.f;
@@ -361,26 +367,27 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
         // Per-tile bookkeeping of this lane's items: in-plane element offset (a harmless in-tensor offset when outside),
         // inside-the-image bits, owner bits (materialise target).  Two books: the raw words run TWO stages ahead of their
         // use, so the last two stages of a tile already load the next tile's words.
-        unsigned cur_off[kPcNPF], cur_own = 0, nxt_off[kPcNPF], nxt_own = 0;   // BYTE offsets
-        float cur_keep[kPcNPF], nxt_keep[kPcNPF];                               // 1 inside the image, 0 outside (zero padding)
-        auto setup = [&](const PcTile& t, unsigned (&b_off)[kPcNPF], float (&b_keep)[kPcNPF], unsigned& b_own) __attribute__((always_inline)) {
+        unsigned cur_off[kPcNPFx], cur_own = 0, nxt_off[kPcNPFx], nxt_own = 0;   // BYTE offsets
+        float cur_keep[kPcNPFx], nxt_keep[kPcNPFx];                               // 1 inside the image, 0 outside (zero padding)
+        auto setup = [&](const PcTile& t, unsigned (&b_off)[kPcNPFx], float (&b_keep)[kPcNPFx], unsigned& b_own) __attribute__((always_inline)) {
             b_own = 0;
 #pragma unroll
-            for (int u = 0; u < kPcNPF; ++u) {
-                const int rr = item_rr(u), hy = 2 * pw + rr, hx = item_col(u);
+            for (int u = 0; u < kPcNPFx; ++u) {
+                const int rr = item_rr(u), hy = SH ? rr : 2 * pw + rr, hx = item_col(u);
                 const int gy = t.y0 + t.py + DIL * (hy - 1), gx = t.x0 + t.px + DIL * (hx - 1);
-                const bool in = (lane + 64 * u) < kPcItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const bool in = item_id(u) < kItems && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 const unsigned n2 = KD == 3 ? 0u : (unsigned)t.n;
                 b_off[u] = 4u * (in ? (unsigned)((((size_t)n2 * a.H + gy) * a.W + gx) * a.Cin + w4 * 4) : (unsigned)(w4 * 4));
                 b_keep[u] = in ? 1.f : 0.f;
-                if (in && (rr == 1 || rr == 2) && hx >= 1 && hx <= kPcTW) b_own |= 1u << u;
+                const bool mine = SH ? (hy >= 1 && hy <= kPcTH) : (rr == 1 || rr == 2);   // SH: the one loader of a pixel of the tile's own 8 x 16
+                if (in && mine && hx >= 1 && hx <= kPcTW) b_own |= 1u << u;
             }
         };
         // One register set per stage parity: raw words (+ residual words) and the (scale, shift) of the stage's 4 channels.
         // A set is refilled for stage s+2 right after stage s has published it, so a load has two stage periods to land:
         // with a single set the chain load -> publish -> next load made the producers' period = memory latency + publish
         // (measured 2.8 us against the consumers' 2.0 us of MFMAs), i.e. the matrix pipe waited for the producers.
-        struct Regs { f32x4 pre[kPcNPF]; f32x4 prer[RES ? kPcNPF : 1]; f32x4 ss[2]; f32x4 rs[2]; };
+        struct Regs { f32x4 pre[kPcNPFx]; f32x4 prer[RES ? kPcNPFx : 1]; f32x4 ss[2]; f32x4 rs[2]; };
         PcTile tl = pc_decode<KD, DIL>(first, a), tn = tl;
         // raw words of stage s -> registers; nx: the stage belongs to the NEXT tile (book nxt_*, tile tn).  The book is
         // selected per value, not per pointer: a pointer select would force both books into scratch memory.
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
             const __amdgpu_buffer_rsrc_t xb = pc_rsrc(reinterpret_cast<const char*>(a.x) + base);
             const __amdgpu_buffer_rsrc_t rb = pc_rsrc(reinterpret_cast<const char*>(RES ? a.res : a.x) + base);
 #pragma unroll
-            for (int u = 0; u < kPcNPF; ++u) {
+            for (int u = 0; u < kPcNPFx; ++u) {
                 const unsigned o = nx ? nxt_off[u] : cur_off[u];
                 r.pre[u] = pc_bload(xb, o);
                 if constexpr (RES) r.prer[u] = pc_bload(rb, o);
@@ -418,6 +425,30 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
 #endif
         bool has_next = false;
         bool interior = false;   // the current tile's whole halo lies inside the image (set per tile below)
+        int gi = 0;              // iterations so far (SH: strip parity; the transform lags one iteration)
+        // (3) input transform B^T d B of this lane's (tile, word): rows (2 of the 4 xi_y), then columns; strip rawT -> V[qbuf]
+        auto transform = [&]() __attribute__((always_inline)) {
+            f32x4 ya[4], yb[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int co = ((cc & 1) * 9 + (cc >> 1)) * kCB;
+                const f32x4 R0 = *reinterpret_cast<const f32x4*>(rawT + rdR0 + co);
+                const f32x4 R1 = *reinterpret_cast<const f32x4*>(rawT + rdR1 + co);
+                const f32x4 R2 = *reinterpret_cast<const f32x4*>(rawT + rdR2 + co);
+                ya[cc] = pk_fma_s(R1, m1, R0);   // R0 - R1
+                yb[cc] = pk_fma_s(R2, sg, R1);     // R1 +- R2
+            }
+            float* Vq = Vb + qbuf * kPcV;
+            const int xa = (2 * thalf) * 4, xb = (2 * thalf + 1) * 4;
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 0, ttile, tword)) = pk_fma_s(ya[2], m1, ya[0]);   // y0 - y2
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 1, ttile, tword)) = pk_add(ya[1], ya[2]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 2, ttile, tword)) = pk_fma_s(ya[1], m1, ya[2]);   // y2 - y1
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 3, ttile, tword)) = pk_fma_s(ya[3], m1, ya[1]);   // y1 - y3
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 0, ttile, tword)) = pk_fma_s(yb[2], m1, yb[0]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 1, ttile, tword)) = pk_add(yb[1], yb[2]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 2, ttile, tword)) = pk_fma_s(yb[1], m1, yb[2]);
+            *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 3, ttile, tword)) = pk_fma_s(yb[3], m1, yb[1]);
+        };
         // one stage: publish set r (stage s of the current tile), refill it for stage s+2, transform, barrier
         auto stage = [&](int s, Regs& r) __attribute__((always_inline)) {
 #ifdef NRGBD_DEV
@@ -427,6 +458,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
             const int cb = s / KD, kd = s - cb * KD;
             const int z = KD == 3 ? tl.n + kd - 1 : tl.n;
             const bool zin = KD != 3 || (z >= 0 && z < a.N);
+            if constexpr (SH) { raw = rawb + (gi & 1) * kPcShStrip; rawT = rawb + ((gi & 1) ^ 1) * kPcShStrip; }
             if (!(abl & 2)) {
 #ifdef NRGBD_DEV
                 if (abl & 64) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -437,7 +469,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                     // 0.74 us alone and 2.0 us beside the consumers' MFMA stream — longer than the MFMAs it has to stay ahead of.
                     if (!zin) {   // a depth tap outside the volume: the whole slice is zero padding
 #pragma unroll
-                        for (int u = 0; u < kPcNPF; ++u) *reinterpret_cast<f32x4*>(raw + wr_off[u]) = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int u = 0; u < kPcNPFx; ++u) *reinterpret_cast<f32x4*>(raw + wr_off[u]) = f32x4{0.f, 0.f, 0.f, 0.f};
                     } else {
                         // (scale, shift) pairs re-paired for the packed FMAs: channels (0,1) and (2,3); identity = (1, 0)
                         asm volatile("" : "+v"(r.ss[0]), "+v"(r.ss[1]));   // re-paired HERE, not behind their loads
@@ -512,17 +544,17 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
                         // a tile whose halo lies inside the image needs no zero-padding mask (its pad pixels of the strip — the
                         // fifth item of lanes 32..63 — are never read by the transform)
                         if (interior) {
-                            if constexpr (RES) {
+                            if constexpr (RES && kPcNPFx > 3) {
                                 group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, std::true_type{});
-                                group(std::integral_constant<int, 3>{}, std::integral_constant<int, kPcNPF>{}, std::true_type{});
+                                group(std::integral_constant<int, 3>{}, std::integral_constant<int, kPcNPFx>{}, std::true_type{});
                             } else {
-                                group(std::integral_constant<int, 0>{}, std::integral_constant<int, kPcNPF>{}, std::true_type{});
+                                group(std::integral_constant<int, 0>{}, std::integral_constant<int, kPcNPFx>{}, std::true_type{});
                             }
-                        } else if constexpr (RES) {
+                        } else if constexpr (RES && kPcNPFx > 3) {
                             group(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, std::false_type{});
-                            group(std::integral_constant<int, 3>{}, std::integral_constant<int, kPcNPF>{}, std::false_type{});
+                            group(std::integral_constant<int, 3>{}, std::integral_constant<int, kPcNPFx>{}, std::false_type{});
                         } else {
-                            group(std::integral_constant<int, 0>{}, std::integral_constant<int, kPcNPF>{}, std::false_type{});
+                            group(std::integral_constant<int, 0>{}, std::integral_constant<int, kPcNPFx>{}, std::false_type{});
                         }
                     }
                 }
@@ -538,33 +570,12 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
 #ifdef NRGBD_DEV
                 const long q2 = wall_clock64();
 #endif
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the strip is wave-private: in-order LDS, no barrier
+                if constexpr (!SH) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the strip is wave-private: in-order LDS, no barrier
 #ifdef NRGBD_DEV
                 p1 = wall_clock64();
                 t_q0 += q0 - p0; t_q1 += q1 - q0; t_q2 += q2 - q1;
 #endif
-                if (!(abl & 4)) {   // (3) input transform B^T d B of this lane's (tile, word): rows (2 of the 4 xi_y), then columns
-                    f32x4 ya[4], yb[4];
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const int co = ((cc & 1) * 9 + (cc >> 1)) * kCB;
-                        const f32x4 R0 = *reinterpret_cast<const f32x4*>(raw + rdR0 + co);
-                        const f32x4 R1 = *reinterpret_cast<const f32x4*>(raw + rdR1 + co);
-                        const f32x4 R2 = *reinterpret_cast<const f32x4*>(raw + rdR2 + co);
-                        ya[cc] = pk_fma_s(R1, m1, R0);   // R0 - R1
-                        yb[cc] = pk_fma_s(R2, sg, R1);     // R1 +- R2
-                    }
-                    float* Vq = Vb + qbuf * kPcV;
-                    const int xa = (2 * thalf) * 4, xb = (2 * thalf + 1) * 4;
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 0, ttile, tword)) = pk_fma_s(ya[2], m1, ya[0]);   // y0 - y2
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 1, ttile, tword)) = pk_add(ya[1], ya[2]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 2, ttile, tword)) = pk_fma_s(ya[1], m1, ya[2]);   // y2 - y1
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xa + 3, ttile, tword)) = pk_fma_s(ya[3], m1, ya[1]);   // y1 - y3
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 0, ttile, tword)) = pk_fma_s(yb[2], m1, yb[0]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 1, ttile, tword)) = pk_add(yb[1], yb[2]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 2, ttile, tword)) = pk_fma_s(yb[1], m1, yb[2]);
-                    *reinterpret_cast<f32x4*>(Vq + pc_slot(xb + 3, ttile, tword)) = pk_fma_s(yb[3], m1, yb[1]);
-                }
+                if (!(abl & 4) && (!SH || gi > 0)) transform();   // SH: of the stage published one iteration ago
             }
 #ifdef NRGBD_DEV
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -574,7 +585,8 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
 #ifdef NRGBD_DEV
             t_pub += p1 - p0; t_tr += p2 - p1; t_pbar += wall_clock64() - p2;
 #endif
-            qbuf = qbuf == kPcNBuf - 1 ? 0 : qbuf + 1;
+            if (!SH || gi > 0) qbuf = qbuf == kPcNBuf - 1 ? 0 : qbuf + 1;
+            ++gi;
         };
         for (int it = 0; it < count; ++it) {
             has_next = it + 1 < count;
@@ -595,8 +607,13 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
             }
             tl = tn;
 #pragma unroll
-            for (int u = 0; u < kPcNPF; ++u) { cur_off[u] = nxt_off[u]; cur_keep[u] = nxt_keep[u]; }
+            for (int u = 0; u < kPcNPFx; ++u) { cur_off[u] = nxt_off[u]; cur_keep[u] = nxt_keep[u]; }
             cur_own = nxt_own;
+        }
+        if constexpr (SH) {                    // the last published stage
+            rawT = rawb + ((gi & 1) ^ 1) * kPcShStrip;
+            if (!(abl & (2 | 4))) transform();
+            __syncthreads();
         }
         __syncthreads();                       // the consumers' last two stages
         __syncthreads();
@@ -739,7 +756,7 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     if (e != hipSuccess) return (int)e;
     if (ncu <= 0) return NRGBD_E_ARG;
     const int nwg = nt < ncu ? (int)nt : ncu;   // persistent: one workgroup per CU
-    const size_t lds = (size_t)(kPcNBuf * kPcV + 4 * kPcRawWave + 4 * Cin) * sizeof(float);   // 96 KB V + 20 KB strips + (scale, shift) tables
+    const size_t lds = (size_t)(kPcNBuf * kPcV + kPcStrips + 4 * Cin) * sizeof(float);   // 96 KB V + 25.6 (20) KB strips + (scale, shift) tables
     hipStream_t st = (hipStream_t)stream;
 #define NRGBD_WINO_PC_LAUNCH(KD_, DIL_, RES_)                                                                       \
     do { if (materialized) NRGBD_WINO_PC_LAUNCH_M(KD_, DIL_, RES_, true); else NRGBD_WINO_PC_LAUNCH_M(KD_, DIL_, RES_, false); } while (0)
@@ -806,7 +823,7 @@ extern "C" int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, 
     if (e != hipSuccess) return (int)e;
     if (ncu <= 0) return NRGBD_E_ARG;
     const int nwg = nt < ncu ? (int)nt : ncu;
-    const size_t lds = (size_t)(kPcNBuf * kPcV + 4 * kPcRawWave) * sizeof(float);
+    const size_t lds = (size_t)(kPcNBuf * kPcV + kPcStrips) * sizeof(float);
 #define NRGBD_WINO_RNET_LAUNCH(ODD_, HALF_)                                                                              \
     do {                                                                                                                 \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, false, ODD_, 1, false, HALF_>), \

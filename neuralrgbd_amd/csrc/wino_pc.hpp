@@ -20,6 +20,17 @@ constexpr int kPcNPF = (kPcItems + 63) / 64;    // per producer lane and stage (
 #define NRGBD_WPOS 1   // MFMA gap (0..3) of a transform point in which the consumers request the weight line 7 points ahead
 #endif
 constexpr int kPcBD = 7, kPcNB = 8;             // weight ring: distance / slots
+// SHARED strips (see wino_dw.hip): the 10 x 18 halo of a stage is split once over the 256 producer lanes into a strip all four
+// producer waves share (3 words per lane instead of 5 from four overlapping 4-row private strips), published one stage ahead of
+// its transform; the stage barrier is the only synchronisation.
+#ifndef NRGBD_PC_SHARED
+#define NRGBD_PC_SHARED 1   // 0: the private-strip producers (experimental A/B builds only)
+#endif
+constexpr int kPcShRows = kPcTH + 2;                       // halo rows of a tile
+constexpr int kPcShStrip = kPcShRows * kPcRawW * kCB;      // floats of one shared strip: [10 rows][20 pixels][16] = 12.8 KB
+constexpr int kPcShItems = kPcShRows * 18 * 4;             // (row, column, 16-byte word) items of a stage: 720
+constexpr int kPcNPFx = NRGBD_PC_SHARED ? 3 : kPcNPF;      // items per producer lane and stage in wino_pc.hip
+constexpr int kPcStrips = NRGBD_PC_SHARED ? 2 * kPcShStrip : 4 * kPcRawWave;   // floats of wino_pc.hip's strip region
 
 struct WinoPcArgs {
     const float* x;       // [N][H][W][Cin] raw input (pre-activation); N = depth slices when KD = 3
