@@ -627,8 +627,9 @@ def main():
             blocks = (-(-D // 2)) * (-(-h // 2)) * (-(-w // 2))
             flops = 2.0 * blocks * 64 * 64 * 64
             tf = flops / (c_ms * 1e-3) / 1e12
-            line["roofline_mfma"] = {"bound": "mfma", "kernel": "conv_wino_dw_kernel<false,false,false> (one K-Net 3x3x3 64->64 layer, "
-                                     "Winograd in all three dimensions; the 10 such layers are ~55 % of the frame)", "achieved": tf,
+            line["roofline_mfma"] = {"bound": "mfma", "kernel": "conv_wino_dw_kernel, the frame's own call = its clamped-FMA-ReLU instantiation (one K-Net "
+                                     "3x3x3 64->64 layer with a BatchNorm + ReLU input, Winograd in all three dimensions; the 10 64->64 layers are "
+                                     "~55 % of the frame)", "achieved": tf,
                                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                      "flops": flops, "direct_conv_flops": nominal,
                                      "direct_conv_equivalent_tflops": nominal / (c_ms * 1e-3) / 1e12, "kernel_ms": c_ms,
