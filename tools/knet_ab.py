@@ -7,6 +7,8 @@ from neuralrgbd_amd import _lib
 if os.environ.get("NRGBD_EXP_LIB"):
     _lib.LIB_PATH = os.environ["NRGBD_EXP_LIB"]
 from neuralrgbd_amd import nets
+if os.environ.get("NO_SPLIT"):          # A/B: the residual layers fused (wino_dw RES variants) instead of nhwc_act + the IDENT form
+    nets.KalmanGainNet._split_residual = False
 if os.environ.get("NO_CLAMP"):            # A/B of the clamped-FMA ReLU form: the plain form everywhere
     nets._relu_unit = lambda owner, bn, count: 0.0
 torch.manual_seed(0)
@@ -24,4 +26,4 @@ with torch.no_grad():
             out = net.forward_channels_last(vol)
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 10)
-print("K-Net %dx%dx%d with %s%s: %s ms per pass; checksum %.6f" % (D, H, W, os.path.basename(_lib.LIB_PATH), " (no clamp form)" if os.environ.get("NO_CLAMP") else "", " ".join("%.2f" % t for t in ts), out.double().abs().mean().item()))
+print("K-Net %dx%dx%d with %s%s: %s ms per pass; checksum %.6f" % (D, H, W, os.path.basename(_lib.LIB_PATH), (" (no clamp form)" if os.environ.get("NO_CLAMP") else "") + (" (fused residual layers)" if os.environ.get("NO_SPLIT") else ""), " ".join("%.2f" % t for t in ts), out.double().abs().mean().item()))
