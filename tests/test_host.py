@@ -296,3 +296,27 @@ def test_conv_embeddings_of_the_training_path_are_exact(monkeypatch):
         assert torch.allclose(y, want, rtol=1e-12, atol=1e-12), type(mod)
         for a, b in zip(got_g, want_g):
             assert torch.allclose(a, b, rtol=1e-11, atol=1e-11), (type(mod), a.shape)
+
+
+def test_relu_unit_bounds_any_batchnorm_output():
+    """ops.relu_unit (the power of two the clamped-FMA ReLU form of wino_dw.hip scales its operands by): 1 / unit exceeds the
+    largest |BatchNorm(y)| under batch statistics for adversarial data — a single huge outlier, constant channels, tiny n — so the
+    [0, 1] clamp can never saturate on the upper side."""
+    import torch
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for n in (2, 7, 4096, 100000):
+        for trial in range(4):
+            C = 6
+            y = torch.randn(n, C, generator=g) * (10.0 ** trial)
+            y[0, 0] = 1e7                      # one outlier dominates channel 0
+            y[:, 1] = 3.25                     # a constant channel (variance 0: eps alone normalises)
+            y[:, 2] = 0.0
+            y[n // 2, 2] = -1e-3
+            gamma = torch.randn(C, generator=g) * 3
+            beta = torch.randn(C, generator=g) * 5
+            z = torch.nn.functional.batch_norm(y, None, None, gamma, beta, training=True, eps=1e-5)
+            unit = ops.relu_unit(gamma, beta, n)
+            k = round(-__import__("math").log2(unit))
+            assert unit == 2.0 ** -k and 0 <= k, unit              # an exact power of two in (0, 1]
+            assert z.abs().max().item() < 1.0 / unit, (n, trial, z.abs().max().item(), unit)
