@@ -357,6 +357,9 @@ int nrgbd_bias_act_nchw(float* x, const float* bias, float slope, int N, int C, 
  *           padding = dilation in {1, 2}.
  * Cin % 16 == 0, Cout % 64 == 0; same fused prologue (x_ss / x_relu / res / res_ss / res_relu / materialized) and statistics
  * epilogue as nrgbd_conv3d_3x3x3_f32 / nrgbd_conv2d_3x3_f32.
+ * Cout = 32 (kd = 1, dilation 1: the trunk's half-resolution 32 -> 32 layers, psm_submodule.py:90-103): the kernel's HALF form —
+ *   w_wino is the 64-column stream of the layer's weights with the upper 32 columns zero, stats has TWO rows per tile
+ *   ([2*32][2 * nrgbd_conv_wino_tiles]: one per (tile, 16-tile row block)); nrgbd_conv_wino_rnet_ex_f32 takes Cout = 32 the same way.
  *   w_wino: [Cout/64][stage = cb*kd + depth tap][16 transform points][4 waves][64 lanes][4] floats, U = G g G^T over (ky, kx)
  *           (host mirror: neuralrgbd_amd/ops.py::conv_wino_pack)
  *   stats  [2*Cout][nrgbd_conv_wino_tiles(N,H,W,dilation)] (COLUMN-major: a channel's per-tile partial sums, then its partial
