@@ -568,7 +568,7 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 
-    _split_residual = True      # measured (tools/r4_knet_split.py): K-Net 25.37 -> 24.67 ms at config B, 3.26 -> 3.18 at S, 20.03 -> 19.60 at H; identical bits
+    _split_residual = True      # measured (tools/knet_ab.py, NO_SPLIT=1): K-Net 25.37 -> 24.67 ms at config B when introduced, 22.74 -> 22.40 after the shared strips; identical bits
 
     def forward_channels_last(self, vol, generation=None):
         """Inference on the hand-written kernels: vol [D,H,W,Cin] (channels-last) -> gain [D,H,W].
