@@ -24,12 +24,12 @@
 //     is full: 128 accumulators + weight ring + operands); phase 2 completes and stores slice z0, phase 3 slice z0+1, each
 //     with its BatchNorm partial statistics;
 //   * producers: a stage needs the depth combination of TWO slices.  The unit of prefetch stays one (slice, channel block):
-//     unit A is normalised / activated and published to the wave's strip exactly as in wino_pc.hip, unit B is activated and
-//     COMBINED with what the strip holds (A +- B: the wave reads back its own words; a wave's LDS operations execute in order),
-//     then the strip is transformed as before.  Each unit has its own register set, refilled for the NEXT stage right after
-//     it was published.
+//     unit A is normalised / activated and published to the stage's strip exactly as in wino_pc.hip, unit B is activated and
+//     COMBINED with what the strip holds (A +- B: a lane reads back its own words; a wave's LDS operations execute in order),
+//     and the strip is transformed one iteration later (shared strips, below).  Each unit has its own register set, refilled
+//     for the NEXT stage right after it was published.
 // Work per pair of output slices: 16 stages (wino_pc: 24); producer publishes 32 (24); plane transforms 16 (24).
-// LDS: 2 x 32 KB V + 4 x 5 KB strips + 2 x 32 KB stash = 148 KB; 8 waves, up to 256 VGPRs each.  (Two V buffers instead of
+// LDS: 2 x 32 KB V + 2 x 12.8 KB strips + 2 x 32 KB stash = 154 KB; 8 waves, up to 256 VGPRs each.  (Two V buffers instead of
 // wino_pc's three — the third one's 32 KB hold the second stash.  A consumer therefore cannot read the first operand of the
 // next stage before the stage barrier; instead it ARRIVES at the barrier early, as soon as its last LDS operand of the stage is
 // in registers, and reads the next stage's first operand under its own last 8 MFMAs.)

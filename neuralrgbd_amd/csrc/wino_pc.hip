@@ -17,11 +17,13 @@
 //       weight lines (1 KB, packed per wave) run 7 steps ahead in an 8-deep register ring that continues across stages and
 //       tiles; the first A operand of the next stage is read before the stage barrier (three V buffers make that legal);
 //       the first k-step of a tile takes a zero C operand (the accumulators are never cleared).
-//   producer wave p (waves 0..3: the older waves win the SIMD's VALU arbitration) = tile row p (8 Winograd tiles): raw rows
-//       2p..2p+3 of the 10x18 halo of one 16-channel block global -> registers (TWO stages ahead, two register sets, the
-//       stage's (scale, shift) with them) -> BatchNorm / ReLU / residual, packed and breadth-first -> its PRIVATE 5 KB
-//       strip of LDS (no workgroup barrier: a wave's LDS operations execute in order) -> B^T d B per (tile, 16-byte word,
-//       half) -> V[q % 3].
+//   producer waves (waves 0..3: the older waves win the SIMD's VALU arbitration): the 10x18 halo of one 16-channel block is
+//       split over their 256 lanes (3 16-byte words each: every halo word has ONE loader — round 4; until then wave p loaded the
+//       four rows 2p..2p+3 of its tile row into a private strip, 16 rows for a 10-row halo): global -> registers (buffer loads,
+//       TWO stages ahead, two register sets, the stage's (scale, shift) with them) -> BatchNorm / ReLU / residual, packed and
+//       breadth-first -> the SHARED strip of the stage (two of them alternate); the transform B^T d B per (tile, 16-byte word,
+//       half) -> V[q % 3] of producer wave p = tile row p (8 Winograd tiles) runs one iteration LATER, on the strip the stage
+//       barrier has completed — no other synchronisation.
 //   One s_barrier per stage; the consumers never wait for data (producers are two stages ahead), the producers wait for
 //   the consumers — which is the point: the matrix pipe is the resource to keep busy.  What was measured on the way
 //   (in-kernel clocks, profiles/r2_pmc_wino.txt): beside a wave that streams MFMAs a partner's VALU
@@ -30,7 +32,7 @@
 //   Persistent: one workgroup per CU walks its share of the tile list (XCD-aware: an XCD's workgroups sweep neighbouring
 //   tiles, depth fastest, so the three slices a 3-D tile needs are shared in that XCD's L2), so a tile's epilogue and the
 //   next tile's first loads overlap with the producers' run-ahead instead of being exposed at every workgroup boundary.
-// LDS: 3 x 32 KB V + 4 x 5 KB raw strips = 116 KB (one workgroup per CU; 2 waves per SIMD, up to 256 VGPRs each).
+// LDS: 3 x 32 KB V + 2 x 12.8 KB strips = 122 KB (one workgroup per CU; 2 waves per SIMD, up to 256 VGPRs each).
 #include "wino_pc.hpp"
 
 namespace nrgbd {
