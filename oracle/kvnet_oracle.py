@@ -153,6 +153,15 @@ def predict(dpv, pose_next, cam, d_candi, rel_extM=None):
     return torch.from_numpy(out)[None]
 
 
+def step_full(sd, ref, src, poses, cam, d_candi, sigma, BV_predict, t_win_r=2, pose_next=None, rel_extM=None):
+    """step() keeping BOTH refined outputs: (R_cur, R_kv, DPV, BV_cur, BV_predict_next) — R_cur = R-Net(BV_cur), R_kv = R-Net(DPV)
+    (KVNET.py:128,176); on the first frame DPV = BV_cur and R_kv = R_cur."""
+    with torch.no_grad():
+        R_cur, R_kv, BV_cur, DPV = kvnet_forward(sd, ref, src, poses, cam, d_candi, sigma, BV_predict)
+        nxt = predict(DPV, poses[0, t_win_r] if pose_next is None else pose_next, cam, d_candi, rel_extM)
+    return R_cur, R_kv, DPV, BV_cur, nxt
+
+
 def step(sd, ref, src, poses, cam, d_candi, sigma, BV_predict, t_win_r=2, pose_next=None, rel_extM=None):
     """One iteration of the reference's test(): forward + PREDICT -> (R_kv, DPV, BV_cur, BV_predict_next)."""
     with torch.no_grad():
