@@ -8,7 +8,7 @@ the convolutions / BatchNorms of the three networks go through Conv2dCL / Conv3d
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 class PackNHWC(torch.autograd.Function):
@@ -359,12 +359,19 @@ def conv2d_module(conv, x, _any_device=False, keep_width=False, act_slope=None):
         that holds the 2x2 window of the stride-2 taps (`_S2_TAP`).
     The weight embeddings are index / pad operations of torch, so autograd maps the weight gradient back by itself.
     (_any_device: the CPU test of the embeddings, tests/test_host.py, which substitutes F.conv2d for Conv2dCL.)
-    Shapes none of this covers (other strides / kernel sizes, groups) are the module's own forward."""
+    Shapes none of this covers (other strides / kernel sizes, groups; none occurs in the path's networks) raise NrgbdError on the
+    GPU — there is no vendor-library route; on the CPU (host-side structure tests, float64 reference graphs) they are the module's own forward."""
     F = torch.nn.functional
     k, st, pd, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+
+    def module_forward():
+        if x.is_cuda and x.dtype == torch.float32:
+            raise _lib.NrgbdError("no hand-written kernel for Conv2d(%d, %d, kernel %s, stride %s, padding %s, dilation %s, groups %d) on a %s input"
+                                  % (conv.in_channels, conv.out_channels, k, st, pd, d, conv.groups, tuple(x.shape)))
+        return _bias_act(conv(x[:, :conv.in_channels] if x.shape[1] != conv.in_channels else x), None, act_slope)
     if not ((x.is_cuda or _any_device) and x.dtype == torch.float32 and conv.groups == 1 and k[0] == k[1] and st[0] == st[1] and d[0] == d[1]
             and pd[0] == pd[1] and conv.padding_mode == "zeros"):
-        return _bias_act(conv(x[:, :conv.in_channels] if x.shape[1] != conv.in_channels else x), None, act_slope)
+        return module_forward()
     w, y = conv.weight, None
     if k == (3, 3) and st == (1, 1) and pd == d:
         y = _conv3x3_cl(x, w, d[0], conv.bias, keep_width, act_slope)
@@ -378,7 +385,7 @@ def conv2d_module(conv, x, _any_device=False, keep_width=False, act_slope=None):
         w2 = (w.reshape(cout, cin, 9).index_select(2, idx) * msk).reshape(cout, cin * 4, 3, 3)
         y = _conv3x3_cl(F.pixel_unshuffle(x, 2), w2, 1, conv.bias, False, act_slope)
     if y is None:
-        return _bias_act(conv(x[:, :conv.in_channels] if x.shape[1] != conv.in_channels else x), None, act_slope)
+        return module_forward()
     return y
 
 
@@ -388,9 +395,15 @@ def conv_transpose2d_module(conv, x, _any_device=False, act_slope=None):
     kernels and stacked along the output channels (4 Cout, ordered co * 4 + a * 2 + b) they are ONE Conv2dCL launch per direction,
     and pixel_shuffle interleaves the phases."""
     F = torch.nn.functional
+
+    def module_forward():
+        if x.is_cuda and x.dtype == torch.float32:
+            raise _lib.NrgbdError("no hand-written kernel for this ConvTranspose2d (%d -> %d, kernel %s, stride %s) on a %s input"
+                                  % (conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, tuple(x.shape)))
+        return _bias_act(conv(x), None, act_slope)
     if not ((x.is_cuda or _any_device) and x.dtype == torch.float32 and conv.groups == 1 and conv.kernel_size == (4, 4) and conv.stride == (2, 2)
             and conv.padding == (1, 1) and conv.output_padding == (0, 0) and conv.dilation == (1, 1)):
-        return _bias_act(conv(x), None, act_slope)
+        return module_forward()
     w = conv.weight                                  # [Cin, Cout, 4, 4]
     cin, cout = w.shape[:2]
     idx, msk = _tap_select("t2", w.device)
@@ -401,7 +414,7 @@ def conv_transpose2d_module(conv, x, _any_device=False, act_slope=None):
     b4 = None if conv.bias is None else conv.bias.repeat(4)
     y = _conv3x3_cl(x, w4, 1, b4, False, act_slope)
     if y is None:
-        return _bias_act(conv(x), None, act_slope)
+        return module_forward()
     # sub-pixel interleave on the channels-last tensor: pixel (Y, X) holds its four output pixels as four runs of Cout channels,
     # so ONE copy of 4 Cout-float runs builds the channels-last result (F.pixel_shuffle would gather single floats into a planar
     # tensor that the next layer converts back)

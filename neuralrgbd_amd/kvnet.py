@@ -211,8 +211,13 @@ class KVNET(nn.Module):
             volume = torch.cat((warped, BV_cur - BV_predict), dim=0)                       # [16,D,h,w]
             if self.kv_net.in_channels == 16 and self.KVNet_feature_dim == 64 and torch.is_grad_enabled():
                 gain = self.kv_net.forward_channels_last_autograd(volume.permute(1, 2, 3, 0).contiguous()).unsqueeze(0)
+            elif volume.is_cuda:
+                # a K-Net the kernels have no form for (KVNet_feature_dim != 64, a window other than 5 frames, depth up-sampling:
+                # no script of the reference selects one): an error, never a silent hand-over to MIOpen
+                raise nets._no_kernel("this K-Net (%d input channels, feature width %d, if_normalize %s, up_sample_ratio %s)" % (
+                    self.kv_net.in_channels, self.KVNet_feature_dim, self.kv_net.if_normalize, self.kv_net.up_sample_ratio))
             else:
-                gain = torch.squeeze(self.kv_net(volume.unsqueeze(0)), dim=1)   # torch modules
+                gain = torch.squeeze(self.kv_net(volume.unsqueeze(0)), dim=1)   # torch modules on the host (structure tests)
             if gain.is_cuda and gain.dtype == torch.float32:
                 from .autograd import LogSoftmaxD
                 DPV = LogSoftmaxD.apply(gain, BV_predict, 1.0)                  # UPDATE, softmax.hip in both directions

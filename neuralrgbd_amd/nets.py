@@ -60,6 +60,13 @@ def _he_init(module):
 
 
 
+def _no_kernel(what):
+    """The inference path runs on the hand-written kernels or not at all: a shape without an instantiation is an error, never
+    a silent hand-over to MIOpen / rocBLAS."""
+    from ._lib import NrgbdError
+    return NrgbdError("no hand-written kernel for " + what)
+
+
 # --------------------------------------------------------------------------- channels-last matrix-core path (shared)
 class _Act(object):
     """A channels-last activation that is still owed its normalisation: value = act(z*s+t) (+ act(r*s'+t')).
@@ -190,36 +197,18 @@ def _fused_ok(x):
 
 
 def _conv_bn_act(x, seq, relu, residual=None):
-    """conv (vendor library) -> BatchNorm2d(batch stats) -> [ReLU] -> [+ residual]; `seq` = Sequential(conv, bn).
-
-    On the fused path the normalise / activation / add are one hand-written two-pass kernel pair
-    (csrc/bn2d.hip) instead of MIOpen BN + separate ReLU + separate add.
-    """
+    """conv -> BatchNorm2d(batch stats) -> [ReLU] -> [+ residual]; `seq` = Sequential(conv, bn): the module (autograd) form of a
+    trunk layer.  On the GPU every direction runs on the hand-written kernels (autograd.conv2d_module, csrc/bn_train.hip),
+    with or without a graph being recorded; on the CPU it is the torch modules (host-side structure tests)."""
     conv, bn = seq[0], seq[1]
-    if torch.is_grad_enabled():
+    if x.is_cuda and x.dtype == torch.float32:
         from .autograd import conv2d_module, batch_norm_act_cl
-        y = conv2d_module(conv, x)           # training: forward / data gradient / weight gradient on the hand-written kernels
-        if y.is_cuda:
-            # BatchNorm2d + ReLU + add in both directions on csrc/bn_train.hip, on the NHWC view of the channels-last map (a
-            # vendor convolution that answered in NCHW — some tiny SPP shapes — is converted first: a no-op otherwise)
-            y = y.contiguous(memory_format=torch.channels_last)
-            r = None if residual is None else residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
-            return batch_norm_act_cl(y.permute(0, 2, 3, 1), bn, relu, r).permute(0, 3, 1, 2)
-    else:
-        y = conv(x)
-    use_batch = bn.training or not bn.track_running_stats
-    if _fused_ok(y) and use_batch:
-        from . import ops
-        upd = bn.training and bn.track_running_stats
-        y, mv = ops.bn2d_train_act(y, bn.weight, bn.bias, bn.eps, relu=relu, residual=residual, want_mean_var=upd)
-        if upd:  # the shortcut norms keep running statistics (psm_submodule.py:131): same update as nn.BatchNorm2d
-            bn.num_batches_tracked += 1
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            n = y.shape[0] * y.shape[2] * y.shape[3]
-            bn.running_mean.mul_(1 - m).add_(mv[:, 0], alpha=m)
-            bn.running_var.mul_(1 - m).add_(mv[:, 1] * (n / max(n - 1, 1)), alpha=m)
-        return y
-    y = bn(y)
+        y = conv2d_module(conv, x)           # forward / data gradient / weight gradient on the hand-written kernels
+        # BatchNorm2d + ReLU + add in both directions on csrc/bn_train.hip, on the NHWC view of the channels-last map
+        y = y.contiguous(memory_format=torch.channels_last)
+        r = None if residual is None else residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        return batch_norm_act_cl(y.permute(0, 2, 3, 1), bn, relu, r).permute(0, 3, 1, 2)
+    y = bn(conv(x))
     if relu:
         y = F.relu(y, inplace=True)
     return y if residual is None else y + residual
@@ -321,7 +310,9 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
 
     def _conv_bn_cl(self, seq, a, relu, materialize=False):
         """Sequential(conv, bn) on a pending channels-last activation -> (pending output, materialised input | None).
-        3x3 / stride-1 layers run on csrc/conv2d.hip; the stride-2 3x3 layers stay on the vendor library."""
+        3x3 / stride-1 layers run on csrc/wino_pc.hip / conv2d.hip, the stride-2 3x3 layers as 2x2-window convolutions on the
+        space-to-depth image (even map sizes: every grid of the path, image sides are multiples of 4).  A layer shape without a
+        kernel raises NrgbdError — there is no vendor-library route."""
         from . import ops
         conv, bn = seq[0], seq[1]
         d = conv.dilation[0]
@@ -350,24 +341,21 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
                 z, st = ops.conv2d_taps(ops.space_to_depth2(mat), _packed_s2(self, conv), conv.out_channels, 4,
                                         want_stats=_needs_stats(bn))
             else:
-                z = F.conv2d(mat.permute(0, 3, 1, 2), conv.weight, None, conv.stride, conv.padding, conv.dilation)
-                z = z.permute(0, 2, 3, 1).contiguous()
-                st = ops.nhwc_stats(z) if _needs_stats(bn) else None
+                raise _no_kernel("feature CNN layer %d -> %d, kernel %s, stride %s, dilation %d on a %d x %d map" % (
+                    conv.in_channels, conv.out_channels, tuple(conv.kernel_size), tuple(conv.stride), d, mat.shape[1], mat.shape[2]))
         count = z.shape[0] * z.shape[1] * z.shape[2]
         return _Act(z, _bn_scale_shift(bn, st, count, cm=wino), relu), mat
 
     def _pointwise_bn_cl(self, seq, m, stride=1):
-        """1x1 Sequential(conv, bn) on a materialised channels-last tensor: a plain GEMM (vendor BLAS) + statistics."""
+        """1x1 Sequential(conv, bn) on a materialised channels-last tensor: the 1-tap form of csrc/conv2d.hip + statistics."""
         from . import ops
         conv, bn = seq[0], seq[1]
         if stride != 1:
             m = m[:, ::stride, ::stride, :]
         N, H, W, C = m.shape
-        if C % 16 == 0 and conv.out_channels in (32, 64, 128):
-            z, st = ops.conv2d_taps(m.contiguous(), _packed_weights(self, conv), conv.out_channels, 1, want_stats=_needs_stats(bn))
-        else:
-            z = torch.mm(m.reshape(-1, C), conv.weight.view(conv.out_channels, C).t()).view(N, H, W, conv.out_channels)
-            st = ops.nhwc_stats(z) if _needs_stats(bn) else None
+        if C % 16 != 0 or conv.out_channels not in (32, 64, 128):
+            raise _no_kernel("1x1 layer %d -> %d" % (C, conv.out_channels))
+        z, st = ops.conv2d_taps(m.contiguous(), _packed_weights(self, conv), conv.out_channels, 1, want_stats=_needs_stats(bn))
         return _Act(z, _bn_scale_shift(bn, st, N * H * W), False)
 
     def _block_cl(self, blk, a):
@@ -394,13 +382,12 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         the 1-tap form of the same kernel.  What is left of torch here: the SPP average pooling of the deep map."""
         from . import ops
         conv, bn = self.firstconv[0]
-        if x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
-            # 3 -> 32, stride 2: the image as a 12(+4)-channel space-to-depth tensor, then a 2x2-window convolution
-            z, st = ops.conv2d_taps(ops.space_to_depth2(x.contiguous(), nchw=True), _packed_s2(self, conv), conv.out_channels, 4,
-                                    want_stats=_needs_stats(bn))
-        else:
-            z = F.conv2d(x, conv.weight, None, conv.stride, conv.padding).permute(0, 2, 3, 1).contiguous()
-            st = ops.nhwc_stats(z) if _needs_stats(bn) else None
+        if x.shape[2] % 4 or x.shape[3] % 4:
+            raise _no_kernel("image %d x %d: the plane-sweep grid is the image / 4 (models/basic.py:254-263), both sides must be multiples of 4"
+                             % (x.shape[2], x.shape[3]))
+        # 3 -> 32, stride 2: the image as a 12(+4)-channel space-to-depth tensor, then a 2x2-window convolution
+        z, st = ops.conv2d_taps(ops.space_to_depth2(x.contiguous(), nchw=True), _packed_s2(self, conv), conv.out_channels, 4,
+                                want_stats=_needs_stats(bn))
         a = _Act(z, _bn_scale_shift(bn, st, z.numel() // z.shape[-1]), True)
         for i in (2, 4):
             a, _ = self._conv_bn_cl(self.firstconv[i], a, relu=True)
@@ -450,17 +437,15 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
             cat = torch.cat([quarter, deep] + pyramid, dim=3)              # [N,h,w,320]
         y, _ = self._conv_bn_cl(self.lastconv[0], _Act(cat), relu=True)
         head = self.lastconv[2]
-        if head.out_channels in (32, 64, 128):   # 1x1 head; BatchNorm + ReLU of lastconv[0] in its loader
-            feat, _ = ops.conv2d_taps(y.z, _packed_weights(self, head), head.out_channels, 1, x_ss=y.ss, x_relu=True, want_stats=False)
-        else:
-            y = ops.nhwc_act(y.z, y.ss, True)
-            feat = torch.mm(y.view(-1, y.shape[-1]), head.weight.view(head.out_channels, -1).t()).view(N, h, w, head.out_channels)
+        if head.out_channels not in (32, 64, 128):
+            raise _no_kernel("feature_dim %d (1x1 head): 32, 64 or 128" % head.out_channels)
+        # 1x1 head; BatchNorm + ReLU of lastconv[0] in its loader
+        feat, _ = ops.conv2d_taps(y.z, _packed_weights(self, head), head.out_channels, 1, x_ss=y.ss, x_relu=True, want_stats=False)
         return half, feat
 
     def forward(self, x):
-        if x.is_cuda and torch.is_grad_enabled():
-            # training: the whole trunk in channels-last memory, the layout of the hand-written conv / BatchNorm kernels (the vendor
-            # convolutions left in the graph keep the format of their input)
+        if x.is_cuda:
+            # the whole trunk in channels-last memory, the layout of the hand-written conv / BatchNorm kernels
             x = x.contiguous(memory_format=torch.channels_last)
         stem = x
         for i in (0, 2, 4):
@@ -476,7 +461,7 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
             y = _conv_bn_act(pools[self.SPP_WINDOWS[i - 1]], branch[1], relu=True)
             pyramid.append(self._upsample(y, size))
         y = _conv_bn_act(torch.cat([quarter, deep] + pyramid, dim=1), self.lastconv[0], relu=True)
-        if y.is_cuda and torch.is_grad_enabled():
+        if y.is_cuda:
             from .autograd import conv2d_module
             feat = conv2d_module(self.lastconv[2], y)       # the 1x1 head on the hand-written kernels in all three directions
         else:
@@ -714,53 +699,60 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 bil = (1 - abs(og[0] - center) / factor) * (1 - abs(og[1] - center) / factor)
                 m.weight.data.copy_(torch.from_numpy(bil))
 
-    def _forward_fused_tail(self, dpv_raw, img_features):
-        """Inference: same graph as forward(), vendor convolutions without their bias, then ONE hand-written pass for
-        bias + LeakyReLU (csrc/bn2d.hip::bias_act_nchw) instead of a bias-add kernel and a LeakyReLU kernel per layer;
-        the final bias add + log-softmax over D run on csrc/softmax.hip."""
-        from . import ops
-        quarter, half, full = (t.contiguous() for t in img_features)
-
-        def layer(m, x, slope=0.01):
-            c = m[0] if isinstance(m, nn.Sequential) else m
-            if isinstance(c, nn.ConvTranspose2d):
-                y = F.conv_transpose2d(x, c.weight, None, c.stride, c.padding)
-            else:
-                y = F.conv2d(x, c.weight, None, c.stride, c.padding)
-            if not y.is_contiguous():
-                y = y.contiguous()
-            return ops.bias_act_(y, c.bias.detach(), slope)
-
-        x = layer(self.conv0_1, layer(self.conv0, torch.cat([dpv_raw, quarter], dim=1)))
-        x = layer(self.trans_conv0, x)
-        x = layer(self.conv1_1, layer(self.conv1, torch.cat([x, half], dim=1)))
-        x = layer(self.trans_conv1, x)
-        x = layer(self.conv2_1, layer(self.conv2, torch.cat([x, full], dim=1)))
-        x = layer(self.conv2_2, x, slope=1.0)
-        return ops.logsoftmax_d(x[0]).unsqueeze(0)
-
     # ------------------------------------------------------------------ hand-written matrix-core path (inference)
-    _SLICES = {64: (64,), 96: (96,), 128: (128,), 160: (96, 64), 192: (96, 96)}   # output columns per launch (kernel widths)
-
     def _widths(self):
-        """(D, C0, C1, C2) of this net, or None when the matrix-core kernel has no instantiation for them: D in {64, 128}
-        depth candidates + 64 / 32 / 3 image-feature channels (every script of the reference: feature_dim 64)."""
+        """(D, Dp, C0, C1, C2) of this net, or None when the kernels do not cover it.  Covered: any D <= 128 depth candidates with
+        64 / 32 / 3 image-feature channels (every script of the reference: feature_dim 64) and no candidate up-sampling.  The
+        kernels are instantiated for Dp = 64 and 128 candidate channels; another D runs ZERO-PADDED to the next of the two: the
+        candidate channels of every buffer are Dp wide (exp(-inf) = 0 in the padding), the weights are embedded with zero rows /
+        columns for it (`_embedded`), and the padding of the last layer carries a -1e30 bias so that the log-softmax over the Dp
+        channels of a pixel is the log-softmax over its D real ones.  A zero operand adds an exact zero to an fp32 FMA chain, so
+        the result is the one a D-wide instantiation with the same summation order would give."""
         D = self.conv2_2.out_channels
         C0 = self.conv0[0].in_channels - D
         C1 = self.conv1[0].in_channels - D
         C2 = self.conv2[0].in_channels - D
-        ok = D in (64, 128) and (C0, C1, C2) == (64, 32, 3) and self.trans_conv0[0].out_channels == D \
+        ok = 1 <= D <= 128 and (C0, C1, C2) == (64, 32, 3) and self.trans_conv0[0].out_channels == D \
             and self.trans_conv1[0].out_channels == D and self.conv2_1[0].out_channels == D
-        return (D, C0, C1, C2) if ok else None
+        return (D, 64 if D <= 64 else 128, C0, C1, C2) if ok else None
 
     def mfma_ok(self, dpv):
-        """The R-Net on the hand-written kernels (inference, batch 1 or 2) at EVERY grid (round 3; rounds 1-2 handed grids below
-        64 16x16-tiles — configs S and K — to MIOpen): the six conv2d_leakyRelu layers on the Winograd kernel's R-Net form
-        (csrc/wino_pc.hip, 8x16-pixel tiles of a persistent launch fill the chip at every grid), the transposed convolutions
-        and the log-softmax layer on csrc/conv2d.hip.  Widths without an instantiation (D not in {64, 128}) take the module graph."""
-        if self._widths() is None or not dpv.is_cuda or torch.is_grad_enabled() or dpv.shape[0] not in (1, 2):
-            return False
-        return True
+        """Inference on the GPU -> the hand-written kernels (forward_log), at EVERY grid and candidate count the reference's
+        scripts use: the six conv2d_leakyRelu layers and conv2_2 on the Winograd kernel's R-Net form (csrc/wino_pc.hip, 8x16-pixel
+        tiles of a persistent launch), the transposed convolutions on csrc/conv2d.hip, the log-softmax on csrc/softmax.hip."""
+        return dpv.is_cuda and not torch.is_grad_enabled() and dpv.dtype == torch.float32
+
+    def _embedded(self):
+        """{layer: (weight, bias)} in the channel layout of the kernels' buffers: a [candidates (D) | image features (C)] concat
+        lives as [D real | Dp - D zero | C], a D-wide output as [D real | Dp - D zero].  D == Dp: the module's own tensors."""
+        D, Dp, C0, C1, C2 = self._widths()
+        mods = {"conv0": self.conv0[0], "conv0_1": self.conv0_1[0], "trans_conv0": self.trans_conv0[0], "conv1": self.conv1[0],
+                "conv1_1": self.conv1_1[0], "trans_conv1": self.trans_conv1[0], "conv2": self.conv2[0], "conv2_1": self.conv2_1[0],
+                "conv2_2": self.conv2_2}
+        if D == Dp:
+            return {k: (m.weight.detach(), m.bias.detach()) for k, m in mods.items()}
+        dev = self.conv2_2.weight.device
+        cat = lambda C: torch.cat((torch.arange(D, device=dev), Dp + torch.arange(C, device=dev)))      # source channel -> position
+        plain = torch.arange(D, device=dev)
+        io = {"conv0": (cat(C0), Dp + C0, cat(C0), Dp + C0), "conv0_1": (cat(C0), Dp + C0, cat(C0), Dp + C0),
+              "trans_conv0": (cat(C0), Dp + C0, plain, Dp), "conv1": (cat(C1), Dp + C1, cat(C1), Dp + C1),
+              "conv1_1": (cat(C1), Dp + C1, cat(C1), Dp + C1), "trans_conv1": (cat(C1), Dp + C1, plain, Dp),
+              "conv2": (cat(C2), Dp + C2, cat(C2), Dp + C2), "conv2_1": (cat(C2), Dp + C2, plain, Dp), "conv2_2": (plain, Dp, plain, Dp)}
+        out = {}
+        for k, m in mods.items():
+            in_idx, cin_p, out_idx, cout_p = io[k]
+            w, b = m.weight.detach(), m.bias.detach()
+            tr = isinstance(m, nn.ConvTranspose2d)            # [Cin, Cout, 4, 4]
+            if tr:
+                w = w.transpose(0, 1)
+            t = w.new_zeros((w.shape[0], cin_p) + tuple(w.shape[2:]))
+            t[:, in_idx] = w
+            wp = w.new_zeros((cout_p, cin_p) + tuple(w.shape[2:]))
+            wp[out_idx] = t
+            bp = b.new_full((cout_p,), -1e30 if k == "conv2_2" else 0.0)    # conv2_2: the padding drops out of the log-softmax
+            bp[out_idx] = b
+            out[k] = ((wp.transpose(0, 1) if tr else wp).contiguous(), bp)
+        return out
 
     def _rnet_packed(self):
         """Per layer a list of output-column slices (packed B-operand stream, padded bias, kernel width, first column,
@@ -772,32 +764,10 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
             return cache["val"]
         pad16 = lambda c: (c + 15) // 16 * 16
         pad32 = pad16                                # pixel width of the concat buffers = whole 16-channel Winograd stages (an odd count has its own instantiation)
+        emb = self._embedded()
 
-        def slices(cout):
-            cp = pad16(cout)
-            cp = cp if cp in self._SLICES else min(k for k in self._SLICES if k >= cp)
-            out, c0 = [], 0
-            for wdt in self._SLICES[cp]:
-                out.append((c0, wdt, max(0, min(wdt, cout - c0))))
-                c0 += wdt
-            return [t for t in out if t[2] > 0]
-
-        def conv(m):
-            c = m[0] if isinstance(m, nn.Sequential) else m
-            w, b = c.weight.detach(), c.bias.detach()
-            cin_p = pad32(w.shape[1])                # = the width of the buffer the layer reads (zero weights for its padding)
-            res = []
-            for c0, wdt, valid in slices(w.shape[0]):
-                wp = w.new_zeros(wdt, cin_p, 3, 3)
-                wp[:valid, :w.shape[1]] = w[c0:c0 + valid]
-                bp = b.new_zeros(wdt)
-                bp[:valid] = b[c0:c0 + valid]
-                res.append((ops.conv_pack_weights(wp.contiguous()), bp.contiguous(), wdt, c0, valid))
-            return res
-
-        def deconv(m):
-            c = m[0]
-            w, b = c.weight.detach(), c.bias.detach()          # [Cin, Cout, 4, 4]
+        def deconv(name):
+            w, b = emb[name]                                   # [Cin, Cout, 4, 4]
             res = {}
             for pa in (0, 1):
                 for pb in (0, 1):
@@ -811,11 +781,10 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                           for i in range(len(res[(0, 0)]))]
             return res
 
-        def wino(m):
+        def wino(name):
             """Winograd-domain stream of a conv2d_leakyRelu layer for the persistent kernel's R-Net form, widths padded with zero
             weights to Cin % 16 == 0 (the buffer it reads) and Cout % 64 == 0; (stream, bias, packed columns, valid columns)."""
-            c = m[0] if isinstance(m, nn.Sequential) else m
-            w, b = c.weight.detach(), c.bias.detach()
+            w, b = emb[name]
             cin_p, cout_p = pad32(w.shape[1]), (w.shape[0] + 63) // 64 * 64
             wp = w.new_zeros(cout_p, cin_p, 3, 3)
             wp[:w.shape[0], :w.shape[1]] = w
@@ -833,51 +802,74 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                         (ops.conv_wino_pack(tail), bp[full:full + 32].contiguous(), 32, extra, full))
             return (ops.conv_wino_pack(wp.contiguous()), bp.contiguous(), cout_p, w.shape[0])
 
-        val = {"conv0": conv(self.conv0), "conv0_1": conv(self.conv0_1), "t0": deconv(self.trans_conv0),
-               "conv0_w": wino(self.conv0), "conv0_1_w": wino(self.conv0_1), "conv1_w": wino(self.conv1),
-               "conv1_1_w": wino(self.conv1_1), "conv2_w": wino(self.conv2), "conv2_1_w": wino(self.conv2_1),
-               "conv1": conv(self.conv1), "conv1_1": conv(self.conv1_1), "t1": deconv(self.trans_conv1),
-               "conv2": conv(self.conv2), "conv2_1": conv(self.conv2_1), "conv2_2": conv(self.conv2_2),
-               "conv2_2_w": wino(self.conv2_2)}
+        val = {"t0": deconv("trans_conv0"), "t1": deconv("trans_conv1")}
+        for name in ("conv0", "conv0_1", "conv1", "conv1_1", "conv2", "conv2_1", "conv2_2"):
+            val[name + "_w"] = wino(name)
         cache["key"], cache["val"] = key, val
         return val
 
     def _rnet_buffers(self, n, h, w, dev):
-        """Persistent channels-last buffers (zero-initialised ONCE: the padding channels of the full-resolution pixels —
-        67 -> 80, 131 -> 144 — are never written and must stay zero).  One set per batch size (1: first frame, 2: update)."""
+        """Persistent channels-last buffers (zero-initialised ONCE: the padding channels of the pixels — 67 -> 80, 131 -> 144,
+        and D -> Dp when D is not 64 / 128 — are never written and must stay zero).  One set per batch size (1: first frame,
+        2: update)."""
         cache = self.__dict__.setdefault("_buf_cache", {})
         key = (n, h, w, str(dev))
         if key not in cache:
             for k in [k for k in cache if k[1:] != key[1:]]:
                 del cache[k]
-            D, C0, C1, C2 = self._widths()
+            D, Dp, C0, C1, C2 = self._widths()
             z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
             p32 = lambda c: (c + 15) // 16 * 16                       # whole 16-channel Winograd stages (_rnet_packed pads its weights to the same widths)
-            w0, w1, w2 = p32(D + C0), p32(D + C1), p32(D + C2)        # 128, 96, 80 at D = 64; 192, 160, 144 at D = 128
+            w0, w1, w2 = p32(Dp + C0), p32(Dp + C1), p32(Dp + C2)     # 128, 96, 80 at Dp = 64; 192, 160, 144 at Dp = 128
             cache[key] = {"x0": z(n, h, w, w0), "a0": z(n, h, w, w0), "b0": z(n, h, w, w0),
                           "c1": z(n, 2 * h, 2 * w, w1), "a1": z(n, 2 * h, 2 * w, w1), "b1": z(n, 2 * h, 2 * w, w1),
-                          "c2": z(n, 4 * h, 4 * w, w2), "g2": z(n, 4 * h, 4 * w, w2), "h2": z(n, 4 * h, 4 * w, D)}
+                          "c2": z(n, 4 * h, 4 * w, w2), "g2": z(n, 4 * h, 4 * w, w2), "h2": z(n, 4 * h, 4 * w, Dp)}
+            if D != Dp:     # staging of the candidate planes: rows D.. stay -inf (exp -> the zero padding of the first concat)
+                cache[key]["dpv"] = torch.full((n, Dp, h, w), float("-inf"), dtype=torch.float32, device=dev)
         return cache[key]
 
     def forward_log(self, dpv_log, img_features):
         """Same result as forward(torch.exp(dpv_log), img_features) (models/KVNET.py:128,176 + Refine.py:79-107) with the
-        exp fused into the first concat; on the matrix-core kernels when mfma_ok()."""
+        exp fused into the first concat.  Inference on the GPU runs on the hand-written kernels (a net they do not cover —
+        candidate up-sampling, other feature widths, D > 128 — raises NrgbdError: there is no vendor-library route);
+        `img_features` are ONE image's features, shared by every sample of the batch (KVNET.forward refines BV_cur and DPV of
+        a frame as one batch of 2)."""
         if not self.mfma_ok(dpv_log):
             return self.forward(torch.exp(dpv_log), img_features)
         from . import ops
-        quarter, half, full = img_features        # one image's features, shared by every sample of the batch
-        n, D, h, w = dpv_log.shape
+        wd = self._widths()
+        if wd is None:
+            raise _no_kernel("this R-Net (candidate up-sampling, image-feature widths other than 64 / 32 / 3, or more than 128 candidates)")
+        D, Dp = wd[0], wd[1]
+        quarter, half, full = img_features
+        n, _, h, w = dpv_log.shape
+        if n > 2:                                  # buffers are kept for the path's two batch sizes; a larger batch in pairs
+            return torch.cat([self.forward_log(dpv_log[i:i + 2], img_features).clone() for i in range(0, n, 2)], dim=0)
+        if tuple(quarter.shape) != (1, 64, h, w) or tuple(half.shape) != (1, 32, 2 * h, 2 * w) or tuple(full.shape) != (1, 3, 4 * h, 4 * w):
+            raise ValueError("forward_log: features of ONE image at 1/4, 1/2 and full resolution ([1,64,h,w], [1,32,2h,2w], [1,3,4h,4w]) expected")
         dev = dpv_log.device
         pk, buf = self._rnet_packed(), self._rnet_buffers(n, h, w, dev)
 
-        def conv(x, layer, out, mode=0, pa=0, pb=0):
-            """All output-column slices of one layer into `out` (pixel stride = its last dimension)."""
+        def deconv(x, layer, out):
+            """ConvTranspose2d(k4, s2, p1) + bias + LeakyReLU: all four sub-pixel phases of every 64-column slice in one launch each."""
             for wp, bias, wdt, c0, valid in layer:
-                ops.conv2d_rnet(x, wp, wdt, bias=bias, out=out, ldy=out.shape[-1], ycoff=c0, cout_valid=valid, mode=mode,
-                                pa=pa, pb=pb)
+                ops.conv2d_rnet(x, wp, wdt, bias=bias, out=out, ldy=out.shape[-1], ycoff=c0, cout_valid=valid, mode=3)
+            return out
+
+        def conv_w(x, name, out=None, lrelu=True):
+            """A 3x3 layer on the Winograd kernel's R-Net form (4 instead of 9 multiplies per output and input channel, even after
+            padding 96 / 67 outputs to 128): the whole 64-column groups in one launch, a 32-column tail (67 = 64 + 3) on its HALF form."""
+            wt = pk[name + "_w"]
+            out = ops.conv_wino_rnet(x, wt[0], wt[2], bias=wt[1], lrelu=lrelu, out=out, cout_valid=wt[3])
+            if len(wt) > 4:
+                t = wt[4]
+                ops.conv_wino_rnet(x, t[0], t[2], bias=t[1], lrelu=lrelu, out=out, ycoff=t[4], cout_valid=t[3])
             return out
 
         # level 1/4: cat(exp(dpv), feat) -> conv0 -> conv0_1
+        if D != Dp:
+            buf["dpv"][:, :D].copy_(dpv_log)
+            dpv_log = buf["dpv"]
         q_cl = quarter.permute(0, 2, 3, 1)
         x = buf["x0"]
         for b in range(n):
@@ -885,42 +877,27 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
                 ops.rnet_pack(dpv_log[b].contiguous(), q_cl[0], feat_planar=False, out=x[b:b + 1])
             else:
                 ops.rnet_pack(dpv_log[b].contiguous(), quarter[0].contiguous(), feat_planar=True, out=x[b:b + 1])
-        def conv_w(x, name, out):
-            """A conv2d_leakyRelu layer: on the Winograd kernel's R-Net form (4 instead of 9 multiplies per output and input
-            channel, even after padding 96 / 67 outputs to 128), the direct kernel as the A/B (NRGBD_RNET_WINO=0)."""
-            w = pk.get(name + "_w")
-            if w is not None:
-                ops.conv_wino_rnet(x, w[0], w[2], bias=w[1], lrelu=True, out=out, cout_valid=w[3])
-                if len(w) > 4:      # the 32-column tail slice (HALF form) behind the whole 64-column groups
-                    t = w[4]
-                    ops.conv_wino_rnet(x, t[0], t[2], bias=t[1], lrelu=True, out=out, ycoff=t[4], cout_valid=t[3])
-                return out
-            return conv(x, pk[name], out)
         x = conv_w(conv_w(x, "conv0", buf["a0"]), "conv0_1", buf["b0"])
-        # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..D-1 of the concat buffer; features behind
+        # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..Dp-1 of the concat buffer; features behind
         c1 = buf["c1"]
-        conv(x, pk["t0"]["all"], c1, mode=3)
-        c1[..., D:D + half.shape[1]].copy_(half.permute(0, 2, 3, 1))
+        deconv(x, pk["t0"]["all"], c1)
+        c1[..., Dp:Dp + 32].copy_(half.permute(0, 2, 3, 1))
         x = conv_w(conv_w(c1, "conv1", buf["a1"]), "conv1_1", buf["b1"])
-        # full resolution: D + 3 channels in 16-aligned pixels (padding channels zero, with zero weights)
+        # full resolution: Dp + 3 channels in 16-aligned pixels (padding channels zero, with zero weights)
         c2 = buf["c2"]
-        conv(x, pk["t1"]["all"], c2, mode=3)
-        c2[..., D:D + 3].copy_(full.permute(0, 2, 3, 1))
+        deconv(x, pk["t1"]["all"], c2)
+        c2[..., Dp:Dp + 3].copy_(full.permute(0, 2, 3, 1))
         x = conv_w(conv_w(c2, "conv2", buf["g2"]), "conv2_1", buf["h2"])
-        if D in (64, 128) and x.shape[-1] == D:
-            # conv2_2 + bias on the Winograd kernel (pixels channels-last), then log-softmax over the D channels of every pixel in
-            # place: the refined DPV is handed out as an [n, D, H, W] VIEW of that channels-last memory (round 4; the direct kernel
-            # with the log-softmax epilogue and a planar store took 1.0 ms at config B)
-            w = pk["conv2_2_w"]
-            z = ops.conv_wino_rnet(x, w[0], w[2], bias=w[1], lrelu=False, cout_valid=w[3])
-            return ops.logsoftmax_rows(z).permute(0, 3, 1, 2)
-        wp, bias, wdt, _, _ = pk["conv2_2"][0]
-        return ops.conv2d_rnet(x, wp, wdt, bias=bias, lrelu=False, mode=2)
+        # conv2_2 + bias on the Winograd kernel (pixels channels-last), then log-softmax over the channels of every pixel in place:
+        # the refined DPV is handed out as an [n, D, H, W] VIEW of that channels-last memory (round 4; the direct kernel with the
+        # log-softmax epilogue and a planar store took 1.0 ms at config B).  D != Dp: the padding's -1e30 bias keeps it out of the sum
+        y = ops.logsoftmax_rows(conv_w(x, "conv2_2", None, lrelu=False)).permute(0, 3, 1, 2)
+        return y if D == Dp else y[:, :D]
 
     def forward(self, dpv_raw, img_features):
-        if dpv_raw.is_cuda and not torch.is_grad_enabled() and dpv_raw.shape[0] == 1 \
-                and (dpv_raw.shape[2] * dpv_raw.shape[3]) % 4 == 0:
-            return self._forward_fused_tail(dpv_raw, img_features)
+        """Refine.py:79-107 as a module call (probabilities in, per-sample features): the autograd-capable composition of the
+        hand-written kernels (training; also what a no-grad call on the GPU runs — inference through KVNET uses forward_log).
+        On the CPU the same composition falls through to the torch modules (host-side structure tests)."""
         quarter, half, full = img_features
         from .autograd import LogSoftmaxCL, cat_cl, conv2d_module, conv_transpose2d_module, padded_in_width
 
@@ -939,4 +916,4 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         x = conv2d_module(self.conv2_2, cl(self.conv2_1, x))
         if LogSoftmaxCL.supported(x) and x.permute(0, 2, 3, 1).is_contiguous():
             return LogSoftmaxCL.apply(x)           # channels-last rows kernel; the result stays an NCHW view of that memory
-        return F.log_softmax(x, dim=1)
+        return torch.log_softmax(x, dim=1)

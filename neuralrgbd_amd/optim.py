@@ -26,9 +26,29 @@ class FusedAdam(torch.optim.Optimizer):
             st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        elif not torch.is_tensor(st["step"]):       # a checkpoint of the reference's torch era (< 1.12): `step` is a Python int
+            st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32, device=p.device)
         elif not (st["step"].is_cuda and st["step"].dtype == torch.float32):     # a torch.optim.Adam checkpoint: host-side counter
             st["step"] = st["step"].detach().to(device=p.device, dtype=torch.float32).reshape(())
         return st
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam checkpoints load as they are (train_KVNet.py:347 saves `optimizer.state_dict()`), except AMSGrad
+        ones: this kernel keeps no running maximum of the second moment, and dropping it silently would change the training."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            if group.get("amsgrad"):
+                raise _lib.NrgbdError("FusedAdam: the loaded param_group has amsgrad=True; this optimizer has no AMSGrad form")
+
+    def mark_updated(self):
+        """Advance the version counter of every parameter this optimizer owns.  The kernel writes through raw pointers, which
+        autograd's version counters do not see; the inference-side caches (nets.py: packed weight streams, the clamped-FMA unit)
+        are keyed on them.  step() calls this itself; a hipGraph REPLAY of a captured step() runs no Python, so whoever replays
+        calls it (train_step.TrainGraph does)."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.requires_grad:
+                    torch._C._increment_version(p)
 
     def init_state(self):
         """Create the state of every parameter now (before a hipGraph capture: a state created inside a capture would become
@@ -78,4 +98,7 @@ class FusedAdam(torch.optim.Optimizer):
                                          float(group["weight_decay"]), int(bool(group["maximize"])),
                                          ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             _lib.check(rc, "nrgbd_adam_step")
+            for p in group["params"]:
+                if p.grad is not None:
+                    torch._C._increment_version(p)      # like torch.optim.Adam's in-place ops (see mark_updated)
         return loss

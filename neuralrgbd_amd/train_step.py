@@ -92,7 +92,8 @@ def train(nGPU, model_KV, optimizer_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, Sr
     if grad_reducer is not None:
         grad_reducer()                 # RCCL all-reduce (sum / (A * world)) of the 21 MB fp32 gradient: buckets whose gradients
                                        # were complete started from the last window's backward hooks; this waits for all of them
-    elif A > 1:
+    if A > 1 and not (grad_reducer is not None and hasattr(grad_reducer, "prepare")):
+        # a plain callable reducer (sum / world) knows nothing about the accumulation: the mean over the A windows is taken here
         torch._foreach_div_([p.grad for p in model_KV.parameters() if p.grad is not None], float(A))
     optimizer_KV.step()
     if A == 1:
@@ -170,6 +171,17 @@ class TrainGraph:
         self.opt.step()
         return out
 
+    def _mark_updated(self):
+        """A replay of the captured optimizer step runs no Python: the parameters' version counters (the keys of the inference
+        caches in nets.py) are advanced here."""
+        if hasattr(self.opt, "mark_updated"):
+            self.opt.mark_updated()
+        else:
+            for group in self.opt.param_groups:
+                for p in group["params"]:
+                    if p.requires_grad:
+                        torch._C._increment_version(p)
+
     def _upload_constants(self, dev):
         # per-trajectory constants (intrinsics, ray table, d_candi) are uploaded once and cached per dict: do it now,
         # an upload inside the capture is not allowed
@@ -218,6 +230,7 @@ class TrainGraph:
         st["ref"].copy_(ref_frame); st["src"].copy_(src_frames); st["poses"].copy_(poses)
         st["dmap"].copy_(dmap); st["dmap_full"].copy_(dmap_full); st["bv"].copy_(bv_predict); st["inv"].copy_(inv)
         self._graph.replay()
+        self._mark_updated()
         return st["out"]
 
     # ------------------------------------------------------------------ split form: N > 1 ranks and / or accumulation
@@ -225,7 +238,9 @@ class TrainGraph:
         """Gradients of the split form live OUTSIDE the graphs: graph 1 accumulates into them over its A replays, the
         all-reduce runs on them, graph 2 reads them."""
         if self.reducer is not None:
-            self.reducer.hold = True                  # replays run no hooks; nothing may be launched from capture-time hooks
+            # replays run no hooks; nothing may be launched from capture-time hooks.  Scoped to this step: step_windows restores
+            # the caller's setting when it returns (an eager train(..., grad_reducer=reducer) afterwards overlaps again)
+            self.reducer.hold = True
             self.reducer.prepare(self.accum)
             return
         if self._grads is None:
@@ -245,6 +260,14 @@ class TrainGraph:
         Returns (mean loss, [BV_predict of each window's next frame]) — clones, valid until overwritten by the caller."""
         if len(windows) != self.accum:
             raise ValueError("%d windows for accum_steps=%d" % (len(windows), self.accum))
+        hold0 = getattr(self.reducer, "hold", None)
+        try:
+            return self._step_windows(windows)
+        finally:
+            if self.reducer is not None and hold0 is not None:
+                self.reducer.hold = hold0
+
+    def _step_windows(self, windows):
         invs = [ops.pose_inverse(w[2][0, self.t_win_r].to(dtype=torch.float32).contiguous()) for w in windows]
         keys = ("ref", "src", "poses", "dmap", "dmap_full", "bv")
         if self._needs_eager():
@@ -279,4 +302,5 @@ class TrainGraph:
             losses.append(st["out"][0].clone()); preds.append(st["out"][1].clone())
         self._reduce_grads()
         self._g_opt.replay()
+        self._mark_updated()
         return torch.stack(losses).mean(), preds

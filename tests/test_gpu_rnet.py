@@ -85,9 +85,11 @@ def test_last_conv_with_planar_log_softmax(H, W):
     assert err < 3e-5 and int((got.argmax(1) != want.argmax(1)).sum()) == 0
 
 
-@pytest.mark.parametrize("channels_last_feats,D", [(False, 64), (True, 64), (True, 128)])
+@pytest.mark.parametrize("channels_last_feats,D", [(False, 64), (True, 64), (True, 128), (True, 16), (False, 8), (True, 24), (True, 32), (True, 100)])
 def test_whole_rnet_matrix_core_path_vs_modules(channels_last_feats, D):
-    """D = 64 (configs S, B, K) and D = 128 (config H: 192 / 160 / 131-channel layers as output-column slices)."""
+    """D = 64 (configs S, B, K) and D = 128 (config H: 192 / 160 / 131-channel layers as output-column slices); any other
+    candidate count zero-padded to the next of the two (round 5: D = 16 — the reference-golden stream and smoke() — used to
+    take MIOpen's convolutions)."""
     from neuralrgbd_amd import nets
     h, w = 48, 64
     net = nets.DPVUpsampleNet(64, 32, 3, D=D)

@@ -664,3 +664,60 @@ def test_fused_adam_vs_torch_adam_and_under_a_hipgraph():
     for i, (a, b) in enumerate(zip(pa, pb)):
         assert (a - b).abs().max().item() <= 4e-6 * max(1.0, b.abs().max().item()), (i, shapes[i])
         assert int(oa.state[a]["step"].item()) == int(ob.state[b]["step"].item())
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_inference_after_a_fused_adam_step_uses_the_updated_weights(graph):
+    """FusedAdam writes the parameters through raw pointers; the inference caches of nets.py (packed weight
+    streams, the clamped-FMA unit of the K-Net) are keyed on tensor versions.  infer (caches populated) -> optimizer step (eager, or
+    the replay of a captured step) -> infer must equal a FRESH model loaded with the updated weights, bit for bit."""
+    import copy
+    import neuralrgbd_amd
+    from neuralrgbd_amd.optim import FusedAdam
+    from neuralrgbd_amd.test_step import test as infer
+    from neuralrgbd_amd.train_step import TrainGraph, train
+    H, W, D = 256, 256, 16
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(0.1, 5, D)
+    model = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    model.load_state_dict(synth.seeded_state_dict(model, 0))
+    model = model.to(DEV)
+    opt = FusedAdam(model.parameters(), lr=3e-3, betas=(.9, .999))      # a large step: stale caches would be visible
+    rng = np.random.RandomState(3)
+
+    def window(i):
+        r, s, p = synth.noise_window(170 + i, H, W)
+        return (r, s, p, torch.from_numpy(rng.randint(0, D, (1, H // 4, W // 4))), torch.from_numpy(rng.randint(0, D, (1, H, W))))
+
+    def two_frames(m):
+        pred, outs = None, []
+        for i in (0, 1):
+            r, s, p, _, _ = window(10 + i)
+            dpv, pred = infer(m, d_candi, [cam], 2, [{"img": r}], [[{"img": s[0, v:v + 1]} for v in range(4)]], p, pred, R_net=True)
+            outs += [dpv.clone(), pred.clone()]
+        return outs
+
+    before = two_frames(model)                                        # populates every inference cache
+    v0 = model.kv_net.dres1[0][0].weight._version
+    pred = None
+    tg = TrainGraph(model, opt, 2, d_candi, cam, warmup=2) if graph else None
+    for i in range(4 if graph else 2):
+        r, s, p, dm, dmf = window(i)
+        if graph and pred is not None:
+            _, nxt = tg.step(r.to(DEV), s.to(DEV), p.to(DEV), dm.to(DEV), dmf.to(DEV), pred)
+            pred = nxt.clone()
+        else:
+            _, pred, _, _, _ = train(1, model, opt, 2, d_candi, [{"img": r, "dmap": dm, "dmap_imgsize_digit": dmf}],
+                                     [[{"img": s[0, v:v + 1]} for v in range(4)]], p, pred, [cam])
+    if graph:
+        assert tg._graph is not None                                   # the last step was a replay
+    assert model.kv_net.dres1[0][0].weight._version > v0
+    after = two_frames(model)
+    fresh = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    fresh.load_state_dict(copy.deepcopy(model.state_dict()))
+    fresh = fresh.to(DEV)
+    # BatchNorm running statistics do not enter train-mode outputs; everything else is the same state
+    want = two_frames(fresh)
+    assert not torch.equal(after[2], before[2])                        # the step moved the update-branch DPV
+    for a, b in zip(after, want):
+        assert torch.equal(a, b)
