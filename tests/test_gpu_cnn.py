@@ -114,10 +114,10 @@ def test_shapes_without_a_kernel_raise_instead_of_reaching_the_vendor_library():
     from neuralrgbd_amd._lib import NrgbdError
     fe = nets.FeatureExtractor(feature_dim=48, multi_scale=True).to(DEV)          # 1x1 head 128 -> 48: no instantiation
     with torch.no_grad(), pytest.raises(NrgbdError):
-        fe.forward_channels_last(torch.rand(2, 3, 64, 64, device=DEV))
+        fe.forward_channels_last(torch.rand(2, 3, 256, 256, device=DEV))
     fe = nets.FeatureExtractor(feature_dim=64, multi_scale=True).to(DEV)
     with torch.no_grad(), pytest.raises(NrgbdError):
-        fe.forward_channels_last(torch.rand(2, 3, 66, 64, device=DEV))            # image side not a multiple of 4
+        fe.forward_channels_last(torch.rand(2, 3, 258, 256, device=DEV))          # image side not a multiple of 4
     rn = nets.DPVUpsampleNet(64, 32, 3, D=16, upsample_D=True).to(DEV)            # candidate up-sampling: never selected by the reference's scripts
     with torch.no_grad(), pytest.raises(NrgbdError):
         rn.forward_log(torch.log_softmax(torch.randn(1, 16, 8, 8, device=DEV), 1),
