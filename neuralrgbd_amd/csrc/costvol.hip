@@ -174,8 +174,10 @@ extern "C" int nrgbd_costvol_fwd_gen(const float* ref_nhwc, const float* src_nhw
     CostvolArgs a{ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, out_cost, out_logp, cx, cy, sigma,
                   dist, align_corners, V, C, Cp, D, h, w, 0, 0, 1, D, 0,
                   (float)(1.0 / (double)cx), (float)(1.0 / (double)cy), (float)(1.0 / (double)sigma)};
+    a.trace = nullptr;
 #ifdef NRGBD_DEV
     a.debug = dev_env_int("NRGBD_ABLATE");
+    if (const char* tp = getenv("NRGBD_CV_TRACE")) a.trace = reinterpret_cast<long long*>(strtoull(tp, nullptr, 0));
 #endif
     hipStream_t s = (hipStream_t)stream;
     // AUTO: generation 3 (quad) for the path's own texel (64 feature channels [+ RGB word]); generation 2 (LDS, lane =

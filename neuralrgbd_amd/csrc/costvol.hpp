@@ -21,6 +21,7 @@ struct CostvolArgs {
     int nchunk, kchunk;    // quad generation: candidate chunks per tile / candidates per chunk (set by the launcher)
     int fuse_softmax;      // quad generation: the workgroup owns all D candidates and also writes out_logp
     float rcx, rcy, rsigma;  // quad generation: RN(1/cx), RN(1/cy), RN(1/sigma) (host, double precision) for div_by_const
+    long long* trace;      // developer builds: per-workgroup phase clocks [workgroups][24] (tools/cv_trace.py); null in the product library
 };
 
 // Developer ablation bits are compiled out of the product library: a stray environment variable must never change results.

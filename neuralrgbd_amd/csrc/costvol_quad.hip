@@ -33,12 +33,31 @@
 // coordinates); only the order of the channel sum differs (16 channels per lane, then the quad), like any other reduction order.
 #include "costvol.hpp"
 
+// developer builds: phase clocks of a workgroup as seen by its thread 0 (a.trace, tools/cv_trace.py); compiled out of the product
+#ifdef NRGBD_DEV
+#define CVT_DECL long long cvt_[24] = {0}; long long cvt_t0_ = 0; const bool cvt_on_ = a.trace != nullptr && threadIdx.x == 0; \
+    if (cvt_on_) { cvt_[0] = wall_clock64(); cvt_[2] = -clock64(); }
+#define CVT_BEGIN() do { if (cvt_on_) cvt_t0_ = clock64(); } while (0)
+#define CVT_END(slot) do { if (cvt_on_) cvt_[slot] += clock64() - cvt_t0_; } while (0)
+#define CVT_COUNT(slot, n) do { if (cvt_on_) cvt_[slot] += (n); } while (0)
+#define CVT_FLUSH() do { if (cvt_on_) { cvt_[1] = wall_clock64(); cvt_[2] += clock64(); \
+    unsigned hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); cvt_[17] = hw_; \
+    unsigned xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); cvt_[18] = xcc_; \
+    for (int q_ = 0; q_ < 24; ++q_) a.trace[(size_t)blockIdx.x * 24 + q_] = cvt_[q_]; } } while (0)
+#else
+#define CVT_DECL
+#define CVT_BEGIN() do {} while (0)
+#define CVT_END(slot) do {} while (0)
+#define CVT_COUNT(slot, n) do {} while (0)
+#define CVT_FLUSH() do {} while (0)
+#endif
+
 namespace nrgbd {
 
 namespace {
 
 constexpr int kQT = 8;            // tile edge
-constexpr int kQRun = 16;         // candidates per staged run (groups of 4)
+constexpr int kQRun = 32;         // candidates per staged run at most (groups of 4): two 16-lane DPP rows of footprint boxes
 // texels of the patch (x 272 B): 188 texels = 50 KB + 20 B per candidate -> 3 workgroups per CU; the views' partial costs meet
 // in global memory.  (Round 3's generation 4 kept them in LDS accumulators next to a 128-texel patch: bit-identical and slower,
 // 415 vs 281 us at config B — profiles/r3_costvol_gen4.txt; removed in round 4.)
@@ -132,6 +151,7 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     constexpr bool EXTRA = TAIL != 0;
     constexpr int kQPatch = PATCH, kQPatchR = (PATCH + 63) / 64 * 64;   // RGB plane: a wave instruction fills 64 slots
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    CVT_DECL
     char* ldsF = smem;                                                  // [kQPatch][256 B]
     char* ldsR = smem + kQPatch * kQFeatBytes;                          // [kQPatchR][16 B]
     int4* boxes = reinterpret_cast<int4*>(ldsR + kQPatchR * 16);        // [D] footprint of the tile per candidate (this view)
@@ -155,6 +175,9 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
             const int r = u >> 5, c = u & 31;
             u = (r << 5) | ((c * 5 + r * 11) & 31);
         }
+        // (Round 5 tried giving every XCD two half-bands, one from the front of the list and its mirror image from the back, so
+        // that a linear cost gradient over the image cancels: 236 vs 234 us, no effect — the workgroups' durations spread 1.9x
+        // inside every XCD, profiles/r5_costvol_limits.txt.)
         id = (blockIdx.x & 7) * per + u;
     }
     const int tile = id / a.nchunk, chunk = id - tile * a.nchunk;
@@ -295,7 +318,8 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
         return keep + rgbpart;
     };
     using T_ = std::true_type; using F_ = std::false_type;
-    using N1 = std::integral_constant<int, 1>; using N2 = std::integral_constant<int, 2>; using N4 = std::integral_constant<int, 4>;
+    using N1 = std::integral_constant<int, 1>; using N2 = std::integral_constant<int, 2>; using N3 = std::integral_constant<int, 3>;
+    using N4 = std::integral_constant<int, 4>;
 
     // Loop order: views OUTER.  All workgroups of an XCD (one band of tiles) sweep the same source view at about the same
     // time, so the band's footprint in ONE view (~2 MB) is what has to live in the 4 MB L2 — with the views inside the
@@ -309,8 +333,9 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
         const SweepTerm st = make_sweep_term(KRv, Ktv, rx, ry, rz);
         // ---- footprint of the tile on every candidate plane of this view: thread = (candidate, tile corner); the sampling
         // positions of the 4 corner pixels bound the taps of the whole tile (a homography maps the convex tile onto a convex
-        // quadrilateral as long as the plane stays in front of the source camera: `bad` otherwise).  Box = their bounding
-        // box + 1 texel of slack, inside [-1, w] x [-1, h] (apron), at least 2 x 2 ----
+        // quadrilateral as long as the plane stays in front of the source camera: `bad` otherwise).  Box = the texels their
+        // bounding box touches, inside [-1, w] x [-1, h] (apron), at least 2 x 2 ----
+        CVT_BEGIN();
         __syncthreads();                                       // the previous view's boxes / the prologue's dcand
         for (int c0 = kb; c0 < ke; c0 += 64) {
             const int c = c0 + (tid >> 2), cr = tid & 3;
@@ -335,20 +360,30 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
             bad |= dpp_i<kXor2>(bad);
             if (c < ke && cr == 0) {
                 int4 b;
-                const float mnx = fmaxf(fxlo, -4.f), mxx = fminf(fxhi, wf + 4.f);
-                const float mny = fmaxf(fylo, -4.f), mxy = fminf(fyhi, hf + 4.f);
-                b.x = min(max((int)floorf(mnx) - 1, -1), a.w - 1);
-                b.y = min(max((int)floorf(mxx) + 2, b.x + 1), a.w);
-                b.z = min(max((int)floorf(mny) - 1, -1), a.h - 1);
-                b.w = min(max((int)floorf(mxy) + 2, b.z + 1), a.h);
+                // TIGHT box (round 5): a pixel's taps are texels floor(i) and floor(i) + 1; over the tile floor(i) ranges over
+                // [floor(min), floor(max)] of the corner positions (convexity), so the box is [floor(min), floor(max) + 1] — with
+                // 1/64 texel of guard for the fp32 evaluation of interior pixels against the corners' (their positions agree
+                // with exact arithmetic to ~1e-4 texel).  Rounds 2-4 carried one more texel on every side: an 8x8 tile at unit
+                // scale filled 11 x 11 = 121 texels per candidate instead of 9 x 9 = 81, and a patch held 2/3 of the candidates.
+                const float mnx = fmaxf(fxlo, -4.f) - 0.015625f, mxx = fminf(fxhi, wf + 4.f) + 0.015625f;
+                const float mny = fmaxf(fylo, -4.f) - 0.015625f, mxy = fminf(fyhi, hf + 4.f) + 0.015625f;
+                b.x = min(max((int)floorf(mnx), -1), a.w - 1);
+                b.y = min(max((int)floorf(mxx) + 1, b.x + 1), a.w);
+                b.z = min(max((int)floorf(mny), -1), a.h - 1);
+                b.w = min(max((int)floorf(mxy) + 1, b.z + 1), a.h);
                 if (bad) { b.x = -(1 << 20); b.y = 1 << 20; b.z = -(1 << 20); b.w = 1 << 20; }   // unbounded: never fits
                 boxes[c] = b;
             }
         }
         __syncthreads();
+        CVT_END(3);
         for (int lo = kb, hi = ke; lo < hi;) {
-            // ---- largest run of 16 / 8 / 4 / 2 candidates whose united footprint fits the patch: lane l < 16 of every wave
-            // holds the l-th next candidate, inclusive prefix union along the 16-lane DPP row ----
+            CVT_BEGIN();
+            // ---- longest run of the next candidates (up to 32) whose united footprint fits the patch: lane l < 32 of every wave
+            // holds the l-th next candidate, inclusive prefix union along the two 16-lane DPP rows (the second row joins the
+            // first row's total), every lane tests ITS prefix, and the run length is the number of leading lanes that fit —
+            // any length, not only 16 / 8 / 4 / 2 (round 5: one ballot instead of five rounds of four v_readlane + scalar
+            // compares; the selection took 8 % of a workgroup's time, profiles/r5_costvol_diag_before.txt) ----
             const int nmax = min(kQRun, hi - lo);
             int4 bx = make_int4(1 << 30, -(1 << 30), 1 << 30, -(1 << 30));
             if (lane < nmax) bx = boxes[rev ? hi - 1 - lane : lo + lane];
@@ -359,15 +394,19 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
             bx.w = max(bx.w, __builtin_amdgcn_update_dpp(-(1 << 30), bx.w, 0x110 + SH, 0xf, 0xf, false));
             NRGBD_ROW_SHR_UNION(1) NRGBD_ROW_SHR_UNION(2) NRGBD_ROW_SHR_UNION(4) NRGBD_ROW_SHR_UNION(8)
 #undef NRGBD_ROW_SHR_UNION
-            int n = 0, xlo = 0, xhi = 1, ylo = 0, yhi = 1;
-#pragma unroll
-            for (int tryn = kQRun; tryn >= 1; tryn >>= 1) {
-                const int l = tryn - 1;       // the lane holding the union of the next tryn candidates
-                const int uxlo = __builtin_amdgcn_readlane(bx.x, l), uxhi = __builtin_amdgcn_readlane(bx.y, l);
-                const int uylo = __builtin_amdgcn_readlane(bx.z, l), uyhi = __builtin_amdgcn_readlane(bx.w, l);
-                if (n == 0 && tryn <= nmax && (long)(uxhi - uxlo + 1) * (uyhi - uylo + 1) <= kQPatch) {
-                    n = tryn; xlo = uxlo; xhi = uxhi; ylo = uylo; yhi = uyhi;
-                }
+            if (nmax > 16) {                                   // block-uniform
+                const int r0x = __builtin_amdgcn_readlane(bx.x, 15), r0y = __builtin_amdgcn_readlane(bx.y, 15);
+                const int r0z = __builtin_amdgcn_readlane(bx.z, 15), r0w = __builtin_amdgcn_readlane(bx.w, 15);
+                if (lane >= 16) { bx.x = min(bx.x, r0x); bx.y = max(bx.y, r0y); bx.z = min(bx.z, r0z); bx.w = max(bx.w, r0w); }
+            }
+            const int bwd = bx.y - bx.x + 1, bht = bx.w - bx.z + 1;      // 2^21 for an unbounded box: test the sides before the product
+            const bool fit = lane < nmax && bwd <= kQPatch && bht <= kQPatch && bwd * bht <= kQPatch;
+            // prefix unions only grow, so the lanes that fit are a prefix of the wave: its length is the run
+            int n = (int)__builtin_ctzll(~__ballot(fit));
+            int xlo = 0, xhi = 1, ylo = 0, yhi = 1;
+            if (n >= 1) {
+                xlo = __builtin_amdgcn_readlane(bx.x, n - 1); xhi = __builtin_amdgcn_readlane(bx.y, n - 1);
+                ylo = __builtin_amdgcn_readlane(bx.z, n - 1); yhi = __builtin_amdgcn_readlane(bx.w, n - 1);
             }
             // a single candidate whose footprint fits could be staged as well (developer bit 32): measured 300 us vs 287 us
             // at config B — a patch fill + two barriers for 64 (pixel, candidate) pairs costs more than their 16 global loads
@@ -376,13 +415,18 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
             const int j0 = rev ? hi - n : lo;                  // the run: candidates j0 .. j0 + n - 1
             const int ngroups = (n + 3) >> 2;
             const int cols = xhi - xlo + 1;
+            CVT_END(4);
+            if (staged) { CVT_COUNT(n >= 16 ? 10 : n >= 8 ? 11 : n >= 4 ? 12 : 13, 1); CVT_COUNT(15, n); CVT_COUNT(19, (long long)cols * (yhi - ylo + 1)); } else CVT_COUNT(14, 1);
 
             if (staged) {
                 const int area = cols * (yhi - ylo + 1);
                 const float inv_cols = 1.0f / (float)cols;     // q / cols = (int)((q + 0.5) * inv_cols): exact for q, cols <= 192
                 const int cpb = a.Cp * 4;
                 const char* svb = reinterpret_cast<const char*>(sv);
+                CVT_BEGIN();
                 __syncthreads();                               // the previous patch has been read by every wave
+                CVT_END(16);
+                CVT_BEGIN();
                 // ---- stage: L2 -> LDS without touching VGPRs; a wave instruction = 4 texels x 256 B (feature plane) or
                 // 64 texels x 16 B (RGB plane), landing in lane order = patch order ----
                 // a patch wholly inside the image (the common case) needs no coordinate clamps: texel (qx, qy) of the patch
@@ -431,9 +475,13 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
                         }
                     }
                 }
+                CVT_END(5);
+                CVT_BEGIN();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                CVT_END(6);
             }
+            CVT_BEGIN();
             if (!NRGBD_DBG(a, 2)) {
 #pragma unroll 1
                 for (int g = 0; g < ngroups; ++g) {
@@ -444,15 +492,18 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
                     if (!staged) acc = group(F_{}, N4{}, sv, st, k0, nc, 0, 0, 0, 0, 0);
                     else if (nc == 1) acc = group(T_{}, N1{}, sv, st, k0, 1, xlo, xhi, ylo, yhi, cols);
                     else if (nc == 2) acc = group(T_{}, N2{}, sv, st, k0, 2, xlo, xhi, ylo, yhi, cols);
+                    else if (nc == 3) acc = group(T_{}, N3{}, sv, st, k0, 3, xlo, xhi, ylo, yhi, cols);
                     else acc = group(T_{}, N4{}, sv, st, k0, 4, xlo, xhi, ylo, yhi, cols);
                     if (inside && j < nc) *o = prev + div_by_const(acc, a.sigma, a.rsigma);   // homography.py:325 (/ sigma), views in order
                 }
             }
+            if (staged) CVT_END(7); else CVT_END(8);
             if (rev) hi -= n; else lo += n;
         }
     }
 
-    if (!a.fuse_softmax) return;
+    if (!a.fuse_softmax) { CVT_FLUSH(); return; }
+    CVT_BEGIN();
     // ---- log_softmax(-cost) over the D candidates of the tile's pixels (models/basic.py:299-300) ----
     // thread = (pixel, quarter of the candidates); the costs were written by other lanes of THIS workgroup: make the stores
     // visible (L2) and read them past the L1
@@ -491,6 +542,8 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
             }
         }
     }
+    CVT_END(9);
+    CVT_FLUSH();
 }
 
 bool costvol_quad_supported(const CostvolArgs& a) {
