@@ -162,25 +162,32 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     const int quad = tid >> 2, j = tid & 3, i3 = quad & 3;
     // workgroup -> (tile, candidate chunk); XCD k (= blockIdx % 8) owns a contiguous eighth of the tile list so that the
     // source rows a band of tiles samples stay in ONE 4 MB L2
-    int id = blockIdx.x;
-    if ((gridDim.x & 7) == 0) {
-        const int per = gridDim.x >> 3;          // workgroups of one XCD = its band of the tile list
-        int u = blockIdx.x >> 3;
+    // workgroup -> (tile, candidate chunk).  XCD k (= blockIdx % 8) owns a contiguous eighth of the TILE list so that the source rows
+    // a band of tiles samples stay in ONE 4 MB L2; with several chunks per tile the XCD's workgroups are ordered chunk-major —
+    // every tile's NEAREST chunk first: those are the expensive ones (short runs, unstaged groups: 2-3x the time of a far chunk,
+    // profiles/r5_costvol_diag_before.txt), and the hardware hands out workgroups in index order as slots free up, so the
+    // cheap far chunks fill in behind the slow near ones (longest-processing-time-first) instead of a slow chunk starting last.
+    const int ntiles = gridDim.x / a.nchunk;
+    int tile = blockIdx.x / a.nchunk, chunk = blockIdx.x - tile * a.nchunk;
+    if ((ntiles & 7) == 0) {
+        const int per = ntiles >> 3;             // tiles of one XCD = its band of the tile list
+        const int uu = blockIdx.x >> 3;
+        chunk = uu / per;
+        int u = uu - chunk * per;
         // Inside the band the tiles are handed out in a scrambled order (developer bit 64 turns it off): the workgroups that
         // share a CU (consecutive or 32 apart in an XCD's dispatch order) then come from tiles ~5 columns / a row + 11
         // columns apart instead of neighbours.  A tile's cost (how many near-plane runs go to global memory) varies
         // smoothly over the image, so neighbours on one CU could make slow CUs and fast CUs.  Measured: 277 vs 280 us at
         // config B (within run-to-run noise) — per-CU load imbalance is not what limits the kernel.
+        // (Round 5 tried giving every XCD two half-bands, one from the front of the list and its mirror image from the back, so
+        // that a linear cost gradient over the image cancels: 236 vs 234 us, no effect — the workgroups' durations spread 1.9x
+        // inside every XCD, profiles/r5_costvol_limits.txt.)
         if ((per & 31) == 0 && !NRGBD_DBG(a, 64)) {
             const int r = u >> 5, c = u & 31;
             u = (r << 5) | ((c * 5 + r * 11) & 31);
         }
-        // (Round 5 tried giving every XCD two half-bands, one from the front of the list and its mirror image from the back, so
-        // that a linear cost gradient over the image cancels: 236 vs 234 us, no effect — the workgroups' durations spread 1.9x
-        // inside every XCD, profiles/r5_costvol_limits.txt.)
-        id = (blockIdx.x & 7) * per + u;
+        tile = (blockIdx.x & 7) * per + u;
     }
-    const int tile = id / a.nchunk, chunk = id - tile * a.nchunk;
     // Developer switch (NRGBD_ABLATE bit 16): every other workgroup walks its candidates far -> near, to de-phase the
     // staging-bound (near planes) and math-bound (far planes) parts of co-resident workgroups.  Measured: 288 us with,
     // 277 us without at config B — the workgroups are not phase-locked; kept off.
