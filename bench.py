@@ -272,12 +272,41 @@ def parity_block(cfg, gpu, oracle_out):
     # (the policy of the parity tests, DESIGN.md §3: 0-2 such ties per frame are measured at S / B / H, up to 6 at K, none beyond a tie)
     depth_vols = ("refined", "dpv", "bv_cur")
     l1 = all(blk[n]["mean"] < 1e-4 for n in names)
-    blk["pass_strict"] = l1 and all(blk[n]["argmax_mismatch"] == 0 for n in depth_vols)
-    blk["pass"] = l1 and all(blk[n]["argmax_mismatch_beyond_tie_1e-3"] == 0 and blk[n]["argmax_mismatch"] <= 8 for n in depth_vols)
+    blk["max_abs_gate"] = MAX_ABS_GATE
+    mx = all(blk[n]["max"] <= MAX_ABS_GATE for n in names)
+    blk["pass_strict"] = l1 and all(blk[n]["max"] <= 1e-4 for n in names) and all(blk[n]["argmax_mismatch"] == 0 for n in depth_vols)
+    blk["pass"] = l1 and mx and all(blk[n]["argmax_mismatch_beyond_tie_1e-3"] == 0 and blk[n]["argmax_mismatch"] <= (32 if n == "refined" else 8)
+                                    for n in depth_vols)
     # a trilinear resample is a convex combination: with the pose inverse owned by the path (same matrix on both sides)
     # BV_predict cannot differ by more than the DPV it resamples does
     blk["pass"] = blk["pass"] and blk["bv_predict"]["max"] <= blk["dpv"]["max"] + 2e-4
     return blk
+
+
+def other_configs(skip, timeout_s=240):
+    """BASELINE.json's other configurations on the same lease, each as a short child run of this script (5 steps after 3 warm-up
+    frames, no CPU baseline, no counter passes): {frames/s, ms per frame, the sampling kernel's time and fraction of the HBM roofline};
+    plus one `--mode train` step pair at config 4's shape.  Driver-visible companions of the headline number, not part of it."""
+    import subprocess
+    out = {}
+    base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-live-traffic", "--no-other-configs"]
+    for cfg in [c for c in ("S", "K", "H") if c != skip]:
+        try:
+            r = subprocess.run(base + ["--config", cfg, "--steps", "5", "--warmup", "3"], capture_output=True, text=True, timeout=timeout_s)
+            doc = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            out[cfg] = {"workload": doc["config"]["workload"], "frames_per_s": doc["value"], "ms_per_frame": doc["ms_per_step"],
+                        "costvol_kernel_ms": doc["roofline"]["kernel_ms"], "costvol_hbm_frac": doc["roofline"]["frac"],
+                        "knet_layer_mfma_frac": doc.get("roofline_mfma", {}).get("frac"), "steps": 5, "warmup": 3}
+        except Exception as e:      # a companion must never cost the headline line
+            out[cfg] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    try:
+        r = subprocess.run(base + ["--mode", "train", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=timeout_s)
+        doc = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        out["train"] = {"workload": doc["config"]["workload"], "windows_per_s": doc["value"], "ms_per_window": doc["ms_per_window"],
+                        "ms_per_step": doc["ms_per_step"], "accum_steps": doc["config"]["accum_steps"], "launch": doc["config"]["launch"], "steps": 2, "warmup": 1}
+    except Exception as e:
+        out["train"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return out
 
 
 def respawn_under_torchrun(gpus):
@@ -299,12 +328,29 @@ FP64_FIXTURES = {   # config -> (file under tests/golden, window seeds, pixel st
     "S": ("net_fp64_S.npz", (101, 102), 4),     # oracle/gen_golden.py::gen_fp64_S
     "B": ("net_fp64_B.npz", (131, 132), 8),     # oracle/gen_golden.py::gen_fp64_B
 }
+MAX_ABS_GATE = 1e-3      # = tests/conftest.py::MAX_ABS_TOL
 TOLERANCE_POLICY = (
     "north_star: arg-max depth index bit-exact, DPV floats within 1e-4.  Asserted here (pass): mean |d| (L1) < 1e-4 on every volume; "
-    "arg-max identical except at pixels whose two best candidates are within 1e-3 in the ORACLE's own volume (ties: <= 8 per frame and "
-    "volume, none beyond a tie); max|d| is REPORTED, not gated at 1e-4 — a builder-authored relaxation: the reference's own fp32 CPU "
-    "evaluation is 1e-3-class (max) away from the same graph in float64 (the `fp64` sub-block: |oracle - fp64| beside |GPU - fp64|), so "
-    "two fp32 evaluations of a 70-layer network cannot agree to 1e-4 max or on exact ties.  pass_strict = the gates as north_star words them.")
+    "max |d| <= 1e-3 on every volume (HARD); arg-max identical except at pixels whose two best candidates are within 1e-3 in the ORACLE's "
+    "own volume (ties: <= 8 per frame and quarter-resolution volume, <= 32 on the full-resolution refined volume, none beyond a tie).  Why "
+    "not 1e-4 max: the `ref_self` sub-block — the UNMODIFIED reference against ITSELF on the config-S windows when only its execution "
+    "changes (oneDNN convolutions on / off, 8 threads / 1; tests/golden/ref_selfnoise_S.npz, oracle/gen_golden.py selfnoise) — differs by up "
+    "to 6.2e-4 (max) in DPV; the `fp64` sub-block shows both fp32 evaluations 1e-3-class (max) away from the same graph in float64.  "
+    "pass_strict = the gates as north_star words them (max <= 1e-4, no arg-max flip at all).")
+
+
+def ref_self_block():
+    """What two executions of the unmodified reference agree to (tests/golden/ref_selfnoise_S.npz): per volume of the update frame
+    [max |d|, mean |d|, arg-max flips, flips beyond a 1e-3 tie, pixels]."""
+    path = os.path.join(ROOT, "tests", "golden", "ref_selfnoise_S.npz")
+    if not os.path.isfile(path):
+        return None
+    g = np.load(path)
+    blk = {"fixture": "tests/golden/ref_selfnoise_S.npz", "config": "S (two frames, noise windows, seeds 101 / 102)",
+           "layout": "[max |d|, mean |d|, arg-max flips, flips beyond a 1e-3 tie, pixels]"}
+    for var in ("onednn_off", "threads_1"):
+        blk[var] = {k: [float(x) for x in g["%s_%s_f2" % (var, k)]] for k in ("refined", "dpv", "bv_cur", "pred")}
+    return blk
 
 
 def fp64_block(cfg, model, cam, d_candi, H, W, dev):
@@ -372,7 +418,51 @@ def verified_ranks(world, device):
         return 1
     t = torch.ones(1, dtype=torch.float32, device=device)
     torch.distributed.all_reduce(t)
-    return int(round(float(t.item())))
+    n = int(round(float(t.item())))
+    if n != world:
+        raise SystemExit("the collective saw %d ranks, the launch has %d" % (n, world))
+    return n
+
+
+def rank_times(world, steps, device):
+    """ms per step of every rank: its own work (before the closing barrier) gathered from all ranks — stragglers show here."""
+    own = getattr(timed_steps, "own", None)
+    if own is None:
+        return None
+    if world == 1:
+        return {"own_ms_per_step": [1e3 * own / steps]}
+    t = torch.tensor([own], dtype=torch.float64, device=device)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    torch.distributed.all_gather(allt, t)
+    v = [1e3 * float(x.item()) / steps for x in allt]
+    return {"own_ms_per_step": v, "min": min(v), "max": max(v), "timed_region_ms_per_step": [1e3 * x / steps for x in timed_steps.per_rank]}
+
+
+def allreduce_probe(reducer, world, device, reps=10):
+    """The bucketed gradient all-reduce ALONE (the same buckets, the same index order, no backward around it): ms per call and
+    the bus bandwidth a ring all-reduce of that size implies, 2 (N - 1) / N x bytes / time, beside one xGMI link's 153 GB/s."""
+    if reducer is None or world == 1:
+        return None
+    nbytes = 4 * reducer.numel
+    for _ in range(2):
+        reducer.prepare()
+        reducer()
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        reducer.prepare()
+        reducer()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    t = torch.tensor([ms], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    ms = float(t.item())
+    return {"allreduce_ms": ms, "bytes": nbytes, "buckets": len(reducer.buckets),
+            "bus_gb_s": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, "xgmi_link_gb_s": 153.0,
+            "note": "prepare (zero the buckets) + %d all-reduces + division, max over ranks" % len(reducer.buckets)}
 
 
 def timed_steps(frame, steps, world, device):
@@ -387,12 +477,20 @@ def timed_steps(frame, steps, world, device):
     t0 = time.perf_counter()
     for i in range(steps):
         frame(i)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    timed_steps.own = time.perf_counter() - t0          # this rank's own work, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
+    timed_steps.per_rank = [dt]
     if world > 1:
+        # every rank's own clock around the same barrier-bracketed region (MAX = the contract's number; MIN beside it shows a
+        # straggler: with the closing barrier inside the region the two differ only by the barrier's own skew)
         t = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allt, t)
+        timed_steps.per_rank = [float(x.item()) for x in allt]
+        dt = max(timed_steps.per_rank)
     return dt
 
 
@@ -475,6 +573,8 @@ def train_main(args):
         step(i + 2)
     dt = timed_steps(step, args.steps, world, dev)
     assert bool(torch.isfinite(state["loss"])), "training loss went non-finite"
+    per_rank = rank_times(world, args.steps, dev)
+    ar = allreduce_probe(reducer, world, dev)
     if rank == 0:
         line = {"metric": "training windows/sec @grid 96x64x64cand, 5-view window, N=1 per forward (BASELINE config 4 shape)",
                 "value": args.steps * A * world / dt, "unit": "windows/s", "n_gpus": world, "rccl_ranks": ranks, "steps": args.steps,
@@ -487,6 +587,10 @@ def train_main(args):
                            "parallelism": "data-parallel x%d, %d windows per rank and step, one bucketed gradient all-reduce per step (%.2f MB fp32)" %
                                           (world, A, 4e-6 * sum(p.numel() for p in set(model.parameters()))),
                            "loss": float(state["loss"])}}
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+        if ar is not None:
+            line["allreduce"] = ar
         if knet_timer.last is not None:
             c_ms = knet_timer.measure(20, warm=30)
             a0 = knet_timer.last[0][0]
@@ -518,6 +622,8 @@ def main():
                     "--pmc child passes of this script (about a minute; N = 1 only)")
     ap.add_argument("--streams", type=int, default=1, help="independent video streams per GPU, each on its own HIP stream "
                     "(a step is then one frame of EVERY stream; the extra streams fill the tails of each other's kernels)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short companion runs of configs S / K / H and of one "
+                    "training step (N = 1, headline config only; about a minute)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU self-test of the N>1 harness
     ap.add_argument("--accum", type=int, default=4, help="--mode train: windows per GPU and optimizer step (gradient accumulation; "
                     "BASELINE config 4 = global batch 32 = 8 GPUs x 4)")
@@ -587,6 +693,7 @@ def main():
     dt = timed_steps(frame, args.steps, world, dev)
     pred = stream.bv_predict
     assert bool(torch.isfinite(pred).all()), "filter state went non-finite"
+    per_rank = rank_times(world, args.steps, dev)
 
     if rank == 0:
         n_k = max(args.steps, 20)
@@ -615,6 +722,8 @@ def main():
                          "timing": "HIP events around back-to-back launches of the frame's own costvol call (log-softmax launch included), after 20 untimed ones, right after the timed region",
                          "traffic": traffic, "traffic_source": traffic_note},
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         if sq:
             # the HBM target is structurally out of reach for this kernel (118 flop/B against a machine balance of 20, SURVEY.md
             # 8d): what binds it is VALU issue and the LDS gather — their utilisation from the kernel's own SQ counters
@@ -651,6 +760,11 @@ def main():
             f64 = fp64_block(args.config, model, cam, d_candi, H, W, dev)
             if f64 is not None:
                 line["parity"]["fp64"] = f64
+            rs = ref_self_block()
+            if rs is not None:
+                line["parity"]["ref_self"] = rs
+        if world == 1 and args.config == "B" and not args.no_other_configs and not args.no_graph and S == 1:
+            line["other_configs"] = other_configs(args.config)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

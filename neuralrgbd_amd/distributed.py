@@ -81,7 +81,7 @@ class GradAllReduce:
     hipGraph, whose replays run no hooks; every bucket is then launched from `__call__`, in index order as always).
     """
 
-    def __init__(self, module, bucket_mb=6.0, overlap=True):
+    def __init__(self, module, bucket_mb=6.0, overlap=True, always_collective=False):
         seen, self.params = set(), []
         for p in module.parameters():
             if p.requires_grad and p.data_ptr() not in seen:
@@ -108,6 +108,10 @@ class GradAllReduce:
         self._pending = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self.overlap = overlap
+        # issue the collectives on a ONE-rank process group as well (they are the identity there): lets a single-GPU box drive
+        # the very code path of N > 1 — hook-launched asynchronous RCCL all-reduces during backward, the waits, the division —
+        # through the real backend (tests/test_gpu_dist.py); off by default, one rank needs no collective
+        self.always_collective = bool(always_collective)
         self.hold = False
         self._accum = 1
         self.launched_in_backward = 0              # buckets whose collective started from a hook in the last step
@@ -121,7 +125,7 @@ class GradAllReduce:
         return sum(p.numel() for p in self.params)
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.always_collective)
 
     def prepare(self, accum_steps=1):
         """Before the (first) backward: zero the messages and make every .grad a view into its bucket."""
