@@ -38,12 +38,16 @@ def main():
     ap.add_argument("--only", default=None, help="costvol|pack|warpvol|resample|softmax")
     ap.add_argument("--dev", action="store_true", help="load libnrgbd_hip_dev.so (python -m neuralrgbd_amd.build --dev): "
                     "honours NRGBD_ABLATE (quad generation: 1 = everything straight from global memory, 2 = staging only, no math)")
+    ap.add_argument("--lib", default=None, help="another library next to libnrgbd_hip.so (an A/B build of neuralrgbd_amd.build.build_variant)")
     ap.add_argument("--dslice", default=None, help="a:b — keep only candidates a..b-1 of the depth set (experiments)")
     args = ap.parse_args()
     gen = args.gen
     if args.dev:
         from neuralrgbd_amd import _lib
         _lib.LIB_PATH = _lib.LIB_PATH.replace("libnrgbd_hip.so", "libnrgbd_hip_dev.so")
+    if args.lib:
+        from neuralrgbd_amd import _lib
+        _lib.LIB_PATH = _lib.LIB_PATH.replace("libnrgbd_hip.so", args.lib)
     from neuralrgbd_amd import camera, ops, synth
     from neuralrgbd_amd import homography as H
     h, w, D = GRIDS[args.config]
