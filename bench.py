@@ -19,7 +19,7 @@ The JSON line carries
                 algorithmic bytes 4[(V+1)*67*hw + D*hw] per launch / its mean launch duration, measured
                 with HIP events on the launch stream inside the timed steps (peak 8.0 TB/s);
                 `traffic` = HBM-side bytes per launch from a committed rocprofv3 --pmc measurement of this bench's
-                own windows (tools/pmc_traffic.sh -> profiles/r4_costvol_traffic.json), reported only while the kernel's
+                own windows (tools/pmc_traffic.sh -> profiles/r5_costvol_traffic.json), reported only while the kernel's
                 sources still hash to what the measurement recorded;
   cpu_baseline  the CPU oracle (oracle/kvnet_oracle.py: the reference algorithm restated on torch-CPU
                 + the C sampling oracle) timed on this node's host cores on update frames of the same
@@ -53,7 +53,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (256
 # `bench.py --no-graph` under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) and writes the per-launch mean of
 # the costvol kernel's dispatches to profiles/r2_costvol_traffic.json (FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
 # prescribes for gfx950).  Configs without an entry report null.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r4_costvol_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r5_costvol_traffic.json")
 COSTVOL_SOURCES = ("costvol_quad.hip", "costvol.hip", "costvol.hpp", "common.hpp")   # what the measured kernel is built from
 
 
@@ -176,15 +176,33 @@ class KernelTimer:
         self.last = None
         self.fn = None
         self.keep = keep
+        self.in_frame = None       # a list while an EAGER frame is being timed: (event before, event after) of every matching call
 
     def wrap(self, fn):
         self.fn = fn
 
         def remembering(*a, **k):
-            if self.keep(a, k):
+            hit = self.keep(a, k)
+            if hit:
                 self.last = (a, k)
+            if hit and self.in_frame is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*a, **k)
+                e1.record()
+                self.in_frame.append((e0, e1))
+                return out
             return fn(*a, **k)
         return remembering
+
+    def in_frame_ms(self):
+        """Mean duration of the matching calls of the eager frame bracketed by `in_frame = []` ... synchronize: the kernel where it
+        sits in the frame (cold operands, the neighbours' tails), beside measure()'s steady-state figure."""
+        if not self.in_frame:
+            return None
+        v = [e0.elapsed_time(e1) for e0, e1 in self.in_frame]
+        self.in_frame = None
+        return sum(v) / len(v), len(v)
 
     def measure(self, launches, warm=1):
         """`warm` untimed launches first: after any idle gap (a host sync, the CPU baseline, a profiler child process) the part
@@ -748,12 +766,18 @@ def main():
             # the same frame on both sides: window ring[0] filtered with the stream's current state
             pred = pred.clone()
             r_, s_, p_ = ring[0]
+            timer.in_frame, knet_timer.in_frame = [], []     # this eager frame also gives the two kernels' in-frame durations
             with torch.no_grad():
                 _, r_kv, bv_cur, dpv = model(r_, s_, p_, torch.zeros(1), cam_intrinsics=[cam], BV_predict=pred, dpv_valid=True)
                 from neuralrgbd_amd import homography as warp_homo
                 nxt = warp_homo.resample_vol_cuda(dpv, ops.pose_inverse(p_[0, 2].contiguous()), cam_intrinsic=cam, d_candi=d_candi,
                                                   padding_value=float(np.log(1.0 / D)), clamp=(-1000., 0.)).unsqueeze(0)
             torch.cuda.synchronize()
+            for tm, key in ((timer, "roofline"), (knet_timer, "roofline_mfma")):
+                got = tm.in_frame_ms()
+                if got is not None and key in line:
+                    line[key]["in_frame_eager_ms"] = got[0]
+                    line[key]["in_frame_eager_calls"] = got[1]
             line["cpu_baseline"], o = cpu_baseline(args.config, cam, d_candi, sd, ring[0], pred, sigma)
             line["parity"] = parity_block(args.config, (r_kv, dpv, bv_cur, nxt), o)
             line["parity"]["tolerance_policy"] = TOLERANCE_POLICY

@@ -516,12 +516,14 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     // visible (L2) and read them past the L1
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    {
+    // thread = (pixel, quarter of the candidates): KMAX candidates per thread — 16 for D <= 64 (the path's configs S / B / K; the D <= 128
+    // instantiation spent half of its unrolled iterations on candidates that do not exist), 32 for D <= 128 (config H when unchunked)
+    auto softmax = [&](auto kmax_c) {
+        constexpr int KMAX = decltype(kmax_c)::value;
         const int pp = tid & 63, part = tid >> 6;
         const int x2 = tx * kQT + (pp & 7), y2 = ty * kQT + (pp >> 3);
         const bool in2 = (x2 < a.w) && (y2 < a.h);
         const size_t p2 = (size_t)min(y2, a.h - 1) * a.w + min(x2, a.w - 1);
-        constexpr int KMAX = 32;                              // D <= 128
         float col[KMAX];
         float m = -INFINITY;
 #pragma unroll
@@ -548,7 +550,8 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
                 if (k < a.D) a.out_logp[(size_t)k * hw + p2] = (col[t] - m) - ls;
             }
         }
-    }
+    };
+    if (a.D <= 64) softmax(std::integral_constant<int, 16>{}); else softmax(std::integral_constant<int, 32>{});
     CVT_END(9);
     CVT_FLUSH();
 }
