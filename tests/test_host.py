@@ -320,3 +320,43 @@ def test_relu_unit_bounds_any_batchnorm_output():
             k = round(-__import__("math").log2(unit))
             assert unit == 2.0 ** -k and 0 <= k, unit              # an exact power of two in (0, 1]
             assert z.abs().max().item() < 1.0 / unit, (n, trial, z.abs().max().item(), unit)
+
+
+def test_rnet_candidate_padding_embedding_is_exact():
+    """DPVUpsampleNet._embedded (round 5: a net with D != 64 / 128 candidates runs zero-padded to 64 / 128 candidate channels on
+    the hand-written kernels): the re-indexed weights, evaluated with plain torch convolutions on the padded channel layout
+    [D real | Dp - D zero | image features], reproduce the module graph (Refine.py:79-107) — the padding contributes exact zeros,
+    the -1e30 bias keeps it out of the final log-softmax.  Host logic only: no GPU, no kernel."""
+    import torch.nn.functional as F
+    from neuralrgbd_amd import nets, synth
+    torch.manual_seed(0)
+    for D in (16, 24, 100):
+        net = nets.DPVUpsampleNet(64, 32, 3, D=D).double()
+        net.load_state_dict({k: v.double() for k, v in synth.seeded_state_dict(net, 5).items()})
+        for m in net.modules():
+            if getattr(m, "bias", None) is not None:
+                torch.nn.init.normal_(m.bias, 0, 0.1)
+        Dr, Dp, C0, C1, C2 = net._widths()
+        assert (Dr, Dp) == (D, 64 if D <= 64 else 128)
+        h, w = 6, 8
+        dpv = torch.softmax(torch.randn(1, D, h, w, dtype=torch.float64), 1)
+        feats = [torch.randn(1, 64, h, w, dtype=torch.float64), torch.randn(1, 32, 2 * h, 2 * w, dtype=torch.float64),
+                 torch.rand(1, 3, 4 * h, 4 * w, dtype=torch.float64)]
+        with torch.no_grad():
+            want = net(dpv, feats)                                   # the CPU module graph
+            e = net._embedded()
+            pad = lambda x, f: torch.cat((x, x.new_zeros(1, Dp - x.shape[1], *x.shape[2:]), f), 1)      # [D | zeros | features]
+            cl = lambda x, k: F.leaky_relu(F.conv2d(x, e[k][0], e[k][1], 1, 1), 0.01)
+            tl = lambda x, k: F.leaky_relu(F.conv_transpose2d(x, e[k][0], e[k][1], 2, 1), 0.01)
+            x = cl(cl(pad(dpv, feats[0]), "conv0"), "conv0_1")
+            assert bool((x[:, D:Dp] == 0).all())                     # the padding stays exactly zero through a layer
+            x = tl(x, "trans_conv0")
+            assert x.shape[1] == Dp and bool((x[:, D:] == 0).all())
+            x = cl(cl(torch.cat((x, feats[1]), 1), "conv1"), "conv1_1")
+            x = tl(x, "trans_conv1")
+            x = cl(cl(torch.cat((x, feats[2]), 1), "conv2"), "conv2_1")
+            z = F.conv2d(x, e["conv2_2"][0], e["conv2_2"][1], 1, 1)
+            got = torch.log_softmax(z, 1)[:, :D]
+        assert got.shape == want.shape
+        assert (got - want).abs().max().item() < 1e-9, D
+    assert nets.DPVUpsampleNet(64, 32, 3, D=200)._widths() is None and nets.DPVUpsampleNet(64, 32, 3, D=16, upsample_D=True)._widths() is None
