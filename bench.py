@@ -293,7 +293,7 @@ def parity_block(cfg, gpu, oracle_out):
     blk["max_abs_gate"] = MAX_ABS_GATE
     mx = all(blk[n]["max"] <= MAX_ABS_GATE for n in names)
     blk["pass_strict"] = l1 and all(blk[n]["max"] <= 1e-4 for n in names) and all(blk[n]["argmax_mismatch"] == 0 for n in depth_vols)
-    blk["pass"] = l1 and mx and all(blk[n]["argmax_mismatch_beyond_tie_1e-3"] == 0 and blk[n]["argmax_mismatch"] <= (32 if n == "refined" else 8)
+    blk["pass"] = l1 and mx and all(blk[n]["argmax_mismatch_beyond_tie_1e-3"] == 0 and blk[n]["argmax_mismatch"] <= 8
                                     for n in depth_vols)
     # a trilinear resample is a convex combination: with the pose inverse owned by the path (same matrix on both sides)
     # BV_predict cannot differ by more than the DPV it resamples does
@@ -350,7 +350,7 @@ MAX_ABS_GATE = 1e-3      # = tests/conftest.py::MAX_ABS_TOL
 TOLERANCE_POLICY = (
     "north_star: arg-max depth index bit-exact, DPV floats within 1e-4.  Asserted here (pass): mean |d| (L1) < 1e-4 on every volume; "
     "max |d| <= 1e-3 on every volume (HARD); arg-max identical except at pixels whose two best candidates are within 1e-3 in the ORACLE's "
-    "own volume (ties: <= 8 per frame and quarter-resolution volume, <= 32 on the full-resolution refined volume, none beyond a tie).  Why "
+    "own volume (ties: <= 8 per frame and volume, none beyond a tie).  Why "
     "not 1e-4 max: the `ref_self` sub-block — the UNMODIFIED reference against ITSELF on the config-S windows when only its execution "
     "changes (oneDNN convolutions on / off, 8 threads / 1; tests/golden/ref_selfnoise_S.npz, oracle/gen_golden.py selfnoise) — differs by up "
     "to 6.2e-4 (max) in DPV; the `fp64` sub-block shows both fp32 evaluations 1e-3-class (max) away from the same graph in float64.  "
@@ -766,6 +766,9 @@ def main():
             # the same frame on both sides: window ring[0] filtered with the stream's current state
             pred = pred.clone()
             r_, s_, p_ = ring[0]
+            with torch.no_grad():   # an untimed eager frame first: the allocator's blocks outside the graph's pool are created here (a
+                model(r_, s_, p_, torch.zeros(1), cam_intrinsics=[cam], BV_predict=pred, dpv_valid=True)   # hipMalloc drains the GPU)
+            torch.cuda.synchronize()
             timer.in_frame, knet_timer.in_frame = [], []     # this eager frame also gives the two kernels' in-frame durations
             with torch.no_grad():
                 _, r_kv, bv_cur, dpv = model(r_, s_, p_, torch.zeros(1), cam_intrinsics=[cam], BV_predict=pred, dpv_valid=True)

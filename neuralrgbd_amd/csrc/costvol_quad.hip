@@ -187,6 +187,14 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
             u = (r << 5) | ((c * 5 + r * 11) & 31);
         }
         tile = (blockIdx.x & 7) * per + u;
+    } else if ((gridDim.x & 7) == 0) {
+        // a tile count that does not split into eight bands (config H: 300 tiles x 4 chunks): the XCD owns a contiguous eighth of
+        // the (tile, chunk) list instead, tile-major — its chunks of one tile sample the same source rows from ONE L2 (without
+        // this the four chunks of a tile ran on four XCDs: FETCH_SIZE 50 -> 105 MB per launch at config H)
+        const int per = (int)gridDim.x >> 3;
+        const int id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        tile = id / a.nchunk;
+        chunk = id - tile * a.nchunk;
     }
     // Developer switch (NRGBD_ABLATE bit 16): every other workgroup walks its candidates far -> near, to de-phase the
     // staging-bound (near planes) and math-bound (far planes) parts of co-resident workgroups.  Measured: 288 us with,

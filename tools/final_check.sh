@@ -2,7 +2,7 @@
 # kernel profiles of the bench (B, S, K), PMC traffic of the sampling kernel, PMC counters of the Winograd kernels
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r5final}; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "amdgpu.ids" > $O/pytest_full.txt; tail -4 $O/pytest_full.txt > $O/pytest.txt
+timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "amdgpu.ids" > $O/pytest_full.txt; grep -E "passed|failed|error" $O/pytest_full.txt | tail -3 > $O/pytest.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 # the kernels smoke() launches (no miopen / Cijk row may appear): a kernel trace of the same call
 ( cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_smoke -- python -c "import __graft_entry__ as g; g.smoke()" > $O/prof_smoke.log 2>&1; cp $(find $O/prof_smoke -name "*kernel_stats.csv" | head -1) $O/smoke_kernel_stats.csv; rm -rf $O/prof_smoke )
