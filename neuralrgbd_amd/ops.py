@@ -458,9 +458,12 @@ def relu_unit(gamma, beta, n):
     affine parameters once (host synchronisation: callers cache it with the packed weights)."""
     import math
     bound = float(gamma.detach().abs().max()) * math.sqrt(float(n)) + float(beta.detach().abs().max())
-    # 2 % headroom: mean / variance reach the kernel through fp32 partial sums, so the realised maximum can exceed the exact-
-    # arithmetic bound by a few ulps of sqrt(n)
-    return 2.0 ** -max(0, math.floor(math.log2(max(1.02 * bound, 1e-30))) + 1)
+    # One extra power of two of headroom (free: a power-of-two unit changes no bit below saturation).  The bound is exact for exact
+    # statistics; the kernels finalise the variance as E[y^2] - mean^2 from fp32 per-tile sums (in float64), which UNDER-estimates it
+    # when |mean| >> std (cancellation at ~1e-7 E[y^2]) and so over-scales the normalised values: the factor 2 covers a computed
+    # variance down to a quarter of the true one, i.e. std / |mean| down to ~1e-3 — beyond that the clamp would saturate instead of
+    # failing (ADVICE r4; conv outputs in front of a BatchNorm are zero-mean to within a few std in every layer of this network)
+    return 2.0 ** -max(0, math.floor(math.log2(max(2.0 * bound, 1e-30))) + 1)
 
 
 def conv_wino_dw(x, w_wino, Cout, x_ss=None, x_relu=False, res=None, res_ss=None, res_relu=False, materialize=False,
