@@ -52,6 +52,12 @@
 #define CVT_FLUSH() do {} while (0)
 #endif
 
+// A/B build knob (neuralrgbd_amd.build.build_variant): wave priority by progress — 1 (product) = 3 - quarter of the workgroup's own
+// (view, candidate) list already done, re-evaluated at every run; 0 = none; 2 = per view only (3 - view, V = 4)
+#ifndef NRGBD_CV_PRIO
+#define NRGBD_CV_PRIO 1
+#endif
+
 namespace nrgbd {
 
 namespace {
@@ -341,7 +347,11 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     // candidate loop it would be all V of them (~9 MB) and every patch fill would go to the fabric.  The price is that a
     // candidate's cost is accumulated across views in memory: out[k][p] is written for view 0 and read-modify-written by
     // the same quad for the others (L2-resident, 4 B per (pixel, candidate, view)).
+    int prio_q = -1;
     for (int v = 0; v < a.V; ++v) {
+#if NRGBD_CV_PRIO == 2
+        if (v == 0) __builtin_amdgcn_s_setprio(3); else if (v == 1) __builtin_amdgcn_s_setprio(2); else if (v == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         const float* KRv = a.KR + 9 * v;
         const float* Ktv = a.Kt + 3 * v;
         const float* sv = a.src + (size_t)v * hw * a.Cp;
@@ -393,6 +403,23 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
         __syncthreads();
         CVT_END(3);
         for (int lo = kb, hi = ke; lo < hi;) {
+#if NRGBD_CV_PRIO == 1
+            {
+                // WAVE PRIORITY BY PROGRESS (round 5).  The launch is one round of 3 workgroups per CU (768 tiles = 256 x 3 at config B) and a
+                // SIMD arbitrates its three waves by age: the workgroup dispatched first wins every contended issue slot, so the three
+                // finished at 350 / 420 / 480 k clocks whatever their tiles (the per-tile cost map has a period of exactly one dispatch round,
+                // profiles/r5_costvol_limits.txt) and the last one ran its final quarter alone on the CU, with nothing to hide its LDS latency
+                // behind.  s_setprio beats age: a workgroup's priority is 3 minus the quarter of its own (view, candidate) list it has
+                // finished, so whoever is ahead yields and the three stay within a quarter of each other.  230 -> 211 us.
+                const int total = a.V * (ke - kb), done = v * (ke - kb) + ((rev ? ke - hi : lo - kb));
+                const int q = (4 * done) / total;
+                if (q != prio_q) {
+                    prio_q = q;
+                    if (q <= 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2);
+                    else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                }
+            }
+#endif
             CVT_BEGIN();
             // ---- longest run of the next candidates (up to 32) whose united footprint fits the patch: lane l < 32 of every wave
             // holds the l-th next candidate, inclusive prefix union along the two 16-lane DPP rows (the second row joins the

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--config", default="B")
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--lib", default="libnrgbd_hip_dev.so")
+    ap.add_argument("--map", action="store_true", help="print the per-tile cost map (one-chunk launches)")
+    ap.add_argument("--seed", type=int, default=0, help="seed of the synthetic poses / features")
     args = ap.parse_args()
     from neuralrgbd_amd import _lib
     _lib.LIB_PATH = _lib.LIB_PATH.replace("libnrgbd_hip.so", args.lib)
@@ -35,7 +37,7 @@ def main():
     V, C = args.views, 67
     dev = torch.device("cuda:0")
     cam = camera.scannet_intrinsics(w, h) if args.config != "K" else camera.kitti_intrinsics(w, h)
-    rng = np.random.RandomState(0)
+    rng = np.random.RandomState(args.seed)
     feats = torch.from_numpy(rng.standard_normal((V + 1, 64, h, w)).astype(np.float32)).to(dev)
     frames = torch.from_numpy(rng.standard_normal((V + 1, 3, 4 * h, 4 * w)).astype(np.float32)).to(dev)
     poses = torch.from_numpy(synth.random_poses(rng, V)).to(dev)
@@ -100,6 +102,19 @@ def main():
     xcc = t[:, 18] & 0xF
     print("per XCD: last end (us) " + " ".join("%d:%.0f" % (x, end[xcc == x].max()) for x in np.unique(xcc)) +
           "   mean workgroup clocks " + " ".join("%d:%.0fk" % (x, tot[xcc == x].mean() / 1e3) for x in np.unique(xcc)))
+    if args.map and n == ((h + 7) // 8) * ((w + 7) // 8) and n % 8 == 0:
+        # cost map: workgroup b -> tile as costvol_quad.hip maps it (one chunk per tile, XCD bands, scrambled inside the band)
+        per, tiles_x = n // 8, (w + 7) // 8
+        grid = np.zeros(n)
+        for b in range(n):
+            u = b >> 3
+            if per % 32 == 0:
+                r, c = u >> 5, u & 31
+                u = (r << 5) | ((c * 5 + r * 11) & 31)
+            grid[(b & 7) * per + u] = tot[b]
+        print("cost map (k clocks per tile, rows = tile rows):")
+        for row in grid.reshape(-1, tiles_x):
+            print(" ".join("%3d" % round(v / 1e3) for v in row))
     # cost by tile position (rows of the image): how uneven is the work
     order = np.argsort(tot)
     print("slowest 5 workgroups (block id, clocks, unstaged groups, runs16/8/4/2):", [(int(i), int(tot[i]), int(t[i, 14]), tuple(int(x) for x in t[i, 10:14])) for i in order[-5:]])
