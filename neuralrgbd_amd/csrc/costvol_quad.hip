@@ -260,8 +260,9 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
             const int xa = (int)fminf(fmaxf(x0f, 0.f), wf - 1.f), xb = (int)fminf(fmaxf(x0f + 1.f, 0.f), wf - 1.f);
             const int ya = (int)fminf(fmaxf(y0f, 0.f), hf - 1.f), yb = (int)fminf(fmaxf(y0f + 1.f, 0.f), hf - 1.f);
             const int cpb = a.Cp * 4;
-            adr[0] = (ya * a.w + xa) * cpb; adr[1] = (ya * a.w + xb) * cpb;
-            adr[2] = (yb * a.w + xa) * cpb; adr[3] = (yb * a.w + xb) * cpb;
+            const int ra = __mul24(ya, a.w), rb = __mul24(yb, a.w);          // 24-bit multiplies (full rate): h * w < 2^24, checked by the launcher
+            adr[0] = __mul24(ra + xa, cpb); adr[1] = __mul24(ra + xb, cpb);
+            adr[2] = __mul24(rb + xa, cpb); adr[3] = __mul24(rb + xb, cpb);
         }
         const int pitchB = cols * kQFeatBytes;
         const char* gsv = reinterpret_cast<const char*>(sv);
@@ -479,8 +480,8 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
                 if (interior) {
                     for (int it = wave; it * 4 < area; it += 4) {
                         const int q = min(it * 4 + (lane >> 4), area - 1);
-                        const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
-                        const unsigned off = base + (unsigned)(qy * rowb + qx * cpb + (lane & 15) * 16);
+                        const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - __mul24(qy, cols);
+                        const unsigned off = base + (unsigned)(__mul24(qy, rowb) + __mul24(qx, cpb) + (lane & 15) * 16);   // 24-bit multiplies: full rate (a row pitch < 16 MB)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
                                                          (__attribute__((address_space(3))) void*)(ldsF + it * 4 * kQFeatBytes),
                                                          16, 0, 0);
@@ -488,8 +489,8 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
                     if constexpr (EXTRA) {
                         for (int it = wave; it * 64 < area; it += 4) {
                             const int q = min(it * 64 + lane, area - 1);
-                            const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
-                            const unsigned off = base + (unsigned)(qy * rowb + qx * cpb + kQFeatBytes);
+                            const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - __mul24(qy, cols);
+                            const unsigned off = base + (unsigned)(__mul24(qy, rowb) + __mul24(qx, cpb) + kQFeatBytes);
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
                                                              (__attribute__((address_space(3))) void*)(ldsR + it * 64 * 16),
                                                              16, 0, 0);
@@ -498,9 +499,9 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
                 } else {
                     for (int it = wave; it * 4 < area; it += 4) {
                         const int q = min(it * 4 + (lane >> 4), area - 1);
-                        const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
+                        const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - __mul24(qy, cols);
                         const int gx = min(max(xlo + qx, 0), a.w - 1), gy = min(max(ylo + qy, 0), a.h - 1);
-                        const unsigned off = (unsigned)((gy * a.w + gx) * cpb + (lane & 15) * 16);
+                        const unsigned off = (unsigned)(__mul24(gy, rowb) + __mul24(gx, cpb) + (lane & 15) * 16);
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
                                                          (__attribute__((address_space(3))) void*)(ldsF + it * 4 * kQFeatBytes),
                                                          16, 0, 0);
@@ -508,9 +509,9 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
                     if constexpr (EXTRA) {
                         for (int it = wave; it * 64 < area; it += 4) {
                             const int q = min(it * 64 + lane, area - 1);
-                            const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - qy * cols;
+                            const int qy = (int)(((float)q + 0.5f) * inv_cols), qx = q - __mul24(qy, cols);
                             const int gx = min(max(xlo + qx, 0), a.w - 1), gy = min(max(ylo + qy, 0), a.h - 1);
-                            const unsigned off = (unsigned)((gy * a.w + gx) * cpb + kQFeatBytes);
+                            const unsigned off = (unsigned)(__mul24(gy, rowb) + __mul24(gx, cpb) + kQFeatBytes);
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(svb + off),
                                                              (__attribute__((address_space(3))) void*)(ldsR + it * 64 * 16),
                                                              16, 0, 0);
@@ -595,7 +596,8 @@ bool costvol_quad_supported(const CostvolArgs& a) {
     const bool extra = a.Cp == 68 && a.C > 64;
     const bool plain = a.Cp == 64 && a.C == 64;
     // 32-bit byte offsets into a view; the LDS image (patch + 20 B per candidate + accumulators) has to fit a workgroup's share
-    return (extra || plain) && (long)a.h * a.w * a.Cp * 4 < (1L << 31) && a.D <= NRGBD_MAX_D;
+    // ... and a row pitch below 16 MB and fewer than 2^24 rows (24-bit multiplies in the patch fill)
+    return (extra || plain) && (long)a.h * a.w * a.Cp * 4 < (1L << 31) && (long)a.w * a.Cp * 4 < (1L << 24) && (long)a.h * a.w < (1L << 24) && a.D <= NRGBD_MAX_D;
 }
 
 // Returns NRGBD_OK and sets *did_softmax when the launch also produced out_logp.
