@@ -185,3 +185,10 @@ class GradAllReduce:
         for bi, w in enumerate(self._work):
             w.wait()
             self.flat[bi].div_(world)
+
+
+def graph_capture_mode():
+    """capture_error_mode for torch.cuda.graph: with a process group alive, RCCL's watchdog / heartbeat threads may query events
+    while THIS thread captures a hipGraph; under the default "global" mode any such call from another thread aborts the capture.
+    "thread_local" confines the check to the capturing thread (what data-parallel training with captured steps needs)."""
+    return "thread_local" if dist.is_available() and dist.is_initialized() else "global"

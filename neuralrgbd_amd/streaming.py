@@ -19,6 +19,12 @@ from . import homography as warp_homo
 from . import ops
 
 
+def _capture_mode():
+    """capture_error_mode of the hipGraph captures (see distributed.graph_capture_mode)."""
+    from .distributed import graph_capture_mode
+    return graph_capture_mode()
+
+
 class DepthStream:
     def __init__(self, model, cam_intrinsics, d_candi, t_win_r=2, use_graph=True, device=None, copy_outputs=False):
         self.model = model
@@ -60,7 +66,7 @@ class DepthStream:
               "bv": self.bv_predict.clone()}
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
             st["out"] = self._frame(st["ref"], st["src"], st["poses"], st["pose_next"], st["bv"])
         st["consts"] = warp_homo.cache_snapshot()      # K / rays / d_candi the graph reads: kept alive with the graph
         self._graph, self._static = g, st

@@ -20,6 +20,12 @@ from .autograd import nll_loss_d
 from .misc import depth_val_regression, valid_dpv
 
 
+def _capture_mode():
+    """capture_error_mode of the hipGraph captures (see distributed.graph_capture_mode)."""
+    from .distributed import graph_capture_mode
+    return graph_capture_mode()
+
+
 def _nll_terms(d_dpv, dmap_cur_refined, kv_dpv, dmap_refined, depth_ref, depth_ref_imgsize, valid):
     """train_KVNet.py:103-120: NLL on the 1/4-res DPV and on its R-Net refinement, for the measurement and (update branch)
     for the filtered volume."""
@@ -221,7 +227,7 @@ class TrainGraph:
             self.opt.zero_grad(set_to_none=True)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
                 st["out"] = self._iteration(st)      # gradients are allocated in the graph's pool and rewritten per replay
             st["consts"] = warp_homo.cache_snapshot()   # K / rays / d_candi the graph reads: kept alive with the graph
             self._graph, self._st = g, st
@@ -284,10 +290,10 @@ class TrainGraph:
             self._zero_grads()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
                 st["out"] = self._fwd_bwd(st)         # accumulates into the persistent gradients
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g.pool()):
+            with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode=_capture_mode()):
                 self.opt.step()
             st["consts"] = warp_homo.cache_snapshot()
             self._graph, self._g_opt, self._st = g, g2, st
