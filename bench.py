@@ -640,6 +640,8 @@ def main():
                     "--pmc child passes of this script (about a minute; N = 1 only)")
     ap.add_argument("--streams", type=int, default=1, help="independent video streams per GPU, each on its own HIP stream "
                     "(a step is then one frame of EVERY stream; the extra streams fill the tails of each other's kernels)")
+    ap.add_argument("--back-to-back", action="store_true", help="also report the sampling kernel re-launched 20x back to back between one pair "
+                    "of events (roofline.back_to_back_ms: the figure of rounds 1-4)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short companion runs of configs S / K / H and of one "
                     "training step (N = 1, headline config only; about a minute)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU self-test of the N>1 harness
@@ -714,9 +716,34 @@ def main():
     per_rank = rank_times(world, args.steps, dev)
 
     if rank == 0:
-        n_k = max(args.steps, 20)
-        k_ms = timer.measure(n_k, warm=20)          # straight behind the timed frames, in the steady state (KernelTimer.measure)
-        c_ms = knet_timer.measure(20, warm=30) if knet_timer.last is not None else None
+        # ---- the two roofline kernels WHERE THEY SIT: consecutive EAGER frames of one window and filter state right behind the timed
+        # region (the timed frames are hipGraph replays, inside which a single kernel cannot be bracketed), every matching launch
+        # between its own pair of HIP events on the launch stream.  Until round 5 the sampling kernel was re-launched 20x back to back
+        # between ONE pair of events instead: that loop measures 0.235 ms where the kernel takes 0.20 ms in the frame and 0.193 ms per
+        # launch once events separate the launches (tools/r5_cv_gap.py) — without anything between them a launch runs into the previous
+        # one's end-of-kernel write-back of 25 MB of dirty cost / log-probability lines.  `--back-to-back` still reports that figure.
+        from neuralrgbd_amd import homography as warp_homo
+        pred = pred.clone()
+        r_, s_, p_ = ring[0]
+
+        def eager_frame():
+            with torch.no_grad():
+                _, r_kv_, bv_cur_, dpv_ = model(r_, s_, p_, torch.zeros(1), cam_intrinsics=[cam], BV_predict=pred, dpv_valid=True)
+                nxt_ = warp_homo.resample_vol_cuda(dpv_, ops.pose_inverse(p_[0, 2].contiguous()), cam_intrinsic=cam, d_candi=d_candi,
+                                                   padding_value=float(np.log(1.0 / D)), clamp=(-1000., 0.)).unsqueeze(0)
+            return r_kv_, dpv_, bv_cur_, nxt_
+        for _ in range(2):       # untimed: the allocator's blocks outside the graph's pool are created here (a hipMalloc drains the GPU)
+            eager_frame()
+        torch.cuda.synchronize()
+        timer.in_frame, knet_timer.in_frame = [], []
+        n_eager = max(8, min(args.steps, 20))
+        for _ in range(n_eager):
+            gpu_out = eager_frame()
+        torch.cuda.synchronize()
+        k_ms, n_k = timer.in_frame_ms()
+        got = knet_timer.in_frame_ms()
+        c_ms, n_c = got if got is not None else (None, 0)
+        b2b_ms = timer.measure(20, warm=20) if args.back_to_back else None
         algo = costvol_bytes(V, 67, D, h, w)
         achieved = algo / (k_ms * 1e-3) / 1e9
         traffic, traffic_note, sq = (None, "", None)
@@ -737,9 +764,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "costvol_quad<L2,3> (fused warp + cost volume + log-softmax over depth, one launch)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes": algo, "kernel_ms": k_ms, "launches_timed": n_k,
-                         "timing": "HIP events around back-to-back launches of the frame's own costvol call (log-softmax launch included), after 20 untimed ones, right after the timed region",
+                         "timing": "mean over the kernel's launches in %d consecutive eager frames right behind the timed region (2 untimed ones first), each "
+                                   "launch between its own pair of HIP events on the launch stream; the log-softmax is part of the launch" % n_eager,
                          "traffic": traffic, "traffic_source": traffic_note},
         }
+        if b2b_ms is not None:
+            line["roofline"]["back_to_back_ms"] = b2b_ms
         if per_rank is not None:
             line["per_rank"] = per_rank
         if sq:
@@ -760,27 +790,11 @@ def main():
                                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                      "flops": flops, "direct_conv_flops": nominal,
                                      "direct_conv_equivalent_tflops": nominal / (c_ms * 1e-3) / 1e12, "kernel_ms": c_ms,
-                                     "launches_timed": 20, "timing": "HIP events around 20 back-to-back re-launches of the frame's own layer call, "
-                                     "after 30 untimed ones, straight behind the timed frames (steady state; profiles/r4_inframe_gap.txt)"}
+                                     "launches_timed": n_c, "timing": "mean over the 5 matching layer launches of each of the same eager frames, every launch "
+                                     "between its own pair of HIP events (no idle gap in front of them: steady state, profiles/r4_inframe_gap.txt)"}
         if world == 1 and not args.no_cpu_baseline:
-            # the same frame on both sides: window ring[0] filtered with the stream's current state
-            pred = pred.clone()
-            r_, s_, p_ = ring[0]
-            with torch.no_grad():   # an untimed eager frame first: the allocator's blocks outside the graph's pool are created here (a
-                model(r_, s_, p_, torch.zeros(1), cam_intrinsics=[cam], BV_predict=pred, dpv_valid=True)   # hipMalloc drains the GPU)
-            torch.cuda.synchronize()
-            timer.in_frame, knet_timer.in_frame = [], []     # this eager frame also gives the two kernels' in-frame durations
-            with torch.no_grad():
-                _, r_kv, bv_cur, dpv = model(r_, s_, p_, torch.zeros(1), cam_intrinsics=[cam], BV_predict=pred, dpv_valid=True)
-                from neuralrgbd_amd import homography as warp_homo
-                nxt = warp_homo.resample_vol_cuda(dpv, ops.pose_inverse(p_[0, 2].contiguous()), cam_intrinsic=cam, d_candi=d_candi,
-                                                  padding_value=float(np.log(1.0 / D)), clamp=(-1000., 0.)).unsqueeze(0)
-            torch.cuda.synchronize()
-            for tm, key in ((timer, "roofline"), (knet_timer, "roofline_mfma")):
-                got = tm.in_frame_ms()
-                if got is not None and key in line:
-                    line[key]["in_frame_eager_ms"] = got[0]
-                    line[key]["in_frame_eager_calls"] = got[1]
+            # the same frame on both sides: window ring[0] filtered with the stream's state — the last of the eager frames above
+            r_kv, dpv, bv_cur, nxt = gpu_out
             line["cpu_baseline"], o = cpu_baseline(args.config, cam, d_candi, sd, ring[0], pred, sigma)
             line["parity"] = parity_block(args.config, (r_kv, dpv, bv_cur, nxt), o)
             line["parity"]["tolerance_policy"] = TOLERANCE_POLICY

@@ -18,15 +18,21 @@ GRIDS = {"S": (64, 96, 64), "B": (192, 256, 64), "K": (64, 192, 64), "H": (120, 
 
 
 def timeit(fn, iters):
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    """Mean duration of a launch, every launch between its OWN pair of HIP events (round 5: one pair around a back-to-back loop adds
+    the previous launch's end-of-kernel write-back to every launch — 0.235 vs 0.193 ms for the fused sampling kernel at config B,
+    tools/r5_cv_gap.py)."""
+    for _ in range(5):
         fn()
-    e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    ev = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        ev.append((e0, e1))
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in ev) / iters
 
 
 def main():
