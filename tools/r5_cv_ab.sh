@@ -3,6 +3,6 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5cv; mkdir -p $O; rm -f $O/ab.txt
 for rep in 1 2; do
 for lib in libnrgbd_hip.so "$@"; do
-  for c in B S H; do echo "== $lib $c" >> $O/ab.txt; python tools/bench_costvol.py --config $c --iters 300 --only costvol+ --lib $lib 2>&1 | grep -i "costvol" >> $O/ab.txt; done
+  for c in B S H; do echo "== $lib $c" >> $O/ab.txt; python tools/bench_costvol.py --config $c --iters 100 --only costvol+ --lib $lib 2>&1 | grep -i "costvol" >> $O/ab.txt; done
 done; done
 cat $O/ab.txt
