@@ -64,10 +64,14 @@ namespace {
 
 constexpr int kQT = 8;            // tile edge
 constexpr int kQRun = 32;         // candidates per staged run at most (groups of 4): two 16-lane DPP rows of footprint boxes
-// texels of the patch (x 272 B): 188 texels = 50 KB + 20 B per candidate -> 3 workgroups per CU; the views' partial costs meet
-// in global memory.  (Round 3's generation 4 kept them in LDS accumulators next to a 128-texel patch: bit-identical and slower,
-// 415 vs 281 us at config B — profiles/r3_costvol_gen4.txt; removed in round 4.)
-constexpr int kQPatch3 = 188;
+// texels of the patch (x 272 B): 156 texels = 42 KB, + 8.4 KB of cost accumulators [64 pixels][32 + 1 candidates], + boxes and candidates = 52.2 KB
+// -> 3 workgroups per CU.  Round 5: the views' partial costs of a PASS (32 candidates of the workgroup, all views) meet in these LDS accumulators
+// and leave them once; until then a candidate's cost was read-modify-written in global memory once per view (188-texel patch): WRITE_SIZE 53 -> 18.5 MB
+// per launch, 236 -> 233.5 us at config B, 50.5 -> 49.1 at S, 226 -> 223 at H (same chip).  (Round 3's generation 4 did the same for all D
+// candidates at once next to a 128-texel patch of LOOSE boxes: 415 vs 281 us — it was the patch size, not the accumulators.)
+constexpr int kQPatch3 = 156;
+constexpr int kQPass = 32;        // candidates per pass (= the longest run)
+constexpr int kQAccPitch = kQPass + 1;
 constexpr int kQFeatBytes = 256;  // feature plane: 16 words of 16 B per texel
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -151,7 +155,7 @@ __device__ __forceinline__ float rgb_word(const f32x4 A, const f32x4 B, const f3
 
 // TAIL: valid channels of the texel's 17th word (Cp = 68: channels 64..66 = pooled RGB => 3; -1 = a.C - 64 at run time);
 // 0 = no 17th word (Cp = 64).  ALIGN: grid_sample's align_corners.
-// A candidate's cost is read-modify-written in global memory (out[k][p], L2-resident) once per view by the quad that owns it.
+// A candidate's cost is accumulated over the views in LDS (ldsA) by the lane that owns it in each view and written once per pass.
 template <int DIST, int TAIL, bool ALIGN, int PATCH, int WGS>
 __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     constexpr bool EXTRA = TAIL != 0;
@@ -160,8 +164,9 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     CVT_DECL
     char* ldsF = smem;                                                  // [kQPatch][256 B]
     char* ldsR = smem + kQPatch * kQFeatBytes;                          // [kQPatchR][16 B]
-    int4* boxes = reinterpret_cast<int4*>(ldsR + kQPatchR * 16);        // [D] footprint of the tile per candidate (this view)
-    float* dcand = reinterpret_cast<float*>(boxes + a.D);               // [D] depth candidates
+    int4* boxes = reinterpret_cast<int4*>(ldsR + kQPatchR * 16);        // [kQPass] footprint of the tile per candidate of the pass (this view)
+    float* dcand = reinterpret_cast<float*>(boxes + kQPass);            // [D] depth candidates
+    float* ldsA = dcand + ((a.D + 3) & ~3);                             // [64 pixels][kQAccPitch] partial costs of the pass, summed over the views
     float* red = reinterpret_cast<float*>(smem);                        // softmax scratch (the patch is dead by then)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     const bool rev = NRGBD_DBG(a, 16) && (((uq ^ (uq >> 5)) & 1) != 0);
     const int tiles_x = (a.w + kQT - 1) / kQT;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int kb = chunk * a.kchunk, ke = min(a.D, kb + a.kchunk);
+    const int kb_all = chunk * a.kchunk, ke_all = min(a.D, kb_all + a.kchunk);
 
     const int x = tx * kQT + (quad & 7), y = ty * kQT + (quad >> 3);
     const bool inside = (x < a.w) && (y < a.h);
@@ -346,9 +351,13 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     // Loop order: views OUTER.  All workgroups of an XCD (one band of tiles) sweep the same source view at about the same
     // time, so the band's footprint in ONE view (~2 MB) is what has to live in the 4 MB L2 — with the views inside the
     // candidate loop it would be all V of them (~9 MB) and every patch fill would go to the fabric.  The price is that a
-    // candidate's cost is accumulated across views in memory: out[k][p] is written for view 0 and read-modify-written by
-    // the same quad for the others (L2-resident, 4 B per (pixel, candidate, view)).
+    // candidate's cost has to be accumulated across views: in the LDS accumulators of the PASS (kQPass candidates of this workgroup, all
+    // their views), which leave for global memory once at the end of the pass (until round 5: read-modify-written in global memory per view).
     int prio_q = -1;
+    // ---- passes of kQPass candidates (the body below is the view loop of ONE pass; it keeps its indentation) ----
+    for (int kb = kb_all; kb < ke_all; kb += kQPass) {
+    const int ke = min(ke_all, kb + kQPass);
+    const int bo = kb;                                  // boxes[] is indexed relative to the pass
     for (int v = 0; v < a.V; ++v) {
 #if NRGBD_CV_PRIO == 2
         if (v == 0) __builtin_amdgcn_s_setprio(3); else if (v == 1) __builtin_amdgcn_s_setprio(2); else if (v == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
                 b.z = min(max((int)floorf(mny), -1), a.h - 1);
                 b.w = min(max((int)floorf(mxy) + 1, b.z + 1), a.h);
                 if (bad) { b.x = -(1 << 20); b.y = 1 << 20; b.z = -(1 << 20); b.w = 1 << 20; }   // unbounded: never fits
-                boxes[c] = b;
+                boxes[c - bo] = b;
             }
         }
         __syncthreads();
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
                 // profiles/r5_costvol_limits.txt) and the last one ran its final quarter alone on the CU, with nothing to hide its LDS latency
                 // behind.  s_setprio beats age: a workgroup's priority is 3 minus the quarter of its own (view, candidate) list it has
                 // finished, so whoever is ahead yields and the three stay within a quarter of each other.  230 -> 211 us.
-                const int total = a.V * (ke - kb), done = v * (ke - kb) + ((rev ? ke - hi : lo - kb));
+                const int total = a.V * (ke_all - kb_all), done = a.V * (kb - kb_all) + v * (ke - kb) + ((rev ? ke - hi : lo - kb));
                 const int q = (4 * done) / total;
                 if (q != prio_q) {
                     prio_q = q;
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
             // compares; the selection took 8 % of a workgroup's time, profiles/r5_costvol_diag_before.txt) ----
             const int nmax = min(kQRun, hi - lo);
             int4 bx = make_int4(1 << 30, -(1 << 30), 1 << 30, -(1 << 30));
-            if (lane < nmax) bx = boxes[rev ? hi - 1 - lane : lo + lane];
+            if (lane < nmax) bx = boxes[(rev ? hi - 1 - lane : lo + lane) - bo];
 #define NRGBD_ROW_SHR_UNION(SH)                                                                                   \
             bx.x = min(bx.x, __builtin_amdgcn_update_dpp(1 << 30, bx.x, 0x110 + SH, 0xf, 0xf, false));              \
             bx.y = max(bx.y, __builtin_amdgcn_update_dpp(-(1 << 30), bx.y, 0x110 + SH, 0xf, 0xf, false));           \
@@ -529,20 +538,29 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
 #pragma unroll 1
                 for (int g = 0; g < ngroups; ++g) {
                     const int k0 = j0 + 4 * g, nc = min(4, n - 4 * g);   // candidates j0 .. j0 + n - 1 = this run
-                    float* o = out + (size_t)min(k0 + j, a.D - 1) * hw + p;
-                    const float prev = (v > 0) ? *o : 0.f;     // this quad's own store of the previous view
+                    float* o = ldsA + quad * kQAccPitch + (min(k0 + j, ke - 1) - kb);   // this lane's candidate of the group; a quad is inside one wave: in-order LDS
+                    const float prev = (v > 0) ? *o : 0.f;
                     float acc;
                     if (!staged) acc = group(F_{}, N4{}, sv, st, k0, nc, 0, 0, 0, 0, 0);
                     else if (nc == 1) acc = group(T_{}, N1{}, sv, st, k0, 1, xlo, xhi, ylo, yhi, cols);
                     else if (nc == 2) acc = group(T_{}, N2{}, sv, st, k0, 2, xlo, xhi, ylo, yhi, cols);
                     else if (nc == 3) acc = group(T_{}, N3{}, sv, st, k0, 3, xlo, xhi, ylo, yhi, cols);
                     else acc = group(T_{}, N4{}, sv, st, k0, 4, xlo, xhi, ylo, yhi, cols);
-                    if (inside && j < nc) *o = prev + div_by_const(acc, a.sigma, a.rsigma);   // homography.py:325 (/ sigma), views in order
+                    if (j < nc) *o = prev + div_by_const(acc, a.sigma, a.rsigma);               // homography.py:325 (/ sigma), views in order
                 }
             }
             if (staged) CVT_END(7); else CVT_END(8);
             if (rev) hi -= n; else lo += n;
         }
+    }
+    // ---- the pass is complete: its costs leave the LDS once (no read-modify-write per view: -3 reads and -3 writes of D x hw floats) ----
+    __syncthreads();
+    for (int idx = tid; idx < 64 * (ke - kb); idx += 256) {
+        const int kk = idx >> 6, q = idx & 63;
+        const int xq = tx * kQT + (q & 7), yq = ty * kQT + (q >> 3);
+        if (xq < a.w && yq < a.h) out[(size_t)(kb + kk) * hw + (size_t)yq * a.w + xq] = ldsA[q * kQAccPitch + kk];
+    }
+    __syncthreads();                                    // the accumulators are free for the next pass
     }
 
     if (!a.fuse_softmax) { CVT_FLUSH(); return; }
@@ -614,7 +632,8 @@ int launch_costvol_quad(const CostvolArgs& args, hipStream_t stream, bool* did_s
     a.fuse_softmax = (nchunk == 1 && a.out_logp != nullptr && a.D <= 128) ? 1 : 0;
     *did_softmax = a.fuse_softmax != 0;
     const int patch = kQPatch3;
-    const size_t lds = (size_t)patch * kQFeatBytes + (size_t)((patch + 63) / 64 * 64) * 16 + (size_t)a.D * (sizeof(int4) + sizeof(float));
+    const size_t lds = (size_t)patch * kQFeatBytes + (size_t)((patch + 63) / 64 * 64) * 16 + (size_t)kQPass * sizeof(int4) +
+                       (size_t)((a.D + 3) & ~3) * sizeof(float) + (size_t)64 * kQAccPitch * sizeof(float);
     const dim3 grid(tiles * nchunk);
     const int tail = a.Cp == 68 ? (a.C - 64 == 3 ? 3 : -1) : 0;
     const bool al = a.align != 0;
