@@ -522,9 +522,10 @@ def stub_main(args):
     for i in range(args.warmup):
         frame(i)
     dt = timed_steps(frame, args.steps, world, torch.device("cpu"))
+    per_rank = rank_times(world, args.steps, torch.device("cpu"))
     if rank == 0:
         print(json.dumps({"stub": True, "n_gpus": world, "collective_ranks": ranks, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": 1e3 * dt / args.steps, "value": args.steps * world / dt, "scaling": "weak"}))
+                          "ms_per_step": 1e3 * dt / args.steps, "value": args.steps * world / dt, "scaling": "weak", "per_rank": per_rank}))
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -230,6 +230,9 @@ def test_bench_spawns_its_own_ranks_without_torchrun():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["collective_ranks"] == 2 and rec["steps"] == 3
     assert rec["ms_per_step"] >= 9.0                              # MAX over ranks: the slower rank sleeps 10 ms per step
+    # every rank's own time per step, gathered: rank 0 sleeps 5 ms, rank 1 sleeps 10 ms — the straggler is visible
+    own = rec["per_rank"]["own_ms_per_step"]
+    assert len(own) == 2 and 4.5 <= own[0] < 9.0 <= own[1] and rec["per_rank"]["max"] == max(own)
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
