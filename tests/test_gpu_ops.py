@@ -338,6 +338,8 @@ def test_homography_terms_match_oracle_bitwise():
     (24, 40, 16, 3, 65, "L1", 0.02, 0.05, 18),    # one valid channel in the RGB word
     (48, 64, 32, 3, 67, "L2", 0.4, 1.0, 19),      # large motions: most taps out of view, planes crossing the camera
     (48, 64, 32, 4, 67, "L2", 0.0, 0.3, 20),      # pure translation 0.3 m: strong zoom on the nearest planes
+    (192, 256, 48, 2, 67, "L2", 0.02, 0.05, 21),  # one workgroup per tile, two accumulator passes with a PARTIAL second one (32 + 16 candidates)
+    (192, 256, 33, 1, 67, "L1", 0.02, 0.05, 22),  # ... a second pass of ONE candidate, single view
 ])
 def test_costvol_quad_vs_oracle(h, w, D, V, C, dist, rot, trans, seed, gen="quad"):
     """Generation 3 of the fused kernel (4 lanes per (pixel, candidate); what the path runs) against the C oracle, against the
