@@ -62,7 +62,20 @@ __global__ __launch_bounds__(kWThreads, 2) void conv3d_wgrad_kernel(const WgradA
 
     const int tiles_x = (a.W + kWW - 1) / kWW, tiles_y = (a.H + kWH - 1) / kWH, tiles_z = (a.D + kWD - 1) / kWD;
     const int ntiles = tiles_x * tiles_y * tiles_z;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Wave priority by progress (round 5, as in costvol_quad.hip): the launch is ONE round of two workgroups per CU, and a SIMD arbitrates
+    // its two waves by age — the older workgroup ran ahead and the younger finished alone, its staging no longer hidden behind the
+    // other's MFMAs.  Priority = 3 - the quarter of the workgroup's own tile list done: whoever is ahead yields.  0.600 -> 0.588 ms.
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    int it_ = 0, pq_ = -1;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it_) {
+        {
+            const int q = (4 * it_) / my_tiles;
+            if (q != pq_) {
+                pq_ = q;
+                if (q <= 0) __builtin_amdgcn_s_setprio(3); else if (q == 1) __builtin_amdgcn_s_setprio(2);
+                else if (q == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            }
+        }
         int t = tile;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y; const int tz = t / tiles_y;
