@@ -527,6 +527,7 @@ def stub_main(args):
         print(json.dumps({"stub": True, "n_gpus": world, "collective_ranks": ranks, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * dt / args.steps, "value": args.steps * world / dt, "scaling": "weak", "per_rank": per_rank}))
     if world > 1:
+        torch.distributed.barrier()      # rank 0 is still measuring kernels / printing: nobody tears its communicator down before that
         torch.distributed.destroy_process_group()
 
 
@@ -626,6 +627,7 @@ def train_main(args):
             line["cpu_baseline"] = cpu_baseline_train(model, cam, d_candi, flat, 10.0)
         print(json.dumps(line))
     if world > 1:
+        torch.distributed.barrier()      # rank 0 is still measuring kernels / printing: nobody tears its communicator down before that
         torch.distributed.destroy_process_group()
 
 
@@ -809,6 +811,7 @@ def main():
             line["other_configs"] = other_configs(args.config)
         print(json.dumps(line))
     if world > 1:
+        torch.distributed.barrier()      # rank 0 is still measuring kernels / printing: nobody tears its communicator down before that
         torch.distributed.destroy_process_group()
 
 
