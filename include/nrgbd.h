@@ -120,8 +120,8 @@ int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc,
 
 /* The same operation with the kernel generation chosen by the caller (tests and A/B measurements):
  * 0 = automatic (what nrgbd_costvol_fwd does), 1 = direct gather (any shape), 2 = LDS-staged, lane = pixel (Cp/4 in
- * {1,2,3,4,8,9,16,17}), 3 = quad: 4 lanes per (pixel, candidate) (Cp = 68 with C > 64, or Cp = C = 64; V <= 8; what 0 picks
- * for those shapes).
+ * {1,2,3,4,8,9,16,17}), 3 = quad: 4 lanes per (pixel, candidate) (Cp = 68 with C > 64, or Cp = C = 64; V <= 8; a view below 2 GB with a
+ * row pitch below 16 MB and h * w < 2^24: 24-bit address multiplies; what 0 picks for those shapes).
  * A generation that does not support the shape returns NRGBD_E_SHAPE; nothing is substituted silently. */
 int nrgbd_costvol_fwd_gen(const float* ref_nhwc, const float* src_nhwc,
                       const float* KR, const float* Kt, const float* rays,
