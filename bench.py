@@ -303,18 +303,20 @@ def parity_block(cfg, gpu, oracle_out):
 
 def other_configs(skip, timeout_s=240):
     """BASELINE.json's other configurations on the same lease, each as a short child run of this script (5 steps after 3 warm-up
-    frames, no CPU baseline, no counter passes): {frames/s, ms per frame, the sampling kernel's time and fraction of the HBM roofline};
+    frames — config H: its 300-frame stream —, no CPU baseline, no counter passes): {frames/s, ms per frame, the sampling kernel's time and fraction of the HBM roofline};
     plus one `--mode train` step pair at config 4's shape.  Driver-visible companions of the headline number, not part of it."""
     import subprocess
     out = {}
     base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-live-traffic", "--no-other-configs"]
     for cfg in [c for c in ("S", "K", "H") if c != skip]:
+        steps = 300 if cfg == "H" else 5        # BASELINE config 5 IS a 300-frame sequence of one stream (state resident): sustained rate
         try:
-            r = subprocess.run(base + ["--config", cfg, "--steps", "5", "--warmup", "3"], capture_output=True, text=True, timeout=timeout_s)
+            r = subprocess.run(base + ["--config", cfg, "--steps", str(steps), "--warmup", "3"], capture_output=True, text=True, timeout=timeout_s)
             doc = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
             out[cfg] = {"workload": doc["config"]["workload"], "frames_per_s": doc["value"], "ms_per_frame": doc["ms_per_step"],
                         "costvol_kernel_ms": doc["roofline"]["kernel_ms"], "costvol_hbm_frac": doc["roofline"]["frac"],
-                        "knet_layer_mfma_frac": doc.get("roofline_mfma", {}).get("frac"), "steps": 5, "warmup": 3}
+                        "knet_layer_mfma_frac": doc.get("roofline_mfma", {}).get("frac"), "steps": steps, "warmup": 3,
+                        "peak_hbm_gb": doc["config"].get("peak_hbm_gb")}
         except Exception as e:      # a companion must never cost the headline line
             out[cfg] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     try:
