@@ -127,6 +127,9 @@ def test_batch_of_two_equals_two_calls():
         ra, rb = net.forward_log(a, feats).clone(), net.forward_log(b, feats).clone()
         both = net.forward_log(torch.cat((a, b), 0), feats)
     assert torch.equal(both[0:1], ra) and torch.equal(both[1:2], rb)
+    with torch.no_grad():       # a larger batch is refined in pairs (the persistent buffers exist for the path's two batch sizes)
+        three = net.forward_log(torch.cat((a, b, a), 0), feats)
+    assert three.shape[0] == 3 and torch.equal(three[0:1], ra) and torch.equal(three[1:2], rb) and torch.equal(three[2:3], ra)
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 24, 40, 128, 128), (1, 19, 35, 64, 64)])
