@@ -270,6 +270,12 @@ def cpu_baseline_train(model, cam, d_candi, wins, sigma):
                       "one first-frame iteration (%.1f s, untimed)" % (times[1], times[0])}
 
 
+def max_tie_flips(ties, mean_abs, tie_tol=1e-3):
+    """= tests/conftest.py::max_tie_flips: twice the expected number of arg-max flips among `ties` near-tie pixels at the measured
+    L1 (a flip needs the two candidates' error difference, <= 2 mean|d| in expectation, to exceed a gap spread over [0, tie_tol])."""
+    return max(2, int(np.ceil(ties * min(1.0, 4.0 * float(mean_abs) / tie_tol))))
+
+
 def parity_block(cfg, gpu, oracle_out):
     """GPU frame vs the oracle's frame on the same window and the same filter state: max / mean |d| and arg-max
     depth-index mismatches of BV_cur, DPV, BV_predict and the refined DPV (BASELINE.json gates: L1 < 1e-4, arg-max exact)."""
@@ -282,18 +288,22 @@ def parity_block(cfg, gpu, oracle_out):
         bad = ig != io
         # a flipped pixel is a TIE when the oracle's own values at the two indices are within 1e-3 of each other
         gap = (o.gather(0, io[None]) - o.gather(0, ig[None]))[0]
+        top2 = o.topk(2, dim=0).values
+        ties = int(((top2[0] - top2[1]) < 1e-3).sum())            # the oracle-side tie population: where two fp32 evaluations may flip
         blk[name] = {"max": float(d.max()), "mean": float(d.mean()), "argmax_mismatch": int(bad.sum()),
-                     "argmax_mismatch_beyond_tie_1e-3": int((bad & (gap > 1e-3)).sum()), "pixels": int(g[0].numel())}
+                     "argmax_mismatch_beyond_tie_1e-3": int((bad & (gap > 1e-3)).sum()), "pixels": int(g[0].numel()),
+                     "oracle_ties_within_1e-3": ties, "argmax_mismatch_bound": max_tie_flips(ties, float(d.mean()))}
     # gates: L1 < 1e-4 on every volume; arg-max identical on the depth volumes (BV_predict's faces are overwritten with a
     # constant, so its arg-max is a tie by construction: reported only).  "pass_strict" = bit-exact arg-max; "pass" also
-    # accepts flips at pixels whose two best candidates are within 1e-3 in the oracle itself, at most 8 per frame and volume
-    # (the policy of the parity tests, DESIGN.md §3: 0-2 such ties per frame are measured at S / B / H, up to 6 at K, none beyond a tie)
+    # accepts flips at pixels whose two best candidates are within 1e-3 in the oracle itself, at most max_tie_flips(tie population
+    # of the oracle's volume, measured L1) of them — the policy of the parity tests (tests/conftest.py), a bound the
+    # unmodified reference obeys against itself on every fixture (ref_self below)
     depth_vols = ("refined", "dpv", "bv_cur")
     l1 = all(blk[n]["mean"] < 1e-4 for n in names)
     blk["max_abs_gate"] = MAX_ABS_GATE
     mx = all(blk[n]["max"] <= MAX_ABS_GATE for n in names)
     blk["pass_strict"] = l1 and all(blk[n]["max"] <= 1e-4 for n in names) and all(blk[n]["argmax_mismatch"] == 0 for n in depth_vols)
-    blk["pass"] = l1 and mx and all(blk[n]["argmax_mismatch_beyond_tie_1e-3"] == 0 and blk[n]["argmax_mismatch"] <= 8
+    blk["pass"] = l1 and mx and all(blk[n]["argmax_mismatch_beyond_tie_1e-3"] == 0 and blk[n]["argmax_mismatch"] <= blk[n]["argmax_mismatch_bound"]
                                     for n in depth_vols)
     # a trilinear resample is a convex combination: with the pose inverse owned by the path (same matrix on both sides)
     # BV_predict cannot differ by more than the DPV it resamples does
@@ -352,25 +362,31 @@ MAX_ABS_GATE = 1e-3      # = tests/conftest.py::MAX_ABS_TOL
 TOLERANCE_POLICY = (
     "north_star: arg-max depth index bit-exact, DPV floats within 1e-4.  Asserted here (pass): mean |d| (L1) < 1e-4 on every volume; "
     "max |d| <= 1e-3 on every volume (HARD); arg-max identical except at pixels whose two best candidates are within 1e-3 in the ORACLE's "
-    "own volume (ties: <= 8 per frame and volume, none beyond a tie).  Why "
+    "own volume (ties: at most max_tie_flips(oracle-side tie population, measured L1) per frame and volume — `argmax_mismatch_bound` —, none beyond a tie).  Why "
     "not 1e-4 max: the `ref_self` sub-block — the UNMODIFIED reference against ITSELF on the config-S windows when only its execution "
-    "changes (oneDNN convolutions on / off, 8 threads / 1; tests/golden/ref_selfnoise_S.npz, oracle/gen_golden.py selfnoise) — differs by up "
-    "to 6.2e-4 (max) in DPV; the `fp64` sub-block shows both fp32 evaluations 1e-3-class (max) away from the same graph in float64.  "
+    "changes (oneDNN convolutions on / off, 8 threads / 1; tests/golden/ref_selfnoise_{S,K,ST}.npz, oracle/gen_golden.py selfnoise*: config S, config K "
+    "and config S with trained-like weights) — differs by up to 6.2e-4 (max) in DPV and flips 1-2 arg-max indices among K's ~500 near-tie pixels; the `fp64` sub-block shows both fp32 evaluations 1e-3-class (max) away from the same graph in float64.  "
     "pass_strict = the gates as north_star words them (max <= 1e-4, no arg-max flip at all).")
 
 
 def ref_self_block():
-    """What two executions of the unmodified reference agree to (tests/golden/ref_selfnoise_S.npz): per volume of the update frame
-    [max |d|, mean |d|, arg-max flips, flips beyond a 1e-3 tie, pixels]."""
-    path = os.path.join(ROOT, "tests", "golden", "ref_selfnoise_S.npz")
-    if not os.path.isfile(path):
-        return None
-    g = np.load(path)
-    blk = {"fixture": "tests/golden/ref_selfnoise_S.npz", "config": "S (two frames, noise windows, seeds 101 / 102)",
-           "layout": "[max |d|, mean |d|, arg-max flips, flips beyond a 1e-3 tie, pixels]"}
-    for var in ("onednn_off", "threads_1"):
-        blk[var] = {k: [float(x) for x in g["%s_%s_f2" % (var, k)]] for k in ("refined", "dpv", "bv_cur", "pred")}
-    return blk
+    """What two executions of the unmodified reference agree to (tests/golden/ref_selfnoise_<tag>.npz: config S, config K, config S
+    with the trained-like weight family): per volume of the update frame [max |d|, mean |d|, arg-max flips, flips beyond a 1e-3
+    tie, pixels] + the reference-side tie population the flip bound is taken from."""
+    out = {"layout": "[max |d|, mean |d|, arg-max flips, flips beyond a 1e-3 tie, pixels]"}
+    desc = {"S": "config S (two frames, noise windows, seeds 101 / 102)", "K": "config K: KITTI grid 64x192, candidates 1-60 m (seeds 111 / 112)",
+            "ST": "config S with the trained-like weight family (synth.trained_like_state_dict; seeds 151 / 152)"}
+    for tag in ("S", "K", "ST"):
+        path = os.path.join(ROOT, "tests", "golden", "ref_selfnoise_%s.npz" % tag)
+        if not os.path.isfile(path):
+            continue
+        g = np.load(path)
+        blk = {"fixture": "tests/golden/ref_selfnoise_%s.npz" % tag, "config": desc[tag]}
+        for var in ("onednn_off", "threads_1"):
+            blk[var] = {k: [float(x) for x in g["%s_%s_f2" % (var, k)]] for k in ("refined", "dpv", "bv_cur", "pred")}
+        blk["ties_within_1e-3"] = {k: int(g["base_%s_f2_ties" % k]) for k in ("refined", "dpv", "bv_cur")}
+        out[tag] = blk
+    return out if len(out) > 1 else None
 
 
 def fp64_block(cfg, model, cam, d_candi, H, W, dev):
@@ -645,8 +661,8 @@ def main():
                     "--pmc child passes of this script (about a minute; N = 1 only)")
     ap.add_argument("--streams", type=int, default=1, help="independent video streams per GPU, each on its own HIP stream "
                     "(a step is then one frame of EVERY stream; the extra streams fill the tails of each other's kernels)")
-    ap.add_argument("--back-to-back", action="store_true", help="also report the sampling kernel re-launched 20x back to back between one pair "
-                    "of events (roofline.back_to_back_ms: the figure of rounds 1-4)")
+    ap.add_argument("--back-to-back", action="store_true", help="(kept for old command lines: roofline.back_to_back_ms — the sampling kernel re-launched "
+                    "20x back to back between one pair of events, the figure of rounds 1-4 — is always reported now)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short companion runs of configs S / K / H and of one "
                     "training step (N = 1, headline config only; about a minute)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU self-test of the N>1 harness
@@ -748,7 +764,7 @@ def main():
         k_ms, n_k = timer.in_frame_ms()
         got = knet_timer.in_frame_ms()
         c_ms, n_c = got if got is not None else (None, 0)
-        b2b_ms = timer.measure(20, warm=20) if args.back_to_back else None
+        b2b_ms = timer.measure(20, warm=20)      # rounds 1-4's figure, always beside the in-frame one (rounds stay comparable)
         algo = costvol_bytes(V, 67, D, h, w)
         achieved = algo / (k_ms * 1e-3) / 1e9
         traffic, traffic_note, sq = (None, "", None)
@@ -763,7 +779,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "config_id": args.config, "grid_hw": [h, w], "depth_candidates": D,
-                       "views": V + 1, "streams_per_gpu": S, "launch": "hipGraph replay" if stream._graph is not None else "eager",
+                       "views": V + 1, "streams_per_gpu": S, "streams_total": S * world, "launch": "hipGraph replay" if stream._graph is not None else "eager",
                        "parallelism": "replicas x%d (independent video streams)" % world,
                        "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9},
             "roofline": {"bound": "hbm", "kernel": "costvol_quad<L2,3> (fused warp + cost volume + log-softmax over depth, one launch)",

@@ -121,8 +121,14 @@ int nrgbd_costvol_fwd(const float* ref_nhwc, const float* src_nhwc,
 /* The same operation with the kernel generation chosen by the caller (tests and A/B measurements):
  * 0 = automatic (what nrgbd_costvol_fwd does), 1 = direct gather (any shape), 2 = LDS-staged, lane = pixel (Cp/4 in
  * {1,2,3,4,8,9,16,17}), 3 = quad: 4 lanes per (pixel, candidate) (Cp = 68 with C > 64, or Cp = C = 64; V <= 8; a view below 2 GB with a
- * row pitch below 16 MB and h * w < 2^24: 24-bit address multiplies; what 0 picks for those shapes).
- * A generation that does not support the shape returns NRGBD_E_SHAPE; nothing is substituted silently. */
+ * row pitch below 8 MB and h * w < 2^23: signed 24-bit address multiplies; what 0 picks for those shapes).
+ * A generation that does not support the shape returns NRGBD_E_SHAPE; nothing is substituted silently.
+ * `rays`: generations 1 and 3 accept ANY ray table.  Generation 3 stages the source texels a tile can touch from the images of the
+ * tile's four corner pixels — exact for the reference's pinhole table (warping/View.py:16-62: rays affine in (x, y), z = 1) — and
+ * re-evaluates from global memory every (16 pixels x 4 candidates) group in which a tap falls outside that prediction, so a
+ * unit-norm or distortion-corrected table costs time, never correctness (tests/test_gpu_ops.py: non-affine rays vs the C oracle).
+ * Generation 2 (not selected for the path's 64(+3)-channel texels) relies on the corner prediction with one texel of slack and
+ * REQUIRES the pinhole table; pass generation 1 for any other table with its channel counts. */
 int nrgbd_costvol_fwd_gen(const float* ref_nhwc, const float* src_nhwc,
                       const float* KR, const float* Kt, const float* rays,
                       const float* d_candi, float cx, float cy, float sigma,
@@ -322,7 +328,7 @@ int nrgbd_conv3d_wgrad_f32(const float* x, const float* gy, float* partial, floa
                            int D, int H, int W, int Cin, void* stream);
 int nrgbd_bn3d_finalize(const float* stats, int num_workgroups, long count,
                         const float* gamma, const float* beta, float eps, float momentum,
-                        float* running_mean, float* running_var, float* scale_shift, void* stream);
+                        float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count, void* stream);
 
 /*
  * 2-D feature CNN helpers (NCHW, HW % 4 == 0, 16-B aligned planes).
@@ -385,7 +391,8 @@ int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, const float
  * the forward stream at w_wino, the data-gradient stream right behind it (w_wino holds 2 * Cout*Cin*kd*16 floats; Cin % 64 too). */
 int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int Cout, int kd, int transposed, void* stream);
 int nrgbd_bn_finalize_cm(const float* stats, int rows, int C, long count, const float* gamma, const float* beta, float eps,
-                         float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream);
+                         float momentum, float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count,
+                         void* stream);
 int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
                         int res_relu, float* materialized, const float* w_wino, float* y, float* stats,
                         int N, int H, int W, int Cin, int Cout, int kd, int dilation, void* stream);
@@ -457,6 +464,10 @@ int nrgbd_rnet_pack(const float* dpv_log, const float* feat, int feat_planar, fl
  *   Cin % 16 == 0; (Cout, dilation) in {(32,1), (64,1), (96,1), (128,1), (128,2)}; N*H*W*Cin < 2^32.
  * nrgbd_bn_finalize: partials [num_workgroups][2*C] -> scale_shift [C][2] = (gamma*invstd, beta - mean*gamma*invstd),
  *   reduced in double; running_mean / running_var (both or neither) get the train-mode update.
+ *   VARIANCE COLLAPSE (all three finalisers): the variance is E[y^2] - mean^2 over fp32 per-tile partials; a channel whose computed
+ *   variance is below 1e-5 mean^2 (std / |mean| < 3.2e-3: no correct digit left; the reference's two-pass statistics would still
+ *   normalise it) gets scale = shift = NaN AND is counted into *collapse_count (device word, may be NULL; atomicAdd of 1 per
+ *   channel) — the kernels' ReLU maps NaN to 0, so the NaN alone could vanish again; the host mirror raises on a non-zero word.
  * nrgbd_nhwc_stats: the same partials for a channels-last tensor produced elsewhere (the stride-2 / 1x1 layers that
  *   stay on the vendor library): x [P][C], stats [nrgbd_nhwc_stats_workgroups(P)][2*C]; C in {32, 64, 128}.
  * nrgbd_nhwc_act: y[p*ldy + c] = act(x*s+t) [+ act(res*s'+t')] — the loader's prologue as a stand-alone pass, for
@@ -498,7 +509,7 @@ int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_relu,
                          void* stream);
 int nrgbd_bn_finalize(const float* stats, int num_workgroups, int C, long count,
                       const float* gamma, const float* beta, float eps, float momentum,
-                      float* running_mean, float* running_var, float* scale_shift, void* stream);
+                      float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count, void* stream);
 /*
  * nrgbd_spp_concat — the tail of the feature CNN's spatial-pyramid pooling in one channels-last pass.
  * Replaces: models/psm_submodule.py:149-161 — for the four branches nn.ReLU after convbn (:100-117 branch1..4), F.upsample(

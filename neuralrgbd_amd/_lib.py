@@ -52,7 +52,7 @@ SIGNATURES = {
     "nrgbd_conv_wino_rnet_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_rnet_ex_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "nrgbd_bn_finalize_cm": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P]),
+    "nrgbd_bn_finalize_cm": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "nrgbd_conv_wino_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_dw_pack": (_I, [_P, _P, _I, _I, _I, _P]),
     "nrgbd_conv_wino_dw_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -60,7 +60,7 @@ SIGNATURES = {
     "nrgbd_conv_wino_dw_unit_f32": (_I, [_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv3d_wgrad_workgroups": (_I, []),
     "nrgbd_conv3d_wgrad_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "nrgbd_bn3d_finalize": (_I, [_P, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P]),
+    "nrgbd_bn3d_finalize": (_I, [_P, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "nrgbd_bn2d_partial_floats": (_I, [_I]),
     "nrgbd_bn2d_train_act": (_I, [_P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _L, _P]),
     "nrgbd_avgpool8": (_I, [_P, _P, _I, _I, _I, _P]),
@@ -74,7 +74,7 @@ SIGNATURES = {
     "nrgbd_conv2d_3x3_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv2d_rnet_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_rnet_pack": (_I, [_P, _P, _I, _P, _I, _I, _L, _P]),
-    "nrgbd_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P]),
+    "nrgbd_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "nrgbd_logsoftmax_rows": (_I, [_P, _P, _L, _I, _P]),
     "nrgbd_logsoftmax_d_bwd": (_I, [_P, _P, _F, _P, _I, _L, _P]),
     "nrgbd_logsoftmax_rows_bwd": (_I, [_P, _P, _P, _L, _I, _P]),

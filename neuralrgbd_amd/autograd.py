@@ -141,9 +141,12 @@ class BatchNormActCL(torch.autograd.Function):
 
 
 def batch_norm_act_cl(x_cl, bn, relu, residual=None):
-    """Train-mode nn.BatchNorm{2,3}d `bn` (+ ReLU, + residual) applied to the channels-last tensor x_cl [..., C] under autograd:
-    csrc/bn_train.hip in both directions; eval-mode norms and the few shapes bn_train.hip has no form for (C / 4 not dividing a
-    256-lane workgroup) are torch's batch_norm / relu / add."""
+    """nn.BatchNorm{2,3}d `bn` (+ ReLU, + residual) applied to the channels-last tensor x_cl [..., C] under autograd.
+    Batch statistics (train mode, or a norm without running statistics: every norm of the reference as it is run):
+    csrc/bn_train.hip in both directions.  Running statistics (a model the caller switched to eval()): the norm is the per-channel
+    affine map x * s + t with s = gamma / sqrt(running_var + eps) — elementwise tensor arithmetic, differentiable as it is.
+    On the GPU there is no other route: a channel count bn_train.hip has no form for raises NrgbdError (never F.batch_norm, i.e.
+    MIOpen — ADVICE r5).  CPU tensors (host-side structure tests) go through torch.nn.functional."""
     import torch.nn.functional as F
     C = x_cl.shape[-1]
     use_batch = bn.training or not bn.track_running_stats
@@ -151,13 +154,24 @@ def batch_norm_act_cl(x_cl, bn, relu, residual=None):
     if upd:
         bn.num_batches_tracked += 1
     m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-    if use_batch and x_cl.is_cuda and x_cl.dtype == torch.float32 and bn.affine and ops.bn_cl_supported(x_cl.numel() // C, C):
+    on_gpu = x_cl.is_cuda and x_cl.dtype == torch.float32
+    if on_gpu and use_batch:
+        if not (bn.affine and ops.bn_cl_supported(x_cl.numel() // C, C)):
+            from ._lib import NrgbdError
+            raise NrgbdError("no hand-written kernel for a batch-statistics BatchNorm over %d channels (affine=%s): csrc/bn_train.hip "
+                             "covers C %% 4 == 0 with C / 4 dividing 256" % (C, bn.affine))
         if x_cl.numel() // C <= 1:      # nn.BatchNorm's own refusal (torch/nn/functional.py::_verify_batch_size)
             raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x_cl.shape),))
         return BatchNormActCL.apply(x_cl, bn.weight, bn.bias, residual, bn.eps, relu, m,
                                     bn.running_mean if upd else None, bn.running_var if upd else None)
-    y = F.batch_norm(x_cl.reshape(-1, C), bn.running_mean if bn.track_running_stats else None,
-                     bn.running_var if bn.track_running_stats else None, bn.weight, bn.bias, use_batch, m, bn.eps).view_as(x_cl)
+    if on_gpu:                          # eval(): the affine map of the running statistics
+        s_ = torch.rsqrt(bn.running_var + bn.eps)
+        if bn.affine:
+            s_ = s_ * bn.weight
+        y = x_cl * s_ + ((bn.bias if bn.affine else 0.0) - bn.running_mean * s_)
+    else:
+        y = F.batch_norm(x_cl.reshape(-1, C), bn.running_mean if bn.track_running_stats else None,
+                         bn.running_var if bn.track_running_stats else None, bn.weight, bn.bias, use_batch, m, bn.eps).view_as(x_cl)
     if relu:
         y = torch.relu(y)
     return y if residual is None else y + residual

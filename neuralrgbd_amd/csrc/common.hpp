@@ -182,6 +182,39 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Last step of every batch-statistics finaliser (conv2d.hip, conv3d.hip, wino_pc.hip): (sum, sum of squares) over `count`
+// values, reduced in fp64 from the convolution epilogues' fp32 per-tile partials -> BatchNorm (scale, shift) + running statistics.
+// VARIANCE-COLLAPSE GUARD.  The variance is E[y^2] - mean^2; a tile's fp32 partial of y^2 carries a relative
+// error of up to ~1.5e-5 (256 sequential adds), so the computed variance is off by up to ~1.5e-5 mean^2.  When it comes out below
+// kBnCollapse * mean^2 (std / |mean| < 3.2e-3) it has no correct digit left: the reference (ATen: two-pass statistics) would still
+// normalise correctly, this path cannot — and the clamped-FMA ReLU of the K-Net (ops.relu_unit), whose bound assumes a computed
+// variance of at least a quarter of the true one, could saturate without an error.  Such a channel gets NaN as its scale: every
+// non-ReLU consumer sees NaN — and, because the kernels' ReLU (v_max_f32 / the FMA clamp) maps NaN to 0 and would hide it again,
+// the finaliser also counts the channel into the caller's status word (`collapse_count`): the host mirror raises NrgbdError at its next
+// synchronisation point (neuralrgbd_amd.nets.check_status: KVNET's valid_dpv probe, DepthStream.step) instead of handing out a
+// wrong depth map.  No collapse reported => computed var >= 1e-5 mean^2 and true var <= computed + 1.5e-5 mean^2 <= 2.5 x computed:
+// inside relu_unit's factor 4.
+// (A channel that is exactly constant and non-zero would trip it too; a convolution without bias over a non-constant input has none.)
+constexpr double kBnCollapse = 1e-5;
+__device__ __forceinline__ void bn_finalize_channel(double sum, double sumsq, double count, float gamma, float beta, float eps,
+                                                    float momentum, float* running_mean, float* running_var, float* ss, int c,
+                                                    unsigned int* collapse_count) {
+    const double mean = sum / count;
+    double var = sumsq / count - mean * mean;
+    const bool collapsed = var < kBnCollapse * mean * mean;          // false for mean == 0 (a dead channel: var == 0, scale finite)
+    if (collapsed && collapse_count) atomicAdd(collapse_count, 1u);  // the caller's status word (nets.check_status raises on it)
+    var = var > 0.0 ? var : 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = collapsed ? __builtin_nanf("") : gamma * invstd;
+    ss[2 * c] = sc;
+    ss[2 * c + 1] = beta - (float)mean * sc;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 #define NRGBD_EXP_INF __builtin_inff()
 #define NRGBD_EXP_RINT __builtin_rint

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void nhwc_act_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int nwg, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ ss) {
+                                                          float* __restrict__ running_var, float* __restrict__ ss, unsigned int* __restrict__ collapse_count) {
     __shared__ double sh[2][256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
@@ -422,20 +422,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
         __syncthreads();
     }
-    if (tid == 0) {
-        const double mean = sh[0][0] / count;
-        double var = sh[1][0] / count - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        ss[2 * c] = sc;
-        ss[2 * c + 1] = beta[c] - (float)mean * sc;
-        if (running_mean) {
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
-    }
+    if (tid == 0) bn_finalize_channel(sh[0][0], sh[1][0], count, gamma[c], beta[c], eps, momentum, running_mean, running_var, ss, c, collapse_count);
 }
 
 template <int COUT, int DIL>
@@ -726,13 +713,13 @@ extern "C" int nrgbd_nhwc_act(const float* x, const float* x_ss, int x_relu, con
 
 extern "C" int nrgbd_bn_finalize(const float* stats, int num_workgroups, int C, long count, const float* gamma,
                                  const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                                 float* scale_shift, void* stream) {
+                                 float* scale_shift, unsigned int* collapse_count, void* stream) {
     using namespace nrgbd;
     if (!stats || !gamma || !beta || !scale_shift) return NRGBD_E_NULL;
     if (num_workgroups <= 0 || count <= 0 || C <= 0) return NRGBD_E_SHAPE;
     if ((running_mean == nullptr) != (running_var == nullptr)) return NRGBD_E_NULL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, num_workgroups, C,
-                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift);
+                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift, collapse_count);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

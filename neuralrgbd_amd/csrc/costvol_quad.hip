@@ -101,12 +101,13 @@ constexpr int kXor2 = 0x4E;  // [2,3,0,1]
 struct TapW { float nw, ne, sw, se; };
 
 // weights with zeros padding (a corner outside the image contributes nothing) + the un-clamped integer corner
-__device__ __forceinline__ TapW tap_weights(float ix, float iy, float wf, float hf, float& x0f, float& y0f) {
+__device__ __forceinline__ TapW tap_weights(float ix, float iy, float wf, float hf, float& x0f, float& y0f, bool& any) {
     x0f = floorf(ix); y0f = floorf(iy);
     const float fx = ix - x0f, fy = iy - y0f, ex = 1.f - fx, ey = 1.f - fy;
     const float x1f = x0f + 1.f, y1f = y0f + 1.f;
     const bool vx0 = (x0f >= 0.f) && (x0f <= wf - 1.f), vx1 = (x1f >= 0.f) && (x1f <= wf - 1.f);
     const bool vy0 = (y0f >= 0.f) && (y0f <= hf - 1.f), vy1 = (y1f >= 0.f) && (y1f <= hf - 1.f);
+    any = (vx0 || vx1) && (vy0 || vy1);          // some tap lies inside the image (lane masks: scalar-unit work)
     TapW t;
     t.nw = (vx0 && vy0) ? ey * ex : 0.f; t.ne = (vx1 && vy0) ? ey * fx : 0.f;
     t.sw = (vx0 && vy1) ? fy * ex : 0.f; t.se = (vx1 && vy1) ? fy * fx : 0.f;
@@ -245,21 +246,30 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
     // STAGED: taps from the LDS patch (box xlo..: pitch = cols); otherwise straight from global memory.  The NI x 4
     // (candidate, step) tap fetches run as one software pipeline, PD steps ahead of the math (LDS: 1, global memory: 2).
     auto group = [&](auto staged_c, auto ni_c, const float* sv, const SweepTerm& st, int k0, int ncand, int xlo, int xhi,
-                     int ylo, int yhi, int cols) -> float {
+                     int ylo, int yhi, int cols, bool& escaped) -> float {
         constexpr bool STAGED = decltype(staged_c)::value;
         constexpr int NI = decltype(ni_c)::value;
         constexpr int PD = STAGED ? 1 : 2;
         const int kc = min(k0 + j, k0 + ncand - 1);          // lanes beyond the group repeat its last candidate
         float ix, iy, x0f, y0f;
         sweep_sample_pos_fast<ALIGN>(st, dcand[kc], a.cx, a.cy, a.rcx, a.rcy, wf, hf, ix, iy);
-        const TapW tw = tap_weights(ix, iy, wf, hf, x0f, y0f);
+        bool any_tap;
+        const TapW tw = tap_weights(ix, iy, wf, hf, x0f, y0f, any_tap);
         // tap addresses: STAGED one patch address (apron => the 3 other taps are +256, +pitch, +pitch+256);
         // global: four clamped texel offsets
         int adr[4];
         if constexpr (STAGED) {
-            const int xi = (int)fminf(fmaxf(x0f, (float)xlo), (float)(xhi - 1)) - xlo;   // NaN -> xlo
-            const int yi = (int)fminf(fmaxf(y0f, (float)ylo), (float)(yhi - 1)) - ylo;
+            const float xcl = fminf(fmaxf(x0f, (float)xlo), (float)(xhi - 1));           // NaN -> xlo
+            const float ycl = fminf(fmaxf(y0f, (float)ylo), (float)(yhi - 1));
+            const int xi = (int)xcl - xlo, yi = (int)ycl - ylo;
             adr[0] = __mul24(yi, cols) + xi;                  // texel index in the patch
+            // A tap with a non-zero weight that the clamp moved has LEFT the box the tile's corners predicted.  The box is exact for
+            // the pinhole ray table of the reference (warping/View.py:16-62: rays affine in (x, y), z = 1 — a homography maps the convex
+            // tile into the convex hull of its corners' images) and carries 1/64 texel of guard; another table (unit-norm or
+            // distortion-corrected rays: the C ABI takes any) can bend a tile's image out of it.  Legitimate clamps — a box clipped to
+            // the image's one-texel apron — only ever move taps whose weights are all zero.  The caller re-evaluates the group from
+            // global memory when any lane of the wave reports an escape: 2 compares per (pixel, candidate).
+            escaped = any_tap && ((xcl != x0f) || (ycl != y0f));
             adr[1] = adr[2] = adr[3] = 0;
         } else {
             const int xa = (int)fminf(fmaxf(x0f, 0.f), wf - 1.f), xb = (int)fminf(fmaxf(x0f + 1.f, 0.f), wf - 1.f);
@@ -540,12 +550,19 @@ __global__ __launch_bounds__(256, WGS) void costvol_quad(const CostvolArgs a) {
                     const int k0 = j0 + 4 * g, nc = min(4, n - 4 * g);   // candidates j0 .. j0 + n - 1 = this run
                     float* o = ldsA + quad * kQAccPitch + (min(k0 + j, ke - 1) - kb);   // this lane's candidate of the group; a quad is inside one wave: in-order LDS
                     const float prev = (v > 0) ? *o : 0.f;
-                    float acc;
-                    if (!staged) acc = group(F_{}, N4{}, sv, st, k0, nc, 0, 0, 0, 0, 0);
-                    else if (nc == 1) acc = group(T_{}, N1{}, sv, st, k0, 1, xlo, xhi, ylo, yhi, cols);
-                    else if (nc == 2) acc = group(T_{}, N2{}, sv, st, k0, 2, xlo, xhi, ylo, yhi, cols);
-                    else if (nc == 3) acc = group(T_{}, N3{}, sv, st, k0, 3, xlo, xhi, ylo, yhi, cols);
-                    else acc = group(T_{}, N4{}, sv, st, k0, 4, xlo, xhi, ylo, yhi, cols);
+                    float acc = 0.f;
+                    bool esc = false, from_lds = staged;
+#pragma unroll 1
+                    for (int attempt = 0; attempt < 2; ++attempt) {
+                        if (!from_lds) { acc = group(F_{}, N4{}, sv, st, k0, nc, 0, 0, 0, 0, 0, esc); break; }
+                        if (nc == 1) acc = group(T_{}, N1{}, sv, st, k0, 1, xlo, xhi, ylo, yhi, cols, esc);
+                        else if (nc == 2) acc = group(T_{}, N2{}, sv, st, k0, 2, xlo, xhi, ylo, yhi, cols, esc);
+                        else if (nc == 3) acc = group(T_{}, N3{}, sv, st, k0, 3, xlo, xhi, ylo, yhi, cols, esc);
+                        else acc = group(T_{}, N4{}, sv, st, k0, 4, xlo, xhi, ylo, yhi, cols, esc);
+                        if (__ballot(esc) == 0) break;          // wave-uniform: the 16 quads of a wave redo the group together
+                        CVT_COUNT(20, 1);
+                        from_lds = false;                       // a tap escaped the footprint box: this group straight from global memory
+                    }
                     if (j < nc) *o = prev + div_by_const(acc, a.sigma, a.rsigma);               // homography.py:325 (/ sigma), views in order
                 }
             }
@@ -614,8 +631,9 @@ bool costvol_quad_supported(const CostvolArgs& a) {
     const bool extra = a.Cp == 68 && a.C > 64;
     const bool plain = a.Cp == 64 && a.C == 64;
     // 32-bit byte offsets into a view; the LDS image (patch + 20 B per candidate + accumulators) has to fit a workgroup's share
-    // ... and a row pitch below 16 MB and fewer than 2^24 rows (24-bit multiplies in the patch fill)
-    return (extra || plain) && (long)a.h * a.w * a.Cp * 4 < (1L << 31) && (long)a.w * a.Cp * 4 < (1L << 24) && (long)a.h * a.w < (1L << 24) && a.D <= NRGBD_MAX_D;
+    // ... and a row pitch below 8 MB and fewer than 2^23 pixels: the address arithmetic uses __mul24, a SIGNED 24-bit multiply whose
+    // operands must stay below 2^23 (a pitch in [8, 16) MB would be sign-extended to a negative offset)
+    return (extra || plain) && (long)a.h * a.w * a.Cp * 4 < (1L << 31) && (long)a.w * a.Cp * 4 < (1L << 23) && (long)a.h * a.w < (1L << 23) && a.D <= NRGBD_MAX_D;
 }
 
 // Returns NRGBD_OK and sets *did_softmax when the launch also produced out_logp.

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
 __global__ __launch_bounds__(1024) void bn_finalize_cm_kernel(const float* __restrict__ stats, int rows, int C, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float eps, float momentum, float* __restrict__ running_mean,
-                                                              float* __restrict__ running_var, float* __restrict__ ss) {
+                                                              float* __restrict__ running_var, float* __restrict__ ss, unsigned int* __restrict__ collapse_count) {
     __shared__ double sh[2][1024];
     const int c = blockIdx.x, tid = threadIdx.x;
     const float* p1 = stats + (size_t)c * rows;
@@ -649,20 +649,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_cm_kernel(const float* __res
         if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
         __syncthreads();
     }
-    if (tid == 0) {
-        const double mean = sh[0][0] / count;
-        double var = sh[1][0] / count - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        ss[2 * c] = sc;
-        ss[2 * c + 1] = beta[c] - (float)mean * sc;
-        if (running_mean) {
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
-    }
+    if (tid == 0) bn_finalize_channel(sh[0][0], sh[1][0], count, gamma[c], beta[c], eps, momentum, running_mean, running_var, ss, c, collapse_count);
 }
 
 // w [Cout][Cin][KD][3][3] -> U = G g G^T (float64, rounded once) in the kernel's B-operand order
@@ -717,14 +704,14 @@ extern "C" int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int 
 }
 
 extern "C" int nrgbd_bn_finalize_cm(const float* stats, int rows, int C, long count, const float* gamma, const float* beta,
-                                    float eps, float momentum, float* running_mean, float* running_var, float* scale_shift,
+                                    float eps, float momentum, float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count,
                                     void* stream) {
     using namespace nrgbd;
     if (!stats || !gamma || !beta || !scale_shift) return NRGBD_E_NULL;
     if (rows <= 0 || count <= 0 || C <= 0) return NRGBD_E_SHAPE;
     if ((running_mean == nullptr) != (running_var == nullptr)) return NRGBD_E_NULL;
     hipLaunchKernelGGL(bn_finalize_cm_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, stats, rows, C, (double)count, gamma,
-                       beta, eps, momentum, running_mean, running_var, scale_shift);
+                       beta, eps, momentum, running_mean, running_var, scale_shift, collapse_count);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

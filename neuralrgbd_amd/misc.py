@@ -14,7 +14,13 @@ def valid_dpv(dpv_in):
     assert isinstance(dpv_in, torch.Tensor), 'input should a Tensor'
     if not 2 <= dpv_in.dim() <= 5:
         raise Exception('wrong dimension for input dpv !')
-    return not bool(torch.isnan(dpv_in[(0,) * dpv_in.dim()]))
+    ok = not bool(torch.isnan(dpv_in[(0,) * dpv_in.dim()]))
+    if dpv_in.is_cuda:
+        # the path's own failure report rides on this synchronisation: a BatchNorm whose batch statistics collapsed in the frame
+        # that produced dpv_in raises here (nets.check_status) instead of passing on a wrong volume
+        from .nets import check_status
+        check_status(dpv_in.device)
+    return ok
 
 
 def depth_val_regression(BV_measure, d_candi_cur, BV_log=True):

@@ -170,6 +170,37 @@ class _PackedWeightsMixin(object):
         return out
 
 
+# ------------------------------------------------------------------ status word (variance collapse; include/nrgbd.h)
+_status_words = {}
+
+
+def status_word(device):
+    """The int32 device word the BatchNorm finalisers count variance-collapsed channels into (csrc/common.hpp
+    bn_finalize_channel): one per device, allocated once (its address is baked into captured hipGraphs)."""
+    key = str(device)
+    w = _status_words.get(key)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=device)
+        _status_words[key] = w
+    return w
+
+
+def check_status(device):
+    """Raise NrgbdError when a BatchNorm finaliser reported a variance collapse since the last check (one device -> host read of
+    4 bytes: called where the path synchronises anyway — misc.valid_dpv, DepthStream's deferred probe).  The reference's two-pass
+    statistics would still normalise such a channel; this path cannot (E[y^2] - mean^2 has no digit left), and says so instead of
+    handing out a wrong depth map."""
+    w = _status_words.get(str(device))
+    if w is None:
+        return
+    n = int(w.item())
+    if n:
+        w.zero_()
+        from ._lib import NrgbdError
+        raise NrgbdError("BatchNorm batch statistics collapsed in %d channel(s) (std / |mean| < 3.2e-3: the variance E[y^2] - mean^2 of "
+                         "the convolution epilogues has no correct digit left); the frame's outputs are invalid" % n)
+
+
 def _bn_scale_shift(bn, stats, count, cm=False):
     """(scale, shift) [C,2] of a BatchNorm: batch statistics from the conv epilogue's partials in train mode (the
     reference never leaves it) incl. the running-statistics side effect; running statistics in eval mode.
@@ -182,7 +213,7 @@ def _bn_scale_shift(bn, stats, count, cm=False):
         momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
         fin = ops.bn_finalize_cm if cm else ops.bn_finalize
         return fin(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, momentum,
-                   bn.running_mean if upd else None, bn.running_var if upd else None)
+                   bn.running_mean if upd else None, bn.running_var if upd else None, status=status_word(stats.device))
     sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
     return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 
@@ -549,7 +580,7 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
             momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             fin = ops.bn_finalize_cm if cm else ops.bn3d_finalize
             return fin(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, momentum,
-                       bn.running_mean if upd else None, bn.running_var if upd else None)
+                       bn.running_mean if upd else None, bn.running_var if upd else None, status=status_word(stats.device))
         sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 

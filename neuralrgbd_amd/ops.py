@@ -459,10 +459,12 @@ def relu_unit(gamma, beta, n):
     import math
     bound = float(gamma.detach().abs().max()) * math.sqrt(float(n)) + float(beta.detach().abs().max())
     # One extra power of two of headroom (free: a power-of-two unit changes no bit below saturation).  The bound is exact for exact
-    # statistics; the kernels finalise the variance as E[y^2] - mean^2 from fp32 per-tile sums (in float64), which UNDER-estimates it
-    # when |mean| >> std (cancellation at ~1e-7 E[y^2]) and so over-scales the normalised values: the factor 2 covers a computed
-    # variance down to a quarter of the true one, i.e. std / |mean| down to ~1e-3 — beyond that the clamp would saturate instead of
-    # failing (conv outputs in front of a BatchNorm are zero-mean to within a few std in every layer of this network)
+    # statistics; the kernels finalise the variance as E[y^2] - mean^2 from fp32 per-tile sums (in float64), which can UNDER-estimate
+    # it when |mean| >> std (a tile's partial of y^2 is good to ~1.5e-5 relative) and so over-scale the normalised values.  The
+    # finalisers guard the other side (csrc/common.hpp bn_finalize_channel): a channel whose computed variance falls below
+    # 1e-5 mean^2 gets a NaN scale (loud: the frame's outputs are NaN, valid_dpv trips) — whenever the scale is finite the computed
+    # variance is at least 1 / 2.5 of the true one, inside the factor 4 that the doubled bound covers.  The clamp can therefore not
+    # saturate silently (tests/test_gpu_knet.py constructs the collapsing channel)
     return 2.0 ** -max(0, math.floor(math.log2(max(2.0 * bound, 1e-30))) + 1)
 
 
@@ -521,13 +523,23 @@ def conv3d_cout1(x, w_tap_major, x_ss=None, x_relu=False, res=None, res_ss=None,
     return y
 
 
-def bn3d_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
-    """Per-workgroup partials -> scale_shift [64,2]; updates the running statistics in place (train mode)."""
+def _status_ptr(status, like):
+    if status is None:
+        return ctypes.c_void_p(0)
+    if not (isinstance(status, torch.Tensor) and status.is_cuda and status.dtype == torch.int32 and status.numel() >= 1 and status.device == like.device):
+        raise TypeError("status must be an int32 tensor on the device of the statistics")
+    return ctypes.c_void_p(status.data_ptr())
+
+
+def bn3d_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, status=None):
+    """Per-workgroup partials -> scale_shift [64,2]; updates the running statistics in place (train mode).
+    status: int32 device word that counts variance-collapsed channels (include/nrgbd.h; nets.check_status raises on it)."""
     stats = _need(stats, "stats")
     ss = torch.empty((64, 2), dtype=torch.float32, device=stats.device)
     with torch.cuda.device(stats.device):
         rc = _lib.load().nrgbd_bn3d_finalize(_p(stats), stats.shape[0], int(count), _p(gamma), _p(beta), float(eps),
-                                             float(momentum), _p(running_mean), _p(running_var), _p(ss), _stream(stats))
+                                             float(momentum), _p(running_mean), _p(running_var), _p(ss), _status_ptr(status, stats),
+                                             _stream(stats))
     _lib.check(rc, "nrgbd_bn3d_finalize")
     return ss
 
@@ -685,14 +697,15 @@ def rnet_pack(dpv_log, feat, feat_planar, out=None):
     return out
 
 
-def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, status=None):
     """Per-workgroup partials [nwg, 2C] -> scale_shift [C,2]; updates the running statistics in place (train mode)."""
     stats = _need(stats, "stats")
     C = stats.shape[1] // 2
     ss = torch.empty((C, 2), dtype=torch.float32, device=stats.device)
     with torch.cuda.device(stats.device):
         rc = _lib.load().nrgbd_bn_finalize(_p(stats), stats.shape[0], C, int(count), _p(gamma), _p(beta), float(eps),
-                                           float(momentum), _p(running_mean), _p(running_var), _p(ss), _stream(stats))
+                                           float(momentum), _p(running_mean), _p(running_var), _p(ss), _status_ptr(status, stats),
+                                           _stream(stats))
     _lib.check(rc, "nrgbd_bn_finalize")
     return ss
 
@@ -762,14 +775,15 @@ def bn_cl_bwd(x, gy, coef, relu):
     return gx, gg[0], gg[1]
 
 
-def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, status=None):
     """Column-major per-tile partials [2C, rows] (conv_wino) -> scale_shift [C,2]; updates the running statistics in place."""
     stats = _need(stats, "stats")
     C = stats.shape[0] // 2
     ss = torch.empty((C, 2), dtype=torch.float32, device=stats.device)
     with torch.cuda.device(stats.device):
         rc = _lib.load().nrgbd_bn_finalize_cm(_p(stats), stats.shape[1], C, int(count), _p(gamma), _p(beta), float(eps),
-                                              float(momentum), _p(running_mean), _p(running_var), _p(ss), _stream(stats))
+                                              float(momentum), _p(running_mean), _p(running_var), _p(ss), _status_ptr(status, stats),
+                                              _stream(stats))
     _lib.check(rc, "nrgbd_bn_finalize_cm")
     return ss
 

@@ -35,10 +35,23 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         """torch.optim.Adam checkpoints load as they are (train_KVNet.py:347 saves `optimizer.state_dict()`), except AMSGrad
         ones: this kernel keeps no running maximum of the second moment, and dropping it silently would change the training."""
-        super().load_state_dict(state_dict)
-        for group in self.param_groups:
+        for group in state_dict.get("param_groups", ()):       # refuse BEFORE any state is replaced
             if group.get("amsgrad"):
                 raise _lib.NrgbdError("FusedAdam: the loaded param_group has amsgrad=True; this optimizer has no AMSGrad form")
+        super().load_state_dict(state_dict)
+        # a checkpoint of the reference's torch era (< 1.12) carries only lr / betas / eps / weight_decay / amsgrad per group:
+        # super() REPLACES the groups with the loaded ones, so the keys step() reads (`maximize`) are filled from the defaults
+        for group in self.param_groups:
+            for k, v in self.defaults.items():
+                group.setdefault(k, v)
+        self._tables = {}                                       # the moments are new tensors: the pointer tables are stale
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for group in self.param_groups:
+            for k, v in self.defaults.items():
+                group.setdefault(k, v)
+        self._tables = {}
 
     def mark_updated(self):
         """Advance the version counter of every parameter this optimizer owns.  The kernel writes through raw pointers, which

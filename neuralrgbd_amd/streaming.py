@@ -5,9 +5,12 @@ Python, one device->host probe (`valid_dpv`), a host-built point grid and its H2
 same per-frame semantics (KVNET.forward + PREDICT, i.e. exactly `neuralrgbd_amd.test_step.test`) but
 
   * keeps BV_predict and the validity flag on its own side (no device->host read in the steady state),
-  * optionally captures the whole update-branch frame into ONE hipGraph (torch.cuda.CUDAGraph) after a warm-up
-    frame, and replays it per frame: every kernel of libnrgbd_hip.so is capture-safe (no allocation, no host
-    sync), the vendor convolutions are captured after their algorithm search has run.
+  * captures the whole update-branch frame into ONE hipGraph (torch.cuda.CUDAGraph) after a warm-up frame, and
+    replays it per frame: every kernel of libnrgbd_hip.so is capture-safe (no allocation, no host sync, no
+    algorithm search — there is no vendor convolution on the path).  A capture that fails RAISES unless the stream
+    was built with allow_eager_fallback=True (then it stays eager and `graph_error` says why).
+  * reads the path's status word (BatchNorm variance collapse, nets.check_status) without stalling: every step
+    queues a 4-byte copy to pinned host memory behind the frame and inspects the PREVIOUS step's copy.
 
 Config 5 of BASELINE.json (a 300-frame high-resolution stream) is this object in a loop.
 """
@@ -26,7 +29,8 @@ def _capture_mode():
 
 
 class DepthStream:
-    def __init__(self, model, cam_intrinsics, d_candi, t_win_r=2, use_graph=True, device=None, copy_outputs=False):
+    def __init__(self, model, cam_intrinsics, d_candi, t_win_r=2, use_graph=True, device=None, copy_outputs=False,
+                 allow_eager_fallback=False):
         self.model = model
         self.cam = cam_intrinsics
         self.d_candi = d_candi
@@ -43,6 +47,9 @@ class DepthStream:
         self._static = None
         self._eager_updates = 0
         self.graph_error = None
+        self.allow_eager_fallback = allow_eager_fallback
+        self._status_host = None        # pinned int32: the status word as of the previous step
+        self._status_event = None
 
     def reset(self):
         """Invalid pose / new trajectory: drop the filter state (test_KVNet.py:241-246)."""
@@ -71,6 +78,23 @@ class DepthStream:
         st["consts"] = warp_homo.cache_snapshot()      # K / rays / d_candi the graph reads: kept alive with the graph
         self._graph, self._static = g, st
 
+    def _probe_status(self):
+        """Deferred, stall-free read of the status word: raise on what the PREVIOUS step's copy shows, queue this step's copy."""
+        from . import nets
+        if self._status_event is not None and self._status_event.query() and int(self._status_host[0]) != 0:
+            nets.check_status(self.device)          # reads, clears and raises
+        word = nets.status_word(self.device)
+        if self._status_host is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._status_event = torch.cuda.Event()
+        self._status_host.copy_(word, non_blocking=True)
+        self._status_event.record(torch.cuda.current_stream(self.device))
+
+    def check(self):
+        """Synchronous form of the status probe (end of a sequence): raises NrgbdError on a reported variance collapse."""
+        from . import nets
+        nets.check_status(self.device)
+
     # ------------------------------------------------------------------ public step
     def step(self, ref_frame, src_frames, src_cam_poses, cam_pose_next=None):
         """ref_frame [1,3,H,W], src_frames [1,V,3,H,W], src_cam_poses [1,V,4,4] (device tensors).
@@ -83,13 +107,16 @@ class DepthStream:
         if self.bv_predict is None:                      # first window of the stream: D-Net only
             r, dpv, nxt = self._frame(ref_frame, src_frames, src_cam_poses, pose_next, None)
             self.bv_predict = nxt
+            self._probe_status()
             return r, dpv
         if self.use_graph and self._graph is None and self.graph_error is None and self._eager_updates >= 1:
             try:
                 self._capture(ref_frame, src_frames, src_cam_poses, pose_next)
-            except Exception as e:  # keep running eagerly, but say so
+            except Exception as e:
                 self.graph_error = repr(e)
                 self._graph = None
+                if not self.allow_eager_fallback:      # a library user must not silently run at eager speed
+                    raise
                 print("[DepthStream] hipGraph capture failed, staying eager: %s" % self.graph_error)
         if self._graph is not None:
             st = self._static
@@ -98,10 +125,12 @@ class DepthStream:
             self._graph.replay()
             r, dpv, nxt = st["out"]
             self.bv_predict = nxt        # static output buffer: copied into st["bv"] at the next step
+            self._probe_status()
             if self.copy_outputs:
                 return r.clone(), dpv.clone()
             return r, dpv                # valid until the next step() (see copy_outputs)
         r, dpv, nxt = self._frame(ref_frame, src_frames, src_cam_poses, pose_next, self.bv_predict)
         self._eager_updates += 1
         self.bv_predict = nxt
+        self._probe_status()
         return r, dpv

@@ -192,3 +192,55 @@ def seeded_state_dict(model, seed=0):
         else:  # BatchNorm beta / conv bias
             out[name] = torch.from_numpy((0.05 * rng.standard_normal(shape)).astype(np.float32))
     return out
+
+
+def trained_like_state_dict(model, seed=0, offset=2.0):
+    """Weights in the regime of a TRAINED checkpoint rather than of an initialiser (the released
+    `kvnet_scannet.tar` cannot be fetched offline): BatchNorm gamma ~ +-U[0.2, 2.5] (one in ten negative), beta ~ N(0, 0.5);
+    every convolution in front of a BatchNorm gets a per-output-channel gain (log-normal) AND a per-output-channel offset
+    added to all of its taps, so that behind the non-negative ReLU activations of the previous layer its output has a mean
+    far from zero — |mean| / std of the pre-BatchNorm maps reaches ~10 and beyond (oracle/gen_golden.py prints the measured
+    distribution): the regime in which a variance taken as E[y^2] - mean^2 loses digits and in which the clamped-FMA ReLU's
+    bound is exercised.  Running statistics start away from (0, 1).  Convolutions without a BatchNorm behind them (R-Net,
+    the 1x1 head, the K-Net's last layer) keep the initialiser's distribution: their output scale is not normalised away.
+    Name-keyed like seeded_state_dict, so the reference model and this package's model receive identical tensors."""
+    base = seeded_state_dict(model, seed)
+    state = model.state_dict()
+    canon = {}
+    for name, ref in state.items():
+        key = (ref.data_ptr(), tuple(ref.shape))
+        canon[key] = min(canon.get(key, name), name)
+    dims = {name: ref.dim() for name, ref in state.items()}
+    out = {}
+    for name, ref in state.items():
+        cname = canon[(ref.data_ptr(), tuple(ref.shape))]
+        rng = np.random.RandomState((zlib.crc32(("trained/" + cname).encode()) + 7919 * seed) & 0x7FFFFFFF)
+        shape = tuple(ref.shape)
+        t = base[name]
+        stem, _, leaf = name.rpartition(".")
+        if leaf == "running_mean":
+            t = torch.from_numpy(rng.normal(0, 0.5, shape).astype(np.float32))
+        elif leaf == "running_var":
+            t = torch.from_numpy(rng.uniform(0.3, 3.0, shape).astype(np.float32))
+        elif leaf == "num_batches_tracked":
+            t = torch.full((), 1000, dtype=ref.dtype)
+        elif leaf == "weight" and ref.dim() >= 4 and stem.endswith(".0") and dims.get(stem[:-2] + ".1.weight") == 1:
+            # the convolution of a Sequential(conv, BatchNorm) (children '0', '1')
+            col = (shape[0],) + (1,) * (len(shape) - 1)
+            gain = np.exp(rng.normal(0, 0.5, col))
+            he = float(np.sqrt(2.0 / (int(np.prod(shape[2:])) * shape[0])))
+            off = offset * rng.normal(0, 1.0, col) * he
+            t = torch.from_numpy((t.numpy().astype(np.float64) * gain + off).astype(np.float32))
+        elif name.endswith("lastconv.2.weight") or name == "kv_net.classify.2.weight":
+            # the 1x1 head has no BatchNorm behind it: with gammas up to 2.5 in front of it the features (and with them the cost
+            # volume, quadratic in the features) would be ~30x the initialiser family's; a trained head keeps the cost in the range
+            # sigma_soft_max was tuned for.  0.25 brings BV_cur back to log-probabilities of -100 and above.  The K-Net's last layer
+            # (64 -> 1, no BatchNorm either) likewise: its output is a log-probability increment, which a trained net keeps moderate
+            t = t * 0.25
+        elif leaf == "weight" and ref.dim() == 1:                       # BatchNorm gamma
+            sign = np.where(rng.rand(*shape) < 0.1, -1.0, 1.0)
+            t = torch.from_numpy((sign * rng.uniform(0.2, 2.5, shape)).astype(np.float32))
+        elif leaf == "bias" and dims.get(stem + ".weight") == 1:        # BatchNorm beta
+            t = torch.from_numpy(rng.normal(0, 0.5, shape).astype(np.float32))
+        out[name] = t
+    return out

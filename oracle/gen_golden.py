@@ -28,6 +28,8 @@ CPU under the installed torch.  Outputs (small, committed):
   export_small.npz export_res_img run through the reference's own function; its two .pgm files read back
   ref_selfnoise_S.npz  the reference against ITSELF at config S (oneDNN on / off, 1 / all threads): the parity envelope; + its
                    refined (R-Net, D = 64) outputs as a golden
+  ref_selfnoise_K.npz   the same at config K (KITTI grid, 1-60 m: the volumes with the most near-ties): envelope + golden
+  ref_selfnoise_ST.npz  the same at config S with the TRAINED-LIKE weight family (synth.trained_like_state_dict): envelope + golden
   train_small.npz  two iterations of the reference's train() (first-frame + update branch, SGD): losses, predicted states,
                    weight deltas (= lr x gradient) of six probe tensors
 
@@ -444,21 +446,39 @@ def _tie_flips(a, b, tol=1e-3):
     return int(bad.sum()), int((bad & (np.abs(vb - va) > tol)).sum())
 
 
-def gen_selfnoise(ref):
-    """how far the UNMODIFIED reference is from ITSELF on the config-S two-frame windows when only the
+SELFNOISE_K = dict(H=256, W=768, D=64, seeds=(111, 112), sigma=10.0, d_min=1.0, d_max=60.0, weight_seed=0, sub=16, sub_q=4,
+                   intr="kitti", family="seeded")        # = the config-K parity test's windows (KITTI: the tie-richest volumes)
+SELFNOISE_ST = dict(H=256, W=384, D=64, seeds=(151, 152), sigma=10.0, d_min=0.1, d_max=5.0, weight_seed=0, sub=8, sub_q=2,
+                    intr="scannet", family="trained")    # config S with the trained-like weight family (synth.trained_like_state_dict)
+SELFNOISE = {"S": SELFNOISE_S, "K": SELFNOISE_K, "ST": SELFNOISE_ST}
+
+
+def selfnoise_setup(n):
+    """(cam, d_candi, weight function) of a self-noise configuration (shared with the GPU tests)."""
+    H, W, D = n["H"], n["W"], n["D"]
+    cam = (camera.kitti_intrinsics if n.get("intr") == "kitti" else camera.scannet_intrinsics)(W // 4, H // 4)
+    d_candi = np.linspace(n["d_min"], n["d_max"], D)
+    weights = synth.trained_like_state_dict if n.get("family") == "trained" else synth.seeded_state_dict
+    return cam, d_candi, weights
+
+
+def gen_selfnoise(ref, tag="S"):
+    """VERDICT r4 item 1(a) / r5 item 1(a, c): how far the UNMODIFIED reference is from ITSELF on two-frame windows when only the
     execution changes — oneDNN convolutions on / off, all host threads / one thread.  Every volume of both frames: max|d|,
     mean|d|, arg-max flips (and how many are beyond a 1e-3 tie).  This is the evidence behind the parity gates of
     tests/test_gpu_parity_configs.py: "within 1e-4 (max)" of BASELINE.json is below what two executions of the reference
-    itself agree to, so the gates are L1 < 1e-4 + a hard max|d| bound taken from THIS file (ENVELOPE below).
-    The base execution's refined outputs (R-Net on D = 64 candidates: the hand-written kernels' instantiation) are stored as a
-    reference golden for the GPU test (every `sub`-th pixel + full-resolution arg-max + sums over all pixels)."""
-    n = SELFNOISE_S
+    itself agree to, so the gates are L1 < 1e-4 + a hard max|d| bound + a tie-flip bound, all taken from THESE files
+    (tests/conftest.py).  tag: "S" (config S, initialiser-like weights), "K" (config K: KITTI grid and 1-60 m candidates — the
+    volumes with the most near-ties), "ST" (config S with the trained-like weight family).
+    The base execution's outputs incl. the refined ones (R-Net on D = 64 candidates: the hand-written kernels' instantiation) are
+    stored as a reference golden for the GPU test (sub-sampled + full-resolution arg-max + sums over all pixels)."""
+    n = SELFNOISE[tag]
     H, W, D, sub = n["H"], n["W"], n["D"], n["sub"]
-    cam = camera.scannet_intrinsics(W // 4, H // 4)
-    d_candi = np.linspace(n["d_min"], n["d_max"], D)
+    sub_q = n.get("sub_q", 2)
+    cam, d_candi, weights = selfnoise_setup(n)
     with ref_shim.quiet():
         model = ref.KVNET.KVNET(64, cam, d_candi, n["sigma"], 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
-    sd = synth.seeded_state_dict(model, n["weight_seed"])
+    sd = weights(model, n["weight_seed"])
     windows = [synth.noise_window(s, H, W) for s in n["seeds"]]
     nthr = torch.get_num_threads()
 
@@ -479,21 +499,22 @@ def gen_selfnoise(ref):
             d = np.abs(a.astype(np.float64) - b)
             fl, beyond = _tie_flips(a, b)
             out["%s_%s_f%d" % (name, k, f + 1)] = np.array([d.max(), d.mean(), fl, beyond, a[0].size])
-            print("selfnoise S: %-10s %-11s f%d  max %.3e mean %.3e  arg-max flips %d (beyond a tie %d) of %d" %
-                  (name, k, f + 1, d.max(), d.mean(), fl, beyond, a[0].size))
+            print("selfnoise %s: %-10s %-11s f%d  max %.3e mean %.3e  arg-max flips %d (beyond a tie %d) of %d" %
+                  (tag, name, k, f + 1, d.max(), d.mean(), fl, beyond, a[0].size))
     for f, k in keys:
         b = base[f][k]
         full = k.startswith("refined")
-        st = sub if full else 2
+        st = sub if full else sub_q
         out["base_%s_f%d_sub" % (k, f + 1)] = b[:, ::st, ::st] if (full or f == 1 or k == "bv_cur") else np.zeros(0, np.float32)
         out["base_%s_f%d_argmax" % (k, f + 1)] = b.argmax(0).astype(np.uint8)
         out["base_%s_f%d_sum" % (k, f + 1)] = b.astype(np.float64).sum()
         top2 = np.sort(b, 0)[-2:]
         out["base_%s_f%d_ties" % (k, f + 1)] = int(((top2[1] - top2[0]) < 1e-3).sum())     # pixels whose two best candidates are within 1e-3
+        out["base_%s_f%d_min" % (k, f + 1)] = float(b.min())
+        print("selfnoise %s: base %-11s f%d  ties within 1e-3: %d of %d, min %.1f" % (tag, k, f + 1, out["base_%s_f%d_ties" % (k, f + 1)], b[0].size, b.min()))
     out["inputs_checksum"] = checksum([w[0] for w in windows] + [w[1] for w in windows] + [w[2] for w in windows])
     out["weights_checksum"] = checksum(sd.values())
-    np.savez_compressed(os.path.join(OUT, "ref_selfnoise_S.npz"), **out)
-
+    np.savez_compressed(os.path.join(OUT, "ref_selfnoise_%s.npz" % tag), **out)
 
 
 def gen_pose_inv(ref):
@@ -518,7 +539,8 @@ def main():
     which = sys.argv[1:] or ["ops", "net", "scene", "ops67", "fp64", "fp64S", "lba", "export", "train", "pose_inv"]
     for name in which:
         {"ops": gen_ops, "net": gen_net, "scene": gen_scene, "ops67": gen_ops67, "fp64": gen_fp64, "fp64S": gen_fp64_S, "lba": gen_lba, "export": gen_export, "train": gen_train, "pose_inv": gen_pose_inv,
-         "scene_stream": gen_scene_stream, "fp64B": gen_fp64_B, "selfnoise": gen_selfnoise}[name](ref)
+         "scene_stream": gen_scene_stream, "fp64B": gen_fp64_B, "selfnoise": gen_selfnoise,
+         "selfnoiseK": lambda r: gen_selfnoise(r, "K"), "selfnoiseST": lambda r: gen_selfnoise(r, "ST")}[name](ref)
 
 
 if __name__ == "__main__":

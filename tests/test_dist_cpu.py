@@ -313,3 +313,68 @@ def test_gradient_accumulation_single_rank_divides_without_a_collective():
     assert torch.allclose(model.weight.grad[0], want, rtol=1e-6, atol=1e-6)
     with __import__("pytest").raises(ValueError):
         reducer.prepare(accum_steps=0)
+
+
+def _alternating_worker(rank, world, port, q):
+    """the real 459-key parameter set, default buckets, accumulate-4, TWO consecutive optimizer steps; in step 0
+    rank 0's first window skips the K-Net (train() takes the first-frame branch when `valid_dpv(BVs_predict)` fails on that rank),
+    in step 1 it is rank 1's third window that does.  Launch order, bucket contents and the replicas must agree after each step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    nd.init_from_env("gloo")
+    import neuralrgbd_amd
+    from neuralrgbd_amd import camera
+    cam = camera.scannet_intrinsics(24, 16)
+    d = np.linspace(.1, 5, 64)
+    model = neuralrgbd_amd.KVNET(64, cam, d, 10., 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    torch.manual_seed(0)
+    for p in model.parameters():
+        p.data.normal_(0, 0.1)
+    reducer = nd.GradAllReduce(model)
+    knet = {id(p) for p in model.kv_net.parameters()}
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    A = 4
+    skip = {(0, 0, 0), (1, 1, 2)}                          # (step, rank, window) whose loss does not touch the K-Net
+    orders, hooks, sums = [], [], []
+    for step in range(2):
+        reducer.prepare(accum_steps=A)
+        for k in range(A):
+            used = [p for p in reducer.params if not ((step, rank, k) in skip and id(p) in knet)]
+            sum((p * float(rank + 1 + k)).sum() for p in used).backward()
+        reducer()
+        opt.step()
+        orders.append([b for b, _ in reducer.launch_order])
+        hooks.append(reducer.launched_in_backward)
+        sums.append([float(reducer.flat[bi].double().sum()) for bi in range(len(reducer.buckets))])
+    n_knet = sum(p.numel() for p in reducer.params if id(p) in knet)
+    q.put((rank, {"orders": orders, "hooks": hooks, "sums": sums, "n_buckets": len(reducer.buckets), "numel": reducer.numel,
+                  "n_knet": n_knet, "w": float(sum(p.detach().double().sum() for p in reducer.params))}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_accumulate_4_over_two_steps_with_ranks_alternately_skipping_the_knet():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_alternating_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    n = a["n_buckets"]
+    assert n >= 3
+    for step in range(2):
+        assert a["orders"][step] == b["orders"][step] == list(range(n))         # same collectives, same order, on both ranks
+        assert a["sums"][step] == b["sums"][step]                                # ... and the same reduced messages
+    # the skipping rank cannot complete the K-Net's buckets from hooks (one of its 4 x len(bucket) gradients never lands): it
+    # launches fewer buckets during backward than its peer — in step 0 that is rank 0, in step 1 rank 1
+    assert a["hooks"][0] < b["hooks"][0] and b["hooks"][1] < a["hooks"][1]
+    # d loss / d p = sum over ranks r and windows k of (r + 1 + k) / (4 * 2): all 8 terms = (1+2+3+4 + 2+3+4+5) / 8 = 3.0 outside
+    # the K-Net; inside it step 0 misses rank 0's window 0 (value 1) -> 23 / 8, step 1 misses rank 1's window 2 (value 4) -> 20 / 8
+    out_k = a["numel"] - a["n_knet"]
+    assert abs(sum(a["sums"][0]) - (3.0 * out_k + 23.0 / 8.0 * a["n_knet"])) < 1e-3 * a["numel"]
+    assert abs(sum(a["sums"][1]) - (3.0 * out_k + 20.0 / 8.0 * a["n_knet"])) < 1e-3 * a["numel"]
+    assert a["w"] == b["w"]                                                      # replicas identical after two optimizer steps

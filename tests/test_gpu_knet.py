@@ -363,3 +363,76 @@ def test_wino_dw_clamped_fma_relu_has_the_bits_of_the_plain_form():
     gamma, beta = torch.tensor([1.5, -0.3, 2.0, 0.1]), torch.tensor([0.2, -4.0, 0.0, 3.0])
     z = torch.nn.functional.batch_norm(yv, None, None, gamma, beta, training=True, eps=1e-5)
     assert z.abs().max().item() < 1.0 / ops.relu_unit(gamma, beta, n)
+
+
+def test_variance_collapse_is_loud_not_saturated():
+    """the finalisers take the variance as E[y^2] - mean^2 from fp32 per-tile partials; a channel with
+    std / |mean| below ~3e-3 has no correct digit left, and the clamped-FMA ReLU of the next K-Net layer (ops.relu_unit assumes a
+    computed variance >= true / 4) could saturate silently.  Such a channel must get a NaN scale (csrc/common.hpp
+    bn_finalize_channel) so that everything it feeds is NaN: (1) crafted partials through all three finalisers, (2) real
+    statistics of a collapsing map through nhwc_stats -> bn_finalize, (3) the clamped kernel turns the NaN scale into NaN outputs
+    (never a clamped finite value), (4) a healthy channel with |mean| / std = 100 stays finite and accurate."""
+    from neuralrgbd_amd import ops
+    C, rows, count = 64, 48, 48 * 256
+    g = torch.Generator().manual_seed(5)
+    mean = torch.full((C,), 50.0)
+    std = torch.ones(C)
+    std[3], std[17] = 0.05, 1e-4                      # std / |mean| = 1e-3 and 2e-6: collapsed
+    mean[40], std[40] = 0.0, 0.0                      # a dead channel (all zero): NOT an error, scale finite
+    s1 = (mean * count / rows)[:, None].expand(C, rows)
+    s2 = ((std ** 2 + mean ** 2) * count / rows)[:, None].expand(C, rows)
+    cm = torch.cat((s1, s2), 0).contiguous().to(DEV)                      # column-major partials [2C, rows]
+    rm = torch.cat((s1.t(), s2.t()), 1).contiguous().to(DEV)              # row-major partials [rows, 2C]
+    gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    word = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for i, fin in enumerate((lambda: ops.bn_finalize_cm(cm, count, gamma, beta, 1e-5, 0.1, status=word),
+                             lambda: ops.bn_finalize(rm, count, gamma, beta, 1e-5, 0.1, status=word),
+                             lambda: ops.bn3d_finalize(rm, count, gamma, beta, 1e-5, 0.1, status=word))):
+        ss = fin()
+        bad = torch.isnan(ss[:, 0]).cpu()
+        assert bad[3] and bad[17] and int(bad.sum()) == 2, bad.nonzero().flatten().tolist()
+        assert torch.isfinite(ss[40]).all()
+        assert int(word.item()) == 2 * (i + 1)                            # counted into the caller's status word
+    # (2) measured statistics: x = 1000 + 1e-3 N(0,1) in channel 5, N(0,1) + 100 in channel 6 (healthy, |mean|/std = 100)
+    x = torch.randn(8, 24, 48, C, generator=g)
+    x[..., 5] = 1000.0 + 1e-3 * x[..., 5]
+    x[..., 6] = 100.0 + x[..., 6]
+    x = x.to(DEV)
+    ss = ops.bn_finalize(ops.nhwc_stats(x), x.numel() // C, gamma, beta, 1e-5, 0.1)
+    assert torch.isnan(ss[5, 0]) and int(torch.isnan(ss[:, 0]).sum()) == 1
+    want6 = 1.0 / x[..., 6].double().std(unbiased=False).item()
+    assert abs(ss[6, 0].item() - want6) < 2e-3 * want6                    # E[y^2] - mean^2 at |mean| / std = 100: 3 digits, finite
+    # (3) the clamped kernel: NaN scale -> NaN output, not a saturated finite one
+    w = (torch.randn(C, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    unit = ops.relu_unit(gamma, beta, x.numel() // C)
+    y, _, _ = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w / unit), C, x_ss=ss, x_relu=True, x_unit=unit)
+    assert torch.isnan(y).all()
+    ss_ok = ss.clone(); ss_ok[5] = 0.0
+    y_ok, _, _ = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w / unit), C, x_ss=ss_ok, x_relu=True, x_unit=unit)
+    y_ref, _, _ = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w), C, x_ss=ss_ok, x_relu=True)
+    assert torch.isfinite(y_ok).all() and torch.equal(y_ok, y_ref)
+    # (5) the host mirror is LOUD: the status word raises at the path's own synchronisation points
+    import neuralrgbd_amd
+    from neuralrgbd_amd import camera, misc, nets, synth
+    from neuralrgbd_amd._lib import NrgbdError
+    from neuralrgbd_amd.streaming import DepthStream
+    dev = torch.device(DEV)
+    nets.check_status(dev)                                                # clean
+    nets.status_word(dev).fill_(3)
+    with pytest.raises(NrgbdError, match="collapsed in 3 channel"):
+        misc.valid_dpv(torch.zeros(1, 4, 2, 2, device=DEV))              # KVNET.forward's probe of BV_predict
+    assert int(nets.status_word(dev).item()) == 0                         # cleared by the raise
+    H, W, D = 256, 256, 16
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(0.1, 5.0, D)
+    model = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+    model.load_state_dict(synth.seeded_state_dict(model, 0))
+    st = DepthStream(model.to(DEV), cam, d_candi, use_graph=False)
+    r, s_, p_ = (t.to(DEV) for t in synth.noise_window(5, H, W))
+    st.step(r, s_, p_); st.step(r, s_, p_)
+    st.check()                                                            # healthy frames report nothing
+    nets.status_word(dev).fill_(1)                                        # what a finaliser of the next frame would have done
+    st.step(r, s_, p_)                                                    # queues the 4-byte copy behind the frame
+    torch.cuda.synchronize()
+    with pytest.raises(NrgbdError):
+        st.step(r, s_, p_)                                                # ... and the following step sees it

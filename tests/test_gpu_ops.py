@@ -372,6 +372,44 @@ def test_costvol_quad_vs_oracle(h, w, D, V, C, dist, rot, trans, seed, gen="quad
         assert np.abs(c2 - cost).max() < 1e-5 * max(10.0, float(np.abs(want).max()))
 
 
+@pytest.mark.parametrize("kind", ["unit_norm", "barrel", "wavy"])
+def test_costvol_quad_non_affine_ray_tables_vs_oracle(kind):
+    """the C ABI takes ANY ray table, the staged patches of generation 3 are predicted from the images of a tile's four
+    corner pixels — exact only for the pinhole table (rays affine in (x, y), z = 1).  With unit-norm rays, a barrel-distorted table
+    and a deliberately wavy one (a tile's interior bulges several texels out of its corners' hull) the kernel must still equal
+    the C oracle: a group whose tap leaves the predicted box is re-evaluated from global memory (costvol_quad.hip `escaped`)."""
+    h, w, D, V, C = 96, 128, 64, 3, 67
+    cam = camera.scannet_intrinsics(w, h)
+    rng = np.random.RandomState(77)
+    feat_ref = rng.standard_normal((C, h, w)).astype(np.float32)
+    feat_src = rng.standard_normal((V, C, h, w)).astype(np.float32)
+    poses = synth.random_poses(rng, V)
+    KR, Kt = co.homography_terms(cam["intrinsic_M_cuda"].numpy(), poses[:, :3, :3], poses[:, :3, 3])
+    d_candi = np.linspace(0.1, 5, D)
+    rays = cam["unit_ray_array_2D"].numpy().astype(np.float64).reshape(3, h, w)
+    if kind == "unit_norm":
+        rays = rays / np.linalg.norm(rays, axis=0, keepdims=True)
+    elif kind == "barrel":
+        r2 = rays[0] ** 2 + rays[1] ** 2
+        rays = np.stack([rays[0] * (1 + 0.25 * r2), rays[1] * (1 + 0.25 * r2), rays[2]])
+    else:   # a 6-pixel-period ripple of ~2.5 texels amplitude: interior pixels of an 8x8 tile leave the corners' hull by whole texels
+        ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        step = rays[0, 0, 1] - rays[0, 0, 0]
+        rays = np.stack([rays[0] + 2.5 * step * np.sin(xs * 1.1 + ys * 0.7), rays[1] + 2.5 * step * np.cos(xs * 0.9 - ys * 1.3), rays[2]])
+    rays = rays.reshape(3, h * w).astype(np.float32)
+    cx, cy = cam["intrinsic_M"][0, 2], cam["intrinsic_M"][1, 2]
+    co.set_threads(32)
+    want = co.costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0)
+    got, lp = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, logp=True, generation="quad")
+    auto, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0)
+    gather, _ = _gpu_costvol(feat_ref, feat_src, KR, Kt, rays, d_candi, cx, cy, 10.0, generation="gather")
+    mx, _, _ = report("quad costvol, %s rays" % kind, -got, -want)
+    assert np.isfinite(got).all() and mx < 1e-5 * max(10.0, float(np.abs(want).max()))
+    assert np.array_equal(auto, got)
+    assert np.abs(gather - got).max() < 1e-5 * max(10.0, float(np.abs(want).max()))
+    assert near_tie_mismatches(lp, co.logsoftmax_d(want, scale=-1.0), tol=1e-4) == 0
+
+
 def test_costvol_quad_align_corners_and_determinism():
     h, w, D, V, C = 40, 72, 24, 4, 67
     cam = camera.scannet_intrinsics(w, h)

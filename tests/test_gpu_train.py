@@ -666,6 +666,34 @@ def test_fused_adam_vs_torch_adam_and_under_a_hipgraph():
         assert int(oa.state[a]["step"].item()) == int(ob.state[b]["step"].item())
 
 
+def test_fused_adam_steps_after_loading_a_reference_era_checkpoint():
+    """a torch < 1.12 Adam checkpoint (what train_KVNet.py:347 saved: int `step`, param_groups without
+    `maximize` / `foreach` / ...) loads into FusedAdam AND steps; the update equals torch.optim.Adam's after the same load."""
+    from neuralrgbd_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 16, 3, 3), (33,), (1,), (4097,)]
+    pa = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    old = {"state": {i: {"step": 7, "exp_avg": 0.1 * torch.randn(*s, generator=g), "exp_avg_sq": 0.01 * torch.rand(*s, generator=g)}
+                     for i, s in enumerate(shapes)},
+           "param_groups": [{"lr": 1e-3, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                             "params": list(range(len(shapes)))}]}
+    import copy
+    oa = FusedAdam(pa, lr=1e-5)
+    ob = torch.optim.Adam(pb, lr=1e-5)
+    oa.load_state_dict(copy.deepcopy(old))
+    ob.load_state_dict(copy.deepcopy(old))
+    for it in range(3):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(*a.shape, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), (i, shapes[i])
+        assert int(oa.state[a]["step"].item()) == 10
+        assert oa.state[a]["step"].is_cuda and oa.state[a]["step"].dtype == torch.float32
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_inference_after_a_fused_adam_step_uses_the_updated_weights(graph):
     """FusedAdam writes the parameters through raw pointers; the inference caches of nets.py (packed weight

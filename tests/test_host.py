@@ -360,3 +360,31 @@ def test_rnet_candidate_padding_embedding_is_exact():
         assert got.shape == want.shape
         assert (got - want).abs().max().item() < 1e-9, D
     assert nets.DPVUpsampleNet(64, 32, 3, D=200)._widths() is None and nets.DPVUpsampleNet(64, 32, 3, D=16, upsample_D=True)._widths() is None
+
+
+def test_fused_adam_loads_a_reference_era_checkpoint():
+    """the reference saves `optimizer.state_dict()` of a torch < 1.12 Adam (train_KVNet.py:347): every
+    param_group holds only lr / betas / eps / weight_decay / amsgrad and `step` is a Python int.  torch's load REPLACES the groups,
+    so the keys this optimizer's step() reads (`maximize`) must be filled from the defaults; an AMSGrad checkpoint is refused before
+    any state is replaced.  (Host logic only: step() itself needs the GPU — tests/test_gpu_train.py steps after such a load.)"""
+    from neuralrgbd_amd._lib import NrgbdError
+    from neuralrgbd_amd.optim import FusedAdam
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    opt = FusedAdam(ps, lr=1e-3)
+    old = {"state": {0: {"step": 11, "exp_avg": torch.full((5, 3), 0.5), "exp_avg_sq": torch.full((5, 3), 0.25)},
+                     1: {"step": 11, "exp_avg": torch.zeros(7), "exp_avg_sq": torch.ones(7)}},
+           "param_groups": [{"lr": 1e-5, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "params": [0, 1]}]}
+    opt.load_state_dict(old)
+    g = opt.param_groups[0]
+    assert g["lr"] == 1e-5 and g["maximize"] is False and set(opt.defaults) <= set(g)
+    assert opt.state[ps[0]]["step"] == 11 and float(opt.state[ps[0]]["exp_avg"][0, 0]) == 0.5
+    import copy
+    import pickle
+    o2 = pickle.loads(pickle.dumps(opt))                     # __setstate__ fills the same defaults
+    assert o2.param_groups[0]["maximize"] is False
+    ams = copy.deepcopy(old)
+    ams["param_groups"][0]["amsgrad"] = True
+    fresh = FusedAdam(ps, lr=1e-3)
+    with pytest.raises(NrgbdError):
+        fresh.load_state_dict(ams)
+    assert fresh.param_groups[0]["lr"] == 1e-3 and not fresh.state      # refused before anything was replaced
