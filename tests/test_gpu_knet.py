@@ -370,8 +370,9 @@ def test_variance_collapse_is_loud_not_saturated():
     std / |mean| below ~3e-3 has no correct digit left, and the clamped-FMA ReLU of the next K-Net layer (ops.relu_unit assumes a
     computed variance >= true / 4) could saturate silently.  Such a channel must get a NaN scale (csrc/common.hpp
     bn_finalize_channel) so that everything it feeds is NaN: (1) crafted partials through all three finalisers, (2) real
-    statistics of a collapsing map through nhwc_stats -> bn_finalize, (3) the clamped kernel turns the NaN scale into NaN outputs
-    (never a clamped finite value), (4) a healthy channel with |mean| / std = 100 stays finite and accurate."""
+    statistics of a collapsing map through nhwc_stats -> bn_finalize (a healthy channel with |mean| / std = 100 stays finite and
+    accurate), (3) the kernels' ReLU forms turn a NaN scale into a switched-off channel — the NaN alone would vanish —, which is
+    why (5) the finalisers also count the collapse into a status word that raises NrgbdError at the path's synchronisation points."""
     from neuralrgbd_amd import ops
     C, rows, count = 64, 48, 48 * 256
     g = torch.Generator().manual_seed(5)
@@ -402,15 +403,18 @@ def test_variance_collapse_is_loud_not_saturated():
     assert torch.isnan(ss[5, 0]) and int(torch.isnan(ss[:, 0]).sum()) == 1
     want6 = 1.0 / x[..., 6].double().std(unbiased=False).item()
     assert abs(ss[6, 0].item() - want6) < 2e-3 * want6                    # E[y^2] - mean^2 at |mean| / std = 100: 3 digits, finite
-    # (3) the clamped kernel: NaN scale -> NaN output, not a saturated finite one
+    # (3) WHY the status word exists: the kernels' ReLU maps NaN to 0 (v_max_f32 returns its non-NaN operand; the FMA clamp of the
+    # clamped form maps NaN to 0 under the kernels' DX10_CLAMP mode), so the NaN scale of a collapsed channel silently becomes
+    # "channel switched off" in the next convolution — finite, plausible, wrong.  Both forms of the K-Net layer show it:
     w = (torch.randn(C, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
     unit = ops.relu_unit(gamma, beta, x.numel() // C)
-    y, _, _ = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w / unit), C, x_ss=ss, x_relu=True, x_unit=unit)
-    assert torch.isnan(y).all()
-    ss_ok = ss.clone(); ss_ok[5] = 0.0
-    y_ok, _, _ = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w / unit), C, x_ss=ss_ok, x_relu=True, x_unit=unit)
-    y_ref, _, _ = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w), C, x_ss=ss_ok, x_relu=True)
-    assert torch.isfinite(y_ok).all() and torch.equal(y_ok, y_ref)
+    ss_off = ss.clone(); ss_off[5] = 0.0
+    for kw, wp in ((dict(x_unit=unit), ops.conv_wino_dw_pack(w / unit)), (dict(), ops.conv_wino_dw_pack(w))):
+        y, _, _ = ops.conv_wino_dw(x, wp, C, x_ss=ss, x_relu=True, **kw)
+        y_off, _, _ = ops.conv_wino_dw(x, wp, C, x_ss=ss_off, x_relu=True, **kw)
+        assert torch.isfinite(y).all() and torch.equal(y, y_off)
+    # (4) a non-ReLU consumer (every residual block's second BatchNorm) does propagate it
+    assert torch.isnan(ops.nhwc_act(x, ss, False)[..., 5]).all()
     # (5) the host mirror is LOUD: the status word raises at the path's own synchronisation points
     import neuralrgbd_amd
     from neuralrgbd_amd import camera, misc, nets, synth

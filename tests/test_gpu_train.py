@@ -415,11 +415,13 @@ def test_batchnorm_statistics_survive_a_large_mean():
 
 def test_batch_norm_module_glue_vs_torch_batch_norm():
     """autograd.batch_norm_act_cl on nn.BatchNorm3d / nn.BatchNorm2d modules (csrc/bn_train.hip) against torch's batch_norm +
-    relu + add on a twin module: output, gradients, running statistics and batch counter; widths bn_train.hip has no form for
-    (C = 48: its 12 channel quads do not tile a 256-lane workgroup) and eval-mode norms take torch's path by themselves."""
+    relu + add on a twin module: output, gradients, running statistics and batch counter.  A width bn_train.hip has no form for
+    (C = 48: its 12 channel quads do not tile a 256-lane workgroup) RAISES on the GPU — never F.batch_norm / MIOpen (ADVICE r5);
+    an eval-mode norm is the affine map of its running statistics, differentiable, equal to the module."""
     from neuralrgbd_amd import ops
+    from neuralrgbd_amd._lib import NrgbdError
     from neuralrgbd_amd.autograd import batch_norm_act_cl
-    for C, track in ((64, True), (32, False), (48, True)):
+    for C, track in ((64, True), (32, False)):
         res = {}
         for mode in ("path", "torch"):
             bn = torch.nn.BatchNorm3d(C, track_running_stats=track).to(DEV)
@@ -434,17 +436,29 @@ def test_batch_norm_module_glue_vs_torch_batch_norm():
             (y * torch.arange(y.numel(), device=DEV).reshape(y.shape).remainder(7).float()).sum().backward()
             res[mode] = (y.detach(), x.grad, r.grad, bn.weight.grad, bn.bias.grad,
                          bn.running_mean.clone() if track else None, int(bn.num_batches_tracked) if track else None)
-        assert ops.bn_cl_supported(6 * 5 * 7, C) == (C != 48)
+        assert ops.bn_cl_supported(6 * 5 * 7, C)
         for a, b in zip(res["path"][:5], res["torch"][:5]):
             assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
         if track:
             assert (res["path"][5] - res["torch"][5]).abs().max().item() < 1e-6 and res["path"][6] == res["torch"][6] == 1
+    assert not ops.bn_cl_supported(6 * 5 * 7, 48)
+    with pytest.raises(NrgbdError):                                  # no kernel for this width: an error, not a vendor call
+        batch_norm_act_cl(torch.randn(6, 5, 7, 48, device=DEV), torch.nn.BatchNorm3d(48).to(DEV), True)
     with pytest.raises(ValueError):                                  # torch's own error for a single value per channel in training
         batch_norm_act_cl(torch.randn(1, 1, 1, 32, device=DEV), torch.nn.BatchNorm3d(32).to(DEV), False)
-    bn = torch.nn.BatchNorm2d(32).to(DEV).eval()                     # running statistics in use: torch's own path
-    x = torch.randn(2, 5, 6, 32, device=DEV, requires_grad=True)
-    y = batch_norm_act_cl(x, bn, False)
-    assert torch.allclose(y, bn(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1), atol=1e-6) and int(bn.num_batches_tracked) == 0
+    # running statistics in use (eval()): the affine map, any width, with gradients
+    for C in (32, 48):
+        bn = torch.nn.BatchNorm2d(C).to(DEV)
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.5); bn.running_var.uniform_(0.3, 3.0); bn.weight.uniform_(0.2, 2.5); bn.bias.normal_(0, 0.5)
+        bn.eval()
+        x = torch.randn(2, 5, 6, C, device=DEV, requires_grad=True)
+        x2 = x.detach().clone().requires_grad_(True)
+        y = batch_norm_act_cl(x, bn, True)
+        want = torch.relu(bn(x2.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+        assert torch.allclose(y, want, atol=2e-6, rtol=1e-6) and int(bn.num_batches_tracked) == 0
+        y.sum().backward(); want.sum().backward()
+        assert torch.allclose(x.grad, x2.grad, atol=1e-6, rtol=1e-6)
 
 
 def _accum_setup(seed, lr=1e-4, capturable=False):
