@@ -46,8 +46,9 @@ extern "C" {
  * The interface version changes whenever an entry point changes its signature or disappears: bind against the version you
  * were built for.  0.4 (round 4): nrgbd_costvol_bwd takes (workspace, workspace_bytes) before `stream` (since round 3: query
  * nrgbd_costvol_bwd_workspace first); nrgbd_conv3d_wino_* and nrgbd_conv_wino_dw_bn_f32 are gone; nrgbd_upsample_bilinear_ac
- * is new. */
-#define NRGBD_INTERFACE_VERSION "0.4"
+ * is new.  0.5 (round 6): the three BatchNorm finalisers take (collapse_count, batches_tracked) before `stream`; nrgbd_pack_nhwc takes
+ * rgb4, nrgbd_conv2d_taps_f32 takes in_stride; nrgbd_avgpool_cl and nrgbd_scatter_channels are new. */
+#define NRGBD_INTERFACE_VERSION "0.5"
 const char* nrgbd_version(void);
 const char* nrgbd_strerror(int code);
 
@@ -87,10 +88,12 @@ int nrgbd_pose_inverse(const float* T, long matrix_stride, float* T_inv, int* si
  *   rgb  [N][3][h*pool][w*pool]   full-resolution frames, or NULL (then only a transpose)
  *   out  [N][h][w][Cp]            out[..,c] = feat[c] (c<Cf); mean of the pool x pool RGB
  *                                 window (c = Cf..Cf+2, rgb != NULL); 0 for padding
+ *   rgb4 [N][h][w][4] or NULL     channels Cf .. Cf+3 of every texel once more as a compact plane (what models/KVNET.py:147-158
+ *                                 warps for the K-Net: `F.avg_pool2d(img, 4)`); needs Cp >= Cf + 4
  * Requires Cp % 4 == 0 and Cp >= Cf (+3 if rgb).
  */
 int nrgbd_pack_nhwc(const float* feat, const float* rgb, float* out,
-                    int N, int Cf, int h, int w, int pool, int Cp, int feat_channels_last, void* stream);
+                    int N, int Cf, int h, int w, int pool, int Cp, int feat_channels_last, float* rgb4, void* stream);
 
 /*
  * nrgbd_costvol_fwd — fused homography warp + bilinear sample + cost accumulate
@@ -328,7 +331,7 @@ int nrgbd_conv3d_wgrad_f32(const float* x, const float* gy, float* partial, floa
                            int D, int H, int W, int Cin, void* stream);
 int nrgbd_bn3d_finalize(const float* stats, int num_workgroups, long count,
                         const float* gamma, const float* beta, float eps, float momentum,
-                        float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count, void* stream);
+                        float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count, long long* batches_tracked, void* stream);
 
 /*
  * 2-D feature CNN helpers (NCHW, HW % 4 == 0, 16-B aligned planes).
@@ -347,6 +350,17 @@ int nrgbd_bn2d_train_act(const float* x, const float* gamma, const float* beta, 
                          const float* residual, float* y, float* partial, float* mean_var,
                          int N, int C, long HW, void* stream);
 int nrgbd_avgpool8(const float* x, float* y, int NC, int H, int W, void* stream);
+/*
+ * nrgbd_avgpool_cl — k x k / stride-k average pooling of a CHANNELS-LAST map: x [N][H][W][C] -> y [N][H/k][W/k][C] (floor: a ragged
+ * border is dropped, as F.avg_pool2d does).  Replaces: the four nn.AvgPool2d of models/psm_submodule.py:100-117 on the inference
+ * path (window 8 on the deep map, then 2 / 4 / 8 on its result: equal windows, the mean of means is the mean).  C % 4 == 0.
+ * nrgbd_scatter_channels — dst[r][pixel][coff + c] = src[c * stride_c + y * stride_y + x * stride_x] for r < n_rep images of pixel
+ * stride ldy, `rep_stride` floats apart: the image features models/Refine.py:88-98 concatenates behind the candidate channels
+ * (`torch.cat((dpv, feat), dim=1)`), written straight into the R-Net's channels-last concat buffers for every sample of the batch.
+ */
+int nrgbd_avgpool_cl(const float* x, float* y, int N, int H, int W, int C, int k, void* stream);
+int nrgbd_scatter_channels(const float* src, long stride_c, long stride_y, long stride_x, int C, int H, int W, float* dst,
+                           int ldy, int coff, int n_rep, long rep_stride, void* stream);
 /*
  * nrgbd_bias_act_nchw — x = leaky_relu(x + bias[c], slope) in place on [N][C][HW] (HW % 4 == 0): the bias + LeakyReLU
  * tail of the R-Net's conv2d_leakyRelu / conv2dTranspose_leakyRelu blocks (models/m_submodule.py:18-27,36-45) in one
@@ -392,7 +406,7 @@ int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, const float
 int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int Cout, int kd, int transposed, void* stream);
 int nrgbd_bn_finalize_cm(const float* stats, int rows, int C, long count, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count,
-                         void* stream);
+                         long long* batches_tracked, void* stream);
 int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu, const float* res, const float* res_ss,
                         int res_relu, float* materialized, const float* w_wino, float* y, float* stats,
                         int N, int H, int W, int Cin, int Cout, int kd, int dilation, void* stream);
@@ -468,6 +482,7 @@ int nrgbd_rnet_pack(const float* dpv_log, const float* feat, int feat_planar, fl
  *   variance is below 1e-5 mean^2 (std / |mean| < 3.2e-3: no correct digit left; the reference's two-pass statistics would still
  *   normalise it) gets scale = shift = NaN AND is counted into *collapse_count (device word, may be NULL; atomicAdd of 1 per
  *   channel) — the kernels' ReLU maps NaN to 0, so the NaN alone could vanish again; the host mirror raises on a non-zero word.
+ *   batches_tracked (device int64, may be NULL): nn.BatchNorm's `num_batches_tracked += 1` side effect, done by the finaliser.
  * nrgbd_nhwc_stats: the same partials for a channels-last tensor produced elsewhere (the stride-2 / 1x1 layers that
  *   stay on the vendor library): x [P][C], stats [nrgbd_nhwc_stats_workgroups(P)][2*C]; C in {32, 64, 128}.
  * nrgbd_nhwc_act: y[p*ldy + c] = act(x*s+t) [+ act(res*s'+t')] — the loader's prologue as a stand-alone pass, for
@@ -477,7 +492,8 @@ int nrgbd_rnet_pack(const float* dpv_log, const float* feat, int feat_planar, fl
  * nrgbd_conv2d_taps_f32 — the trunk's remaining convolution forms on the same kernel (round 2: no vendor convolution is left in
  * the feature CNN), with the prologue (x_ss, x_relu) and the statistics epilogue of nrgbd_conv2d_3x3_f32:
  *   taps = 1: 1x1 convolution (psm_submodule.py:40-43,63-66 shortcut of layer2 / layer3, :103-117 SPP branch convs, :122 head);
- *             w_packed = nrgbd_conv_pack_weights(w [Cout][Cin][1], taps = 1); Cout in {32, 64, 128}
+ *             w_packed = nrgbd_conv_pack_weights(w [Cout][Cin][1], taps = 1); Cout in {32, 64, 128}; in_stride = s > 1: the
+ *             convolution's own stride — x is [N][H*s][W*s][Cin], output pixel (y, x) reads input pixel (y*s, x*s) (no gather pass)
  *   taps = 4: the 2x2 window {y-1, y} x {x-1, x} — a stride-2, pad-1 3x3 convolution (psm_submodule.py:90 firstconv, :120
  *             layer2's first conv) on the space-to-depth image of its input (nrgbd_space_to_depth2), weights re-indexed by the
  *             host mirror (neuralrgbd_amd/ops.py::conv_s2_pack); Cout in {32, 64}
@@ -485,7 +501,7 @@ int nrgbd_rnet_pack(const float* dpv_log, const float* feat, int feat_planar, fl
  *   x is [N][C][H][W] (nchw = 1: the input image) or [N][H][W][C]; H, W even, Cp >= 4C.
  */
 int nrgbd_conv2d_taps_f32(const float* x, const float* x_ss, int x_relu, const float* w_packed, float* y, float* stats,
-                          int N, int H, int W, int Cin, int Cout, int taps, void* stream);
+                          int N, int H, int W, int Cin, int Cout, int taps, int in_stride, void* stream);
 int nrgbd_space_to_depth2(const float* x, int nchw, float* y, int N, int C, int H, int W, int Cp, void* stream);
 /*
  * nrgbd_conv2d_wgrad_f32 — weight gradient of a 3x3 stride-1 convolution (padding = dilation in {1, 2}) on channels-last
@@ -509,7 +525,7 @@ int nrgbd_conv2d_3x3_f32(const float* x, const float* x_ss, int x_relu,
                          void* stream);
 int nrgbd_bn_finalize(const float* stats, int num_workgroups, int C, long count,
                       const float* gamma, const float* beta, float eps, float momentum,
-                      float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count, void* stream);
+                      float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count, long long* batches_tracked, void* stream);
 /*
  * nrgbd_spp_concat — the tail of the feature CNN's spatial-pyramid pooling in one channels-last pass.
  * Replaces: models/psm_submodule.py:149-161 — for the four branches nn.ReLU after convbn (:100-117 branch1..4), F.upsample(

@@ -23,7 +23,7 @@ SIGNATURES = {
     "nrgbd_strerror": (_c.c_char_p, [_I]),
     "nrgbd_homography_terms": (_I, [_P, _P, _L, _L, _P, _L, _L, _P, _P, _I, _P]),
     "nrgbd_pose_inverse": (_I, [_P, _L, _P, _P, _I, _P]),
-    "nrgbd_pack_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_pack_nhwc": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "nrgbd_costvol_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P,
                                _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_costvol_fwd_gen": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _P, _P,
@@ -52,7 +52,7 @@ SIGNATURES = {
     "nrgbd_conv_wino_rnet_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_rnet_ex_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_pack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "nrgbd_bn_finalize_cm": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "nrgbd_bn_finalize_cm": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     "nrgbd_conv_wino_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_dw_pack": (_I, [_P, _P, _I, _I, _I, _P]),
     "nrgbd_conv_wino_dw_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -60,21 +60,23 @@ SIGNATURES = {
     "nrgbd_conv_wino_dw_unit_f32": (_I, [_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv3d_wgrad_workgroups": (_I, []),
     "nrgbd_conv3d_wgrad_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "nrgbd_bn3d_finalize": (_I, [_P, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "nrgbd_bn3d_finalize": (_I, [_P, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     "nrgbd_bn2d_partial_floats": (_I, [_I]),
     "nrgbd_bn2d_train_act": (_I, [_P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _L, _P]),
     "nrgbd_avgpool8": (_I, [_P, _P, _I, _I, _I, _P]),
+    "nrgbd_avgpool_cl": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_scatter_channels": (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _I, _I, _I, _L, _P]),
     "nrgbd_bias_act_nchw": (_I, [_P, _P, _F, _I, _I, _L, _P]),
     "nrgbd_conv2d_workgroups": (_I, [_I, _I, _I]),
     "nrgbd_conv2d_wgrad_workgroups": (_I, [_I, _I, _I, _I, _I]),
     "nrgbd_conv2d_wgrad_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "nrgbd_conv2d_taps_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "nrgbd_conv2d_taps_f32": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_space_to_depth2": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _P]),
     "nrgbd_conv2d_3x3_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv2d_rnet_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_rnet_pack": (_I, [_P, _P, _I, _P, _I, _I, _L, _P]),
-    "nrgbd_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "nrgbd_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     "nrgbd_logsoftmax_rows": (_I, [_P, _P, _L, _I, _P]),
     "nrgbd_logsoftmax_d_bwd": (_I, [_P, _P, _F, _P, _I, _L, _P]),
     "nrgbd_logsoftmax_rows_bwd": (_I, [_P, _P, _P, _L, _I, _P]),

@@ -1,7 +1,7 @@
 // api.hip — library identification and error text of libnrgbd_hip.so.
 #include "common.hpp"
 
-extern "C" const char* nrgbd_version(void) { return "nrgbd_hip 0.4 (gfx950, CDNA4)"; }
+extern "C" const char* nrgbd_version(void) { return "nrgbd_hip 0.5 (gfx950, CDNA4)"; }
 
 extern "C" const char* nrgbd_strerror(int code) {
     switch (code) {

@@ -45,6 +45,8 @@ struct Conv2dArgs {
     int up;               // 1: this launch is sub-pixel phase (pa, pb) of a stride-2 transposed conv: 2x2 taps, output pixel
     int pa, pb;           //    (2y+pa, 2x+pb) of a [N][2H][2W] tensor
     float* planar;        // EPI = 1: log_softmax over the COUT channels, written as [N][COUT][H][W] (the R-Net's last layer)
+    int xs;               // NTAP = 1 only: spatial stride of the input (0 / 1 = none): x is [N][H*xs][W*xs][Cin] and output pixel (y, x)
+                          // reads input pixel (y*xs, x*xs) — the stride-2 1x1 shortcut of psm_submodule.py:127-131 without a gather pass
 };
 
 // NTAP = 9: 3x3 convolution.  NTAP = 4: one sub-pixel phase of ConvTranspose2d(k=4, s=2, p=1) (m_submodule.py:37-45): output
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(256, COUT <= 32 ? 3 : 2) void conv2d_mfma_kernel(co
         const int hy = hv / HS, hx = hv - hy * HS;
         const int gy = y0 + hy - DIL, gx = x0 + hx - DIL;
         const bool ok = hv < HALO && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        pf_off[u] = ok ? (unsigned)((((size_t)n * a.H + gy) * a.W + gx) * Cin + c4 * 4) : (unsigned)(c4 * 4);
+        const int xs = (NTAP == 1 && a.xs > 1) ? a.xs : 1;
+        pf_off[u] = ok ? (unsigned)((((size_t)n * (a.H * xs) + (size_t)gy * xs) * (a.W * xs) + (size_t)gx * xs) * Cin + c4 * 4) : (unsigned)(c4 * 4);
         if (ok) pf_ok |= 1u << u;
         if (ok && hy >= DIL && hy < DIL + kT2 && hx >= DIL && hx < DIL + kT2) pf_own |= 1u << u;
     }
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256) void nhwc_act_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int nwg, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float* __restrict__ ss, unsigned int* __restrict__ collapse_count) {
+                                                          float* __restrict__ running_var, float* __restrict__ ss, unsigned int* __restrict__ collapse_count, long long* __restrict__ batches_tracked) {
     __shared__ double sh[2][256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
@@ -423,6 +426,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         __syncthreads();
     }
     if (tid == 0) bn_finalize_channel(sh[0][0], sh[1][0], count, gamma[c], beta[c], eps, momentum, running_mean, running_var, ss, c, collapse_count);
+    if (tid == 0 && c == 0 && batches_tracked) *batches_tracked += 1;      // nn.BatchNorm's num_batches_tracked side effect (one launch less per layer)
 }
 
 template <int COUT, int DIL>
@@ -546,14 +550,15 @@ extern "C" int nrgbd_space_to_depth2(const float* x, int nchw, float* y, int N, 
 }
 
 extern "C" int nrgbd_conv2d_taps_f32(const float* x, const float* x_ss, int x_relu, const float* w_packed, float* y,
-                                     float* stats, int N, int H, int W, int Cin, int Cout, int taps, void* stream) {
+                                     float* stats, int N, int H, int W, int Cin, int Cout, int taps, int in_stride, void* stream) {
     using namespace nrgbd;
     if (!x || !w_packed || !y) return NRGBD_E_NULL;
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % kCB) return NRGBD_E_SHAPE;
-    if ((long)N * H * W * Cin >= (1L << 32)) return NRGBD_E_SHAPE;
     if (taps != 1 && taps != 4) return NRGBD_E_ARG;
+    if (in_stride < 1 || in_stride > 8 || (in_stride != 1 && taps != 1)) return NRGBD_E_ARG;
+    if ((long)N * H * W * Cin * in_stride * in_stride >= (1L << 32)) return NRGBD_E_SHAPE;
     Conv2dArgs a{x, x_ss, nullptr, nullptr, nullptr, w_packed, nullptr, y, stats, x_relu, 0, 0, N, H, W, Cin,
-                 0, Cout, 0, Cout, 0, 0, 0, nullptr};
+                 0, Cout, 0, Cout, 0, 0, 0, nullptr, in_stride};
     const int nwg = ceil_div(W, kT2) * ceil_div(H, kT2) * N;
     hipStream_t st = (hipStream_t)stream;
     if (taps == 1) {
@@ -713,13 +718,13 @@ extern "C" int nrgbd_nhwc_act(const float* x, const float* x_ss, int x_relu, con
 
 extern "C" int nrgbd_bn_finalize(const float* stats, int num_workgroups, int C, long count, const float* gamma,
                                  const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                                 float* scale_shift, unsigned int* collapse_count, void* stream) {
+                                 float* scale_shift, unsigned int* collapse_count, long long* batches_tracked, void* stream) {
     using namespace nrgbd;
     if (!stats || !gamma || !beta || !scale_shift) return NRGBD_E_NULL;
     if (num_workgroups <= 0 || count <= 0 || C <= 0) return NRGBD_E_SHAPE;
     if ((running_mean == nullptr) != (running_var == nullptr)) return NRGBD_E_NULL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, num_workgroups, C,
-                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift, collapse_count);
+                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift, collapse_count, batches_tracked);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

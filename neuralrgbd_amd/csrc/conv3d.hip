@@ -497,7 +497,7 @@ __global__ void conv3d_pack_weights_kernel(const float* __restrict__ w, float* _
 __global__ __launch_bounds__(256) void bn3d_finalize_kernel(const float* __restrict__ stats, int nwg, double count,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float eps, float momentum, float* __restrict__ running_mean,
-                                     float* __restrict__ running_var, float* __restrict__ ss, unsigned int* __restrict__ collapse_count) {
+                                     float* __restrict__ running_var, float* __restrict__ ss, unsigned int* __restrict__ collapse_count, long long* __restrict__ batches_tracked) {
     __shared__ double sh[2][256];
     const int c = blockIdx.x, tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
@@ -512,6 +512,7 @@ __global__ __launch_bounds__(256) void bn3d_finalize_kernel(const float* __restr
         __syncthreads();
     }
     if (tid == 0) bn_finalize_channel(sh[0][0], sh[1][0], count, gamma[c], beta[c], eps, momentum, running_mean, running_var, ss, c, collapse_count);
+    if (tid == 0 && c == 0 && batches_tracked) *batches_tracked += 1;      // nn.BatchNorm's num_batches_tracked side effect (one launch less per layer)
 }
 
 }  // namespace nrgbd
@@ -588,13 +589,13 @@ extern "C" int nrgbd_conv3d_3x3x3_cout1_f32(const float* x, const float* x_ss, i
 
 extern "C" int nrgbd_bn3d_finalize(const float* stats, int num_workgroups, long count, const float* gamma,
                                    const float* beta, float eps, float momentum, float* running_mean,
-                                   float* running_var, float* scale_shift, unsigned int* collapse_count, void* stream) {
+                                   float* running_var, float* scale_shift, unsigned int* collapse_count, long long* batches_tracked, void* stream) {
     using namespace nrgbd;
     if (!stats || !gamma || !beta || !scale_shift) return NRGBD_E_NULL;
     if (num_workgroups <= 0 || count <= 0) return NRGBD_E_SHAPE;
     if ((running_mean == nullptr) != (running_var == nullptr)) return NRGBD_E_NULL;
     hipLaunchKernelGGL(bn3d_finalize_kernel, dim3(kCout), dim3(256), 0, (hipStream_t)stream, stats, num_workgroups,
-                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift, collapse_count);
+                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift, collapse_count, batches_tracked);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -14,7 +14,8 @@ constexpr int kPackTX = 64;  // pixels of one image row per workgroup
 __global__ __launch_bounds__(256) void pack_nhwc_kernel(const float* __restrict__ feat,
                                                         const float* __restrict__ rgb,
                                                         float* __restrict__ out, int Cf, int h,
-                                                        int w, int pool, int Cp, int feat_nhwc) {
+                                                        int w, int pool, int Cp, int feat_nhwc,
+                                                        float* __restrict__ rgb4) {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [Cp][kPackTX + 1]
     constexpr int LD = kPackTX + 1;
     const int x0 = blockIdx.x * kPackTX, y = blockIdx.y, n = blockIdx.z;
@@ -63,13 +64,21 @@ __global__ __launch_bounds__(256) void pack_nhwc_kernel(const float* __restrict_
         o[i] = make_float4(tile[(c + 0) * LD + px], tile[(c + 1) * LD + px],
                            tile[(c + 2) * LD + px], tile[(c + 3) * LD + px]);
     }
+    // 5. the word that holds the pooled RGB (channels Cf .. Cf+3) once more as a compact [N][h][w][4] plane: the K-Net's warp
+    // gathers it, and at the texels' 272-byte stride every tap of that kernel touched its own cache line
+    if (rgb4) {
+        float4* r4 = reinterpret_cast<float4*>(rgb4) + ((size_t)n * h + y) * w + x0;
+        for (int px = tid; px < npx; px += 256)
+            r4[px] = make_float4(tile[(Cf + 0) * LD + px], tile[(Cf + 1) * LD + px], tile[(Cf + 2) * LD + px], tile[(Cf + 3) * LD + px]);
+    }
 }
 
 }  // namespace nrgbd
 
 extern "C" int nrgbd_pack_nhwc(const float* feat, const float* rgb, float* out, int N, int Cf,
-                               int h, int w, int pool, int Cp, int feat_channels_last, void* stream) {
+                               int h, int w, int pool, int Cp, int feat_channels_last, float* rgb4, void* stream) {
     if (!feat || !out) return NRGBD_E_NULL;
+    if (rgb4 && (Cp < Cf + 4 || (reinterpret_cast<uintptr_t>(rgb4) & 15))) return NRGBD_E_ALIGN;
     if (N <= 0 || Cf <= 0 || h <= 0 || w <= 0 || pool <= 0 || h > 65535 || N > 65535) return NRGBD_E_SHAPE;
     if ((Cp & 3) || Cp < Cf + (rgb ? 3 : 0)) return NRGBD_E_ALIGN;
     if (reinterpret_cast<uintptr_t>(out) & 15) return NRGBD_E_ALIGN;
@@ -77,7 +86,7 @@ extern "C" int nrgbd_pack_nhwc(const float* feat, const float* rgb, float* out, 
     if (lds > 160 * 1024) return NRGBD_E_SHAPE;
     dim3 grid(nrgbd::ceil_div(w, nrgbd::kPackTX), h, N);
     hipLaunchKernelGGL(nrgbd::pack_nhwc_kernel, grid, dim3(256), lds, (hipStream_t)stream, feat,
-                       rgb, out, Cf, h, w, pool, Cp, feat_channels_last);
+                       rgb, out, Cf, h, w, pool, Cp, feat_channels_last, rgb4);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

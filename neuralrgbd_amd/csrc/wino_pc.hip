@@ -636,13 +636,24 @@ __global__ __launch_bounds__(512) void conv_wino_pc_kernel(const WinoPcArgs a) {
 __global__ __launch_bounds__(1024) void bn_finalize_cm_kernel(const float* __restrict__ stats, int rows, int C, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float eps, float momentum, float* __restrict__ running_mean,
-                                                              float* __restrict__ running_var, float* __restrict__ ss, unsigned int* __restrict__ collapse_count) {
+                                                              float* __restrict__ running_var, float* __restrict__ ss, unsigned int* __restrict__ collapse_count, long long* __restrict__ batches_tracked) {
     __shared__ double sh[2][1024];
     const int c = blockIdx.x, tid = threadIdx.x;
     const float* p1 = stats + (size_t)c * rows;
     const float* p2 = stats + (size_t)(C + c) * rows;
+    // a thread's share is a few dozen strided floats (K-Net at config B: rows = 12,288 -> 12 per run): all of them are requested
+    // before the first is added (round 6: the one-at-a-time loop cost a DRAM latency per element, 15.4 us per K-Net layer at
+    // config B); the order of the fp64 additions per thread is unchanged (g ascending), so are the bits
     double s1 = 0.0, s2 = 0.0;
-    for (int g = tid; g < rows; g += 1024) { s1 += (double)p1[g]; s2 += (double)p2[g]; }
+    int g = tid;
+    for (; g + 7 * 1024 < rows; g += 8 * 1024) {
+        float u[8], v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { u[k] = p1[g + k * 1024]; v[k] = p2[g + k * 1024]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1 += (double)u[k]; s2 += (double)v[k]; }
+    }
+    for (; g < rows; g += 1024) { s1 += (double)p1[g]; s2 += (double)p2[g]; }
     sh[0][tid] = s1; sh[1][tid] = s2;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
@@ -650,6 +661,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_cm_kernel(const float* __res
         __syncthreads();
     }
     if (tid == 0) bn_finalize_channel(sh[0][0], sh[1][0], count, gamma[c], beta[c], eps, momentum, running_mean, running_var, ss, c, collapse_count);
+    if (tid == 0 && c == 0 && batches_tracked) *batches_tracked += 1;      // nn.BatchNorm's num_batches_tracked side effect (one launch less per layer)
 }
 
 // w [Cout][Cin][KD][3][3] -> U = G g G^T (float64, rounded once) in the kernel's B-operand order
@@ -704,14 +716,14 @@ extern "C" int nrgbd_conv_wino_pack(const float* w, float* w_wino, int Cin, int 
 }
 
 extern "C" int nrgbd_bn_finalize_cm(const float* stats, int rows, int C, long count, const float* gamma, const float* beta,
-                                    float eps, float momentum, float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count,
+                                    float eps, float momentum, float* running_mean, float* running_var, float* scale_shift, unsigned int* collapse_count, long long* batches_tracked,
                                     void* stream) {
     using namespace nrgbd;
     if (!stats || !gamma || !beta || !scale_shift) return NRGBD_E_NULL;
     if (rows <= 0 || count <= 0 || C <= 0) return NRGBD_E_SHAPE;
     if ((running_mean == nullptr) != (running_var == nullptr)) return NRGBD_E_NULL;
     hipLaunchKernelGGL(bn_finalize_cm_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, stats, rows, C, (double)count, gamma,
-                       beta, eps, momentum, running_mean, running_var, scale_shift, collapse_count);
+                       beta, eps, momentum, running_mean, running_var, scale_shift, collapse_count, batches_tracked);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

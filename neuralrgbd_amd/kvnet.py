@@ -47,6 +47,7 @@ class DNet(nn.Module):
         self.feat_dist = feat_dist
         self.align_corners = False  # torch>=1.3 grid_sample default, what the reference runs today
         self.texels = None
+        self.rgb4 = None            # [V+1,h,w,4]: the texels' pooled-RGB word as a compact plane (inference; written by pack_nhwc)
 
     def forward(self, ref_frame, src_frames, src_cam_poses, cam_intrinsics=None, BV_predict=None, debug_ipdb=False):
         assert src_frames.shape[0] == 1, 'dim0 of src_frames should be 0'
@@ -81,10 +82,13 @@ class DNet(nn.Module):
             texels = PackNHWC.apply(feats, rgb)
             cost = PlaneSweepCost.apply(texels, KR, Kt, rays, d_dev, cx, cy, self.sigma_soft_max, C,
                                         self.feat_dist, self.align_corners)
-            self.texels = texels.detach()
+            self.texels, self.rgb4 = texels.detach(), None
             BV = (LogSoftmaxD.apply(cost, None, -1.0) if self.BV_log else torch.softmax(-cost, dim=0)).unsqueeze(0)
         else:
-            texels = ops.pack_nhwc(feats, rgb, channels_last=feats_cl)
+            if rgb is not None:     # + the pooled-RGB word as a compact plane for the K-Net's warp (same launch)
+                texels, self.rgb4 = ops.pack_nhwc(feats, rgb, channels_last=feats_cl, want_rgb4=True)
+            else:
+                texels, self.rgb4 = ops.pack_nhwc(feats, rgb, channels_last=feats_cl), None
             self.texels = texels
             cost, logp = ops.costvol(texels[V], texels[:V], KR, Kt, rays, d_dev, cx, cy, self.sigma_soft_max, C,
                                      dist=self.feat_dist, align_corners=self.align_corners,
@@ -195,7 +199,7 @@ class KVNET(nn.Module):
         KR, Kt = warp_homo.homography_terms(K, src_cam_poses[0, :, :3, :3], src_cam_poses[0, :, :3, 3])
         # the RGB word of every texel as a compact [V+1,h,w,4] plane: at the texel tensor's 272-B stride every lane of the
         # warp kernel's gathers touched its own cache line; at 16 B per texel four neighbouring taps share one
-        rgb4 = texels[..., F_dim:].contiguous()
+        rgb4 = self.d_net.rgb4 if (self.d_net.rgb4 is not None and texels.shape[-1] == F_dim + 4) else texels[..., F_dim:].contiguous()
         rgb_src, rgb_ref, Cp = rgb4[:V], rgb4[V], rgb4.shape[-1]
         fused = (not torch.is_grad_enabled()) and self.kv_net.in_channels == 16 and self.KVNet_feature_dim == 64 \
             and not self.kv_net.if_normalize and self.kv_net.up_sample_ratio is None
@@ -225,7 +229,7 @@ class KVNET(nn.Module):
                 DPV = torch.log_softmax(gain + BV_predict, dim=1)
 
         if batch_refine:
-            both = self.r_net.forward_log(torch.cat((BV_cur, DPV), dim=0), features)     # [2,D,H,W]
+            both = self.r_net.forward_log((BV_cur, DPV), features)                       # [2,D,H,W]; no concatenation pass
             dmap_cur_refined, dmap_refined = both[0:1], both[1:2]
         else:
             dmap_refined = self._refine(DPV, features) if self.if_refined else -1

@@ -208,12 +208,16 @@ def _bn_scale_shift(bn, stats, count, cm=False):
     from . import ops
     if bn.training or not bn.track_running_stats:
         upd = bn.training and bn.track_running_stats
-        if upd:
+        nbt = None
+        if upd and bn.momentum is None:           # cumulative average: the factor needs the counter's value on the host
             bn.num_batches_tracked += 1
+        elif upd:
+            nbt = bn.num_batches_tracked          # incremented by the finaliser itself (an ATen launch less per layer)
         momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
         fin = ops.bn_finalize_cm if cm else ops.bn_finalize
         return fin(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, momentum,
-                   bn.running_mean if upd else None, bn.running_var if upd else None, status=status_word(stats.device))
+                   bn.running_mean if upd else None, bn.running_var if upd else None, status=status_word(stats.device),
+                   batches_tracked=nbt)
     sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
     return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 
@@ -381,13 +385,12 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         """1x1 Sequential(conv, bn) on a materialised channels-last tensor: the 1-tap form of csrc/conv2d.hip + statistics."""
         from . import ops
         conv, bn = seq[0], seq[1]
-        if stride != 1:
-            m = m[:, ::stride, ::stride, :]
         N, H, W, C = m.shape
-        if C % 16 != 0 or conv.out_channels not in (32, 64, 128):
-            raise _no_kernel("1x1 layer %d -> %d" % (C, conv.out_channels))
-        z, st = ops.conv2d_taps(m.contiguous(), _packed_weights(self, conv), conv.out_channels, 1, want_stats=_needs_stats(bn))
-        return _Act(z, _bn_scale_shift(bn, st, N * H * W), False)
+        if C % 16 != 0 or conv.out_channels not in (32, 64, 128) or H % stride or W % stride:
+            raise _no_kernel("1x1 layer %d -> %d, stride %d on a %d x %d map" % (C, conv.out_channels, stride, H, W))
+        # a strided shortcut (psm_submodule.py:127-131) reads every stride-th pixel inside the kernel: no gather pass
+        z, st = ops.conv2d_taps(m.contiguous(), _packed_weights(self, conv), conv.out_channels, 1, want_stats=_needs_stats(bn), stride=stride)
+        return _Act(z, _bn_scale_shift(bn, st, N * (H // stride) * (W // stride)), False)
 
     def _block_cl(self, blk, a):
         """BasicBlock (psm_submodule.py:31-50): out = bn(conv2(relu(bn(conv1(x))))) + shortcut(x), no ReLU after the add."""
@@ -410,7 +413,7 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
         channels-last.  Same graph as forward() (psm_submodule.py:136-167); every 3x3 stride-1 conv is one fused pass
         (conv on the fp32 matrix cores, BatchNorm statistics in its epilogue, normalise + ReLU + residual in the next
         layer's loader); the stride-2 3x3 convs run as 2x2-window convolutions on the space-to-depth image, the 1x1 convs as
-        the 1-tap form of the same kernel.  What is left of torch here: the SPP average pooling of the deep map."""
+        the 1-tap form of the same kernel, the SPP average pooling on csrc/glue.hip.  Nothing of the frame is a torch op."""
         from . import ops
         conv, bn = self.firstconv[0]
         if x.shape[2] % 4 or x.shape[3] % 4:
@@ -443,17 +446,18 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
             a = self._block_cl(blk, a)
         deep = ops.nhwc_act(a.z, a.ss, a.relu, a.r, a.r_ss, a.r_relu)
         N, h, w, _ = deep.shape
-        deep_nchw = deep.permute(0, 3, 1, 2)                               # channels-last view for the torch pooling ops
+        if h < 64 or w < 64:
+            raise _no_kernel("an SPP window of 64 on a %d x %d map (psm_submodule.py:100: images below 256 x 256)" % (h, w))
         if h % 8 == 0 and w % 8 == 0:                                      # see _spp_pools: the floor crops agree at every level
-            p8 = F.avg_pool2d(deep_nchw, 8)
-            pools = {8: p8, 16: F.avg_pool2d(p8, 2), 32: F.avg_pool2d(p8, 4), 64: F.avg_pool2d(p8, 8)}
+            p8 = ops.avgpool_cl(deep, 8)                                   # csrc/glue.hip: the map is read once, channels-last
+            pools = {8: p8, 16: ops.avgpool_cl(p8, 2), 32: ops.avgpool_cl(p8, 4), 64: ops.avgpool_cl(p8, 8)}
         else:
-            pools = {k: F.avg_pool2d(deep_nchw, (k, k), stride=(k, k)) for k in self.SPP_WINDOWS}
+            pools = {k: ops.avgpool_cl(deep, k) for k in self.SPP_WINDOWS}
         pyramid, fused = [], []
         for i in (4, 3, 2, 1):
             branch = getattr(self, "branch%d" % i)
             pool = pools[self.SPP_WINDOWS[i - 1]]
-            pb = self._pointwise_bn_cl(branch[1], pool.permute(0, 2, 3, 1).contiguous())   # 1x1 conv + BatchNorm statistics on the tiny map
+            pb = self._pointwise_bn_cl(branch[1], pool)                    # 1x1 conv + BatchNorm statistics on the tiny map
             if pb.ss is not None:
                 fused.append((pb.z, pb.ss))                                # normalise + ReLU at the taps of spp_concat
                 continue
@@ -575,12 +579,16 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         use_batch = bn.training or not bn.track_running_stats
         if use_batch:
             upd = bn.training and bn.track_running_stats
-            if upd:
+            nbt = None
+            if upd and bn.momentum is None:
                 bn.num_batches_tracked += 1
+            elif upd:
+                nbt = bn.num_batches_tracked      # incremented by the finaliser itself
             momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             fin = ops.bn_finalize_cm if cm else ops.bn3d_finalize
             return fin(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, momentum,
-                       bn.running_mean if upd else None, bn.running_var if upd else None, status=status_word(stats.device))
+                       bn.running_mean if upd else None, bn.running_var if upd else None, status=status_word(stats.device),
+                       batches_tracked=nbt)
         sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 
@@ -865,7 +873,10 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
         candidate up-sampling, other feature widths, D > 128 — raises NrgbdError: there is no vendor-library route);
         `img_features` are ONE image's features, shared by every sample of the batch (KVNET.forward refines BV_cur and DPV of
         a frame as one batch of 2)."""
-        if not self.mfma_ok(dpv_log):
+        first = dpv_log[0] if isinstance(dpv_log, (list, tuple)) else dpv_log
+        if not self.mfma_ok(first):
+            if isinstance(dpv_log, (list, tuple)):
+                dpv_log = torch.cat(list(dpv_log), dim=0)
             return self.forward(torch.exp(dpv_log), img_features)
         from . import ops
         wd = self._widths()
@@ -873,12 +884,17 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
             raise _no_kernel("this R-Net (candidate up-sampling, image-feature widths other than 64 / 32 / 3, or more than 128 candidates)")
         D, Dp = wd[0], wd[1]
         quarter, half, full = img_features
-        n, _, h, w = dpv_log.shape
+        if isinstance(dpv_log, (list, tuple)):     # the frame's two volumes (BV_cur, DPV) as they are: no torch.cat pass
+            vols = [v[i:i + 1] for v in dpv_log for i in range(v.shape[0])]
+        else:
+            vols = [dpv_log[i:i + 1] for i in range(dpv_log.shape[0])]
+        n = len(vols)
+        _, _, h, w = vols[0].shape
         if n > 2:                                  # buffers are kept for the path's two batch sizes; a larger batch in pairs
-            return torch.cat([self.forward_log(dpv_log[i:i + 2], img_features).clone() for i in range(0, n, 2)], dim=0)
+            return torch.cat([self.forward_log(vols[i:i + 2], img_features).clone() for i in range(0, n, 2)], dim=0)
         if tuple(quarter.shape) != (1, 64, h, w) or tuple(half.shape) != (1, 32, 2 * h, 2 * w) or tuple(full.shape) != (1, 3, 4 * h, 4 * w):
             raise ValueError("forward_log: features of ONE image at 1/4, 1/2 and full resolution ([1,64,h,w], [1,32,2h,2w], [1,3,4h,4w]) expected")
-        dev = dpv_log.device
+        dev = first.device
         pk, buf = self._rnet_packed(), self._rnet_buffers(n, h, w, dev)
 
         def deconv(x, layer, out):
@@ -899,25 +915,26 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
 
         # level 1/4: cat(exp(dpv), feat) -> conv0 -> conv0_1
         if D != Dp:
-            buf["dpv"][:, :D].copy_(dpv_log)
-            dpv_log = buf["dpv"]
+            for b in range(n):
+                buf["dpv"][b, :D].copy_(vols[b][0])
+            vols = [buf["dpv"][b:b + 1] for b in range(n)]
         q_cl = quarter.permute(0, 2, 3, 1)
         x = buf["x0"]
         for b in range(n):
             if q_cl.is_contiguous():
-                ops.rnet_pack(dpv_log[b].contiguous(), q_cl[0], feat_planar=False, out=x[b:b + 1])
+                ops.rnet_pack(vols[b][0].contiguous(), q_cl[0], feat_planar=False, out=x[b:b + 1])
             else:
-                ops.rnet_pack(dpv_log[b].contiguous(), quarter[0].contiguous(), feat_planar=True, out=x[b:b + 1])
+                ops.rnet_pack(vols[b][0].contiguous(), quarter[0].contiguous(), feat_planar=True, out=x[b:b + 1])
         x = conv_w(conv_w(x, "conv0", buf["a0"]), "conv0_1", buf["b0"])
         # level 1/2: transposed conv (4 sub-pixel phases) straight into channels 0..Dp-1 of the concat buffer; features behind
         c1 = buf["c1"]
         deconv(x, pk["t0"]["all"], c1)
-        c1[..., Dp:Dp + 32].copy_(half.permute(0, 2, 3, 1))
+        ops.scatter_channels(half[0], c1, Dp)          # the 1/2-resolution features behind the candidates of every sample (csrc/glue.hip)
         x = conv_w(conv_w(c1, "conv1", buf["a1"]), "conv1_1", buf["b1"])
         # full resolution: Dp + 3 channels in 16-aligned pixels (padding channels zero, with zero weights)
         c2 = buf["c2"]
         deconv(x, pk["t1"]["all"], c2)
-        c2[..., Dp:Dp + 3].copy_(full.permute(0, 2, 3, 1))
+        ops.scatter_channels(full[0], c2, Dp)
         x = conv_w(conv_w(c2, "conv2", buf["g2"]), "conv2_1", buf["h2"])
         # conv2_2 + bias on the Winograd kernel (pixels channels-last), then log-softmax over the channels of every pixel in place:
         # the refined DPV is handed out as an [n, D, H, W] VIEW of that channels-last memory (round 4; the direct kernel with the

@@ -80,8 +80,9 @@ def pose_inverse(T, singular_count=None):
     return out
 
 
-def pack_nhwc(feat, rgb=None, Cp=None, channels_last=False):
-    """feat [N,Cf,h,w] (or [N,h,w,Cf] if channels_last) (+ rgb [N,3,h*pool,w*pool]) -> texels [N,h,w,Cp] (nrgbd_pack_nhwc)."""
+def pack_nhwc(feat, rgb=None, Cp=None, channels_last=False, want_rgb4=False):
+    """feat [N,Cf,h,w] (or [N,h,w,Cf] if channels_last) (+ rgb [N,3,h*pool,w*pool]) -> texels [N,h,w,Cp] (nrgbd_pack_nhwc).
+    want_rgb4: -> (texels, rgb4 [N,h,w,4]): the pooled-RGB word of every texel once more as a compact plane (the K-Net's warp)."""
     feat = _need(feat, "feat")
     if channels_last:
         N, h, w, Cf = feat.shape
@@ -98,11 +99,12 @@ def pack_nhwc(feat, rgb=None, Cp=None, channels_last=False):
     if Cp is None:
         Cp = padded_channels(Cf + (3 if rgb is not None else 0))
     out = torch.empty((N, h, w, Cp), dtype=torch.float32, device=feat.device)
+    rgb4 = torch.empty((N, h, w, 4), dtype=torch.float32, device=feat.device) if want_rgb4 else None
     with torch.cuda.device(feat.device):
         rc = _lib.load().nrgbd_pack_nhwc(_p(feat), _p(rgb), _p(out), N, Cf, h, w, pool, Cp, int(bool(channels_last)),
-                                          _stream(feat))
+                                          _p(rgb4), _stream(feat))
     _lib.check(rc, "nrgbd_pack_nhwc")
-    return out
+    return (out, rgb4) if want_rgb4 else out
 
 
 def costvol(ref_nhwc, src_nhwc, KR, Kt, rays, d_candi, cx, cy, sigma, C, dist="L2",
@@ -531,14 +533,22 @@ def _status_ptr(status, like):
     return ctypes.c_void_p(status.data_ptr())
 
 
-def bn3d_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, status=None):
+def _nbt_ptr(nbt, like):
+    if nbt is None:
+        return ctypes.c_void_p(0)
+    if not (isinstance(nbt, torch.Tensor) and nbt.is_cuda and nbt.dtype == torch.int64 and nbt.numel() == 1 and nbt.device == like.device):
+        raise TypeError("batches_tracked must be an int64 scalar tensor on the device of the statistics")
+    return ctypes.c_void_p(nbt.data_ptr())
+
+
+def bn3d_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, status=None, batches_tracked=None):
     """Per-workgroup partials -> scale_shift [64,2]; updates the running statistics in place (train mode).
     status: int32 device word that counts variance-collapsed channels (include/nrgbd.h; nets.check_status raises on it)."""
     stats = _need(stats, "stats")
     ss = torch.empty((64, 2), dtype=torch.float32, device=stats.device)
     with torch.cuda.device(stats.device):
         rc = _lib.load().nrgbd_bn3d_finalize(_p(stats), stats.shape[0], int(count), _p(gamma), _p(beta), float(eps),
-                                             float(momentum), _p(running_mean), _p(running_var), _p(ss), _status_ptr(status, stats),
+                                             float(momentum), _p(running_mean), _p(running_var), _p(ss), _status_ptr(status, stats), _nbt_ptr(batches_tracked, stats),
                                              _stream(stats))
     _lib.check(rc, "nrgbd_bn3d_finalize")
     return ss
@@ -621,16 +631,21 @@ def space_to_depth2(x, nchw=False, cp=None):
     return y
 
 
-def conv2d_taps(x, w_packed, cout, taps, x_ss=None, x_relu=False, want_stats=True):
+def conv2d_taps(x, w_packed, cout, taps, x_ss=None, x_relu=False, want_stats=True, stride=1):
     """1x1 convolution (taps = 1) or the 2x2-window form of a stride-2 3x3 convolution on a space-to-depth input (taps = 4) on
-    the matrix-core kernel, with the trunk's prologue and statistics epilogue: x [N,H,W,Cin] -> (y [N,H,W,cout], stats | None)."""
+    the matrix-core kernel, with the trunk's prologue and statistics epilogue: x [N,H,W,Cin] -> (y [N,H,W,cout], stats | None).
+    stride > 1 (taps = 1 only): the 1x1 convolution's own stride — x [N,H*s,W*s,Cin] is read at every s-th pixel."""
     x = _need(x, "x")
     N, H, W, Cin = x.shape
+    if stride != 1:
+        if taps != 1 or H % stride or W % stride:
+            raise ValueError("conv2d_taps: a stride needs taps = 1 and sides that are multiples of it")
+        H, W = H // stride, W // stride
     y = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
     stats = torch.empty((conv2d_workgroups(N, H, W), 2 * cout), dtype=torch.float32, device=x.device) if want_stats else None
     with torch.cuda.device(x.device):
         rc = _lib.load().nrgbd_conv2d_taps_f32(_p(x), _p(x_ss), int(x_relu), _p(w_packed), _p(y), _p(stats), N, H, W, Cin,
-                                                int(cout), int(taps), _stream(x))
+                                                int(cout), int(taps), int(stride), _stream(x))
     _lib.check(rc, "nrgbd_conv2d_taps_f32")
     return y, stats
 
@@ -697,14 +712,14 @@ def rnet_pack(dpv_log, feat, feat_planar, out=None):
     return out
 
 
-def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, status=None):
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, status=None, batches_tracked=None):
     """Per-workgroup partials [nwg, 2C] -> scale_shift [C,2]; updates the running statistics in place (train mode)."""
     stats = _need(stats, "stats")
     C = stats.shape[1] // 2
     ss = torch.empty((C, 2), dtype=torch.float32, device=stats.device)
     with torch.cuda.device(stats.device):
         rc = _lib.load().nrgbd_bn_finalize(_p(stats), stats.shape[0], C, int(count), _p(gamma), _p(beta), float(eps),
-                                           float(momentum), _p(running_mean), _p(running_var), _p(ss), _status_ptr(status, stats),
+                                           float(momentum), _p(running_mean), _p(running_var), _p(ss), _status_ptr(status, stats), _nbt_ptr(batches_tracked, stats),
                                            _stream(stats))
     _lib.check(rc, "nrgbd_bn_finalize")
     return ss
@@ -775,14 +790,14 @@ def bn_cl_bwd(x, gy, coef, relu):
     return gx, gg[0], gg[1]
 
 
-def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, status=None):
+def bn_finalize_cm(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, status=None, batches_tracked=None):
     """Column-major per-tile partials [2C, rows] (conv_wino) -> scale_shift [C,2]; updates the running statistics in place."""
     stats = _need(stats, "stats")
     C = stats.shape[0] // 2
     ss = torch.empty((C, 2), dtype=torch.float32, device=stats.device)
     with torch.cuda.device(stats.device):
         rc = _lib.load().nrgbd_bn_finalize_cm(_p(stats), stats.shape[1], C, int(count), _p(gamma), _p(beta), float(eps),
-                                              float(momentum), _p(running_mean), _p(running_var), _p(ss), _status_ptr(status, stats),
+                                              float(momentum), _p(running_mean), _p(running_var), _p(ss), _status_ptr(status, stats), _nbt_ptr(batches_tracked, stats),
                                               _stream(stats))
     _lib.check(rc, "nrgbd_bn_finalize_cm")
     return ss
@@ -983,6 +998,32 @@ def avgpool8(x):
         rc = _lib.load().nrgbd_avgpool8(_p(x), _p(y), N * C, H, W, _stream(x))
     _lib.check(rc, "nrgbd_avgpool8")
     return y
+
+
+def avgpool_cl(x, k):
+    """k x k / stride-k average pooling of a channels-last map x [N,H,W,C] -> [N,H//k,W//k,C] (nrgbd_avgpool_cl; floor like avg_pool2d)."""
+    x = _need(x, "x")
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // k, W // k, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_avgpool_cl(_p(x), _p(y), N, H, W, C, int(k), _stream(x))
+    _lib.check(rc, "nrgbd_avgpool_cl")
+    return y
+
+
+def scatter_channels(src, dst, coff):
+    """dst[r, y, x, coff + c] = src[c, y, x] for every image r of the channels-last buffer dst [R,H,W,ldy]; src is any strided
+    [C,H,W] view (NCHW planes or a permuted channels-last tensor) (nrgbd_scatter_channels)."""
+    src = _need(src, "src", strided=True)
+    dst = _need(dst, "dst", strided=True)
+    C, H, W = src.shape
+    if dst.dim() != 4 or tuple(dst.shape[1:3]) != (H, W) or not dst.is_contiguous() or dst.shape[3] < coff + C:
+        raise ValueError("scatter_channels: dst must be a contiguous [R,%d,%d,>= %d] tensor" % (H, W, coff + C))
+    with torch.cuda.device(src.device):
+        rc = _lib.load().nrgbd_scatter_channels(_p(src), src.stride(0), src.stride(1), src.stride(2), C, H, W, _p(dst),
+                                                 int(dst.shape[3]), int(coff), int(dst.shape[0]), int(dst.stride(0)), _stream(src))
+    _lib.check(rc, "nrgbd_scatter_channels")
+    return dst
 
 
 def bias_act_(x, bias, slope):

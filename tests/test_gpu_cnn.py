@@ -372,3 +372,39 @@ def test_upsample_bilinear_align_corners_forward_and_adjoint(N, bh, bw, H, W, C)
     # <adjoint(gy), x> == <gy, forward(x)> (the kernel pair is an exact adjoint pair up to fp32 summation)
     lhs, rhs = (gx.double() * x.detach().double()).sum().item(), (gy.double() * y.detach().double()).sum().item()
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(rhs))
+
+
+def test_glue_kernels_pool_scatter_strided_pointwise_and_rgb_plane():
+    """Round 6: the ATen launches that were left in the inference frame (avg_pool2d, strided copies, a cat) on csrc/glue.hip and as
+    options of existing kernels, each against the torch op it replaces (psm_submodule.py:100-117,127-131; Refine.py:88-98;
+    KVNET.py:147-158)."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(9)
+    # channels-last average pooling, incl. a ragged border (floor like avg_pool2d)
+    for (N, H, W, C, k) in ((5, 48, 64, 128, 8), (2, 6, 8, 128, 2), (1, 70, 52, 32, 8), (3, 64, 64, 64, 64)):
+        x = torch.randn(N, H, W, C, generator=g).to(DEV)
+        got = ops.avgpool_cl(x, k)
+        want = F.avg_pool2d(x.permute(0, 3, 1, 2).double(), k).permute(0, 2, 3, 1)
+        assert tuple(got.shape) == tuple(want.shape) and (got.double() - want).abs().max().item() < 1e-6
+    # a strided [C,H,W] view into the channel window of every image of a wider channels-last buffer
+    for src in (torch.randn(1, 3, 40, 56, generator=g).to(DEV)[0],                              # NCHW planes (the image)
+                torch.randn(1, 20, 28, 32, generator=g).to(DEV).permute(0, 3, 1, 2)[0]):        # NCHW view of channels-last memory
+        C, H, W = src.shape
+        dst = torch.full((2, H, W, 64 + 16), 7.0, device=DEV)
+        ops.scatter_channels(src, dst, 64)
+        for r in range(2):
+            assert torch.equal(dst[r, :, :, 64:64 + C], src.permute(1, 2, 0))
+        assert bool((dst[..., :64] == 7.0).all()) and bool((dst[..., 64 + C:] == 7.0).all())    # the rest of the pixel untouched
+    # 1x1 convolution with its own stride: no gather pass (layer2's shortcut)
+    x = torch.randn(5, 32, 48, 32, generator=g).to(DEV)
+    w = (torch.randn(64, 32, 1, 1, generator=g) * 0.2).to(DEV)
+    y, st = ops.conv2d_taps(x, ops.conv_pack_weights(w), 64, 1, stride=2)
+    want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), stride=2).permute(0, 2, 3, 1)
+    assert tuple(y.shape) == (5, 16, 24, 64) and (y.double() - want).abs().max().item() < 1e-5
+    y1, st1 = ops.conv2d_taps(x[:, ::2, ::2].contiguous(), ops.conv_pack_weights(w), 64, 1)
+    assert torch.equal(y, y1) and torch.equal(st, st1)                                           # the bits of the gathered form
+    # the pooled-RGB word of the texels as a compact plane, from the same launch
+    feat = torch.randn(5, 12, 16, 64, generator=g).to(DEV)
+    rgb = torch.randn(5, 3, 48, 64, generator=g).to(DEV)
+    tex, rgb4 = ops.pack_nhwc(feat, rgb, channels_last=True, want_rgb4=True)
+    assert torch.equal(tex, ops.pack_nhwc(feat, rgb, channels_last=True)) and torch.equal(rgb4, tex[..., 64:].contiguous())
