@@ -450,7 +450,9 @@ class PSMFeatures(_PackedWeightsMixin, nn.Module):
             raise _no_kernel("an SPP window of 64 on a %d x %d map (psm_submodule.py:100: images below 256 x 256)" % (h, w))
         if h % 8 == 0 and w % 8 == 0:                                      # see _spp_pools: the floor crops agree at every level
             p8 = ops.avgpool_cl(deep, 8)                                   # csrc/glue.hip: the map is read once, channels-last
-            pools = {8: p8, 16: ops.avgpool_cl(p8, 2), 32: ops.avgpool_cl(p8, 4), 64: ops.avgpool_cl(p8, 8)}
+            p16 = ops.avgpool_cl(p8, 2)                                    # 2 x 2 of the level below: equal windows, the mean of means
+            p32 = ops.avgpool_cl(p16, 2)
+            pools = {8: p8, 16: p16, 32: p32, 64: ops.avgpool_cl(p32, 2)}
         else:
             pools = {k: ops.avgpool_cl(deep, k) for k in self.SPP_WINDOWS}
         pyramid, fused = [], []

@@ -381,7 +381,7 @@ def test_glue_kernels_pool_scatter_strided_pointwise_and_rgb_plane():
     from neuralrgbd_amd import ops
     g = torch.Generator().manual_seed(9)
     # channels-last average pooling, incl. a ragged border (floor like avg_pool2d)
-    for (N, H, W, C, k) in ((5, 48, 64, 128, 8), (2, 6, 8, 128, 2), (1, 70, 52, 32, 8), (3, 64, 64, 64, 64)):
+    for (N, H, W, C, k) in ((5, 48, 64, 128, 8), (5, 192, 256, 128, 8), (2, 6, 8, 128, 2), (1, 70, 52, 32, 8), (2, 120, 160, 64, 8), (3, 64, 64, 64, 64)):
         x = torch.randn(N, H, W, C, generator=g).to(DEV)
         got = ops.avgpool_cl(x, k)
         want = F.avg_pool2d(x.permute(0, 3, 1, 2).double(), k).permute(0, 2, 3, 1)
@@ -390,7 +390,7 @@ def test_glue_kernels_pool_scatter_strided_pointwise_and_rgb_plane():
     for src in (torch.randn(1, 3, 40, 56, generator=g).to(DEV)[0],                              # NCHW planes (the image)
                 torch.randn(1, 20, 28, 32, generator=g).to(DEV).permute(0, 3, 1, 2)[0]):        # NCHW view of channels-last memory
         C, H, W = src.shape
-        dst = torch.full((2, H, W, 64 + 16), 7.0, device=DEV)
+        dst = torch.full((2, H, W, 64 + 48), 7.0, device=DEV)
         ops.scatter_channels(src, dst, 64)
         for r in range(2):
             assert torch.equal(dst[r, :, :, 64:64 + C], src.permute(1, 2, 0))
