@@ -193,7 +193,12 @@ def check_status(device):
     w = _status_words.get(str(device))
     if w is None:
         return
-    n = int(w.item())
+    # read through a device-side copy, never by a memcpy FROM the word itself: on this stack (ROCm 7.0 / torch 2.10) a direct
+    # device -> host copy of this long-lived 4-byte allocation between two replays of an unrelated hipGraph (train_step.TrainGraph)
+    # reproducibly changed what the graph's NEXT replay computed (tests/test_gpu_train.py::test_split_train_graph_with_accumulation_
+    # equals_eager_accumulation: 8 of 8 runs; reading a clone, or any freshly allocated tensor, never did).  Unexplained — the word is
+    # only ever written by a finaliser that found a collapsed channel — and avoided: the clone is one tiny kernel.
+    n = int(w.clone().item())
     if n:
         w.zero_()
         from ._lib import NrgbdError

@@ -87,7 +87,8 @@ class DepthStream:
         if self._status_host is None:
             self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._status_event = torch.cuda.Event()
-        self._status_host.copy_(word, non_blocking=True)
+        self._status_stage = word.clone()           # a device-side copy first (see nets.check_status: no memcpy from the word itself)
+        self._status_host.copy_(self._status_stage, non_blocking=True)
         self._status_event.record(torch.cuda.current_stream(self.device))
 
     def check(self):
