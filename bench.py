@@ -663,6 +663,8 @@ def main():
                     "(a step is then one frame of EVERY stream; the extra streams fill the tails of each other's kernels)")
     ap.add_argument("--back-to-back", action="store_true", help="(kept for old command lines: roofline.back_to_back_ms — the sampling kernel re-launched "
                     "20x back to back between one pair of events, the figure of rounds 1-4 — is always reported now)")
+    ap.add_argument("--no-pipeline", action="store_true", help="strictly sequential frames (one hipGraph per frame) instead of the default: the D-Net "
+                    "of frame t + 1 on a second HIP stream under the K-Net / R-Net / PREDICT of frame t (same video, same kernels, same bits)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short companion runs of configs S / K / H and of one "
                     "training step (N = 1, headline config only; about a minute)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU self-test of the N>1 harness
@@ -716,7 +718,8 @@ def main():
     S = max(1, args.streams)
     models = [model] + [copy.deepcopy(model) for _ in range(S - 1)]
     hip_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
-    streams = [DepthStream(m, cam, d_candi, t_win_r=2, use_graph=not args.no_graph, device=dev) for m in models]
+    pipe = (not args.no_pipeline) and (not args.no_graph)
+    streams = [DepthStream(m, cam, d_candi, t_win_r=2, use_graph=not args.no_graph, device=dev, pipeline=pipe) for m in models]
     stream = streams[0]
 
     def frame(i):
@@ -728,10 +731,27 @@ def main():
         return out
 
     frame(0)                       # first window of the stream: D-Net only, creates the filter state
-    for i in range(max(args.warmup, 2)):   # >= 2: one eager update frame, then the capture frame
+    # >= 2: one eager update frame, then the capture frame; pipelined: two eager frames, the capture, one replay of either slot
+    for i in range(max(args.warmup, 6 if pipe else 2)):
         frame(i + 1)
 
     dt = timed_steps(frame, args.steps, world, dev)
+    seq_fps = None
+    if pipe:
+        # the same stream once more WITHOUT the overlap (one hipGraph per frame, strictly sequential): reported beside the headline
+        for st_ in streams:
+            st_.flush()
+        seq = [DepthStream(m, cam, d_candi, t_win_r=2, use_graph=True, device=dev, pipeline=False) for m in models]
+
+        def seq_frame(i):
+            for k in range(S):
+                r, s_, p = ring[(i + k) % len(ring)]
+                with torch.cuda.stream(hip_streams[k]):
+                    seq[k].step(r, s_, p)
+        for i in range(4):
+            seq_frame(i)
+        dt_seq = timed_steps(seq_frame, args.steps, world, dev)
+        seq_fps = args.steps * S * world / dt_seq
     pred = stream.bv_predict
     assert bool(torch.isfinite(pred).all()), "filter state went non-finite"
     per_rank = rank_times(world, args.steps, dev)
@@ -779,7 +799,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "config_id": args.config, "grid_hw": [h, w], "depth_candidates": D,
-                       "views": V + 1, "streams_per_gpu": S, "streams_total": S * world, "launch": "hipGraph replay" if stream._graph is not None else "eager",
+                       "views": V + 1, "streams_per_gpu": S, "streams_total": S * world,
+                       "launch": ("hipGraph replay, the two halves of consecutive frames of the video pipelined: D-Net (feature CNN + fused warp / cost volume) of "
+                                  "frame t+1 on a second HIP stream under K-Net + DPV update + R-Net + PREDICT of frame t; every frame computed in full, "
+                                  "outputs bit-identical to the sequential order (tests/test_gpu_fullsize.py), one frame of latency"
+                                  if pipe and stream._graph is not None else "hipGraph replay" if stream._graph is not None else "eager"),
+                       "sequential_frames_per_s": seq_fps,
                        "parallelism": "replicas x%d (independent video streams)" % world,
                        "peak_hbm_gb": torch.cuda.max_memory_allocated(dev) / 1e9},
             "roofline": {"bound": "hbm", "kernel": "costvol_quad<L2,3> (fused warp + cost volume + log-softmax over depth, one launch)",

@@ -150,8 +150,21 @@ class KVNET(nn.Module):
             return self.r_net.forward_log(dpv_log, features)      # exp fused into the first concat; matrix-core convs
         return self.r_net(torch.exp(dpv_log), img_features=features)
 
+    # ------------------------------------------------------------------ the frame in two halves (streaming.DepthStream pipelines them)
+    def measure(self, ref_frame, src_frames, src_cam_poses):
+        """FRONT half of an inference frame: everything that does not depend on the filter state — the feature CNN of the window,
+        the texel pack, the fused warp + cost volume + log-softmax (KVNET.py:120-123: `self.d_net(...)`).  Returns the record
+        `forward(..., measured=record)` continues from: the D-Net of frame t+1 can run while the K-Net of frame t is still busy
+        (a2-a4 of the next frame are independent of this frame's state)."""
+        if self.if_refined:
+            BV_cur, features = self.d_net(ref_frame, src_frames, src_cam_poses, BV_predict=None)
+            features.append(ref_frame)
+        else:
+            BV_cur, features = self.d_net(ref_frame, src_frames, src_cam_poses, BV_predict=None), None
+        return {"BV_cur": BV_cur, "features": features, "texels": self.d_net.texels, "rgb4": self.d_net.rgb4}
+
     def forward(self, ref_frame, src_frames, src_cam_poses, BatchIdx, cam_intrinsics=None,
-                BV_predict=None, mGPU=False, IntMs=None, unit_ray_Ms_2D=None, dpv_valid=None):
+                BV_predict=None, mGPU=False, IntMs=None, unit_ray_Ms_2D=None, dpv_valid=None, measured=None):
         """
         ref_frame [1,3,H,W], src_frames [1,V,3,H,W], src_cam_poses [1,V,4,4], BatchIdx [1],
         cam_intrinsics: list of dicts, BV_predict [1,D,h,w] or None.
@@ -159,6 +172,7 @@ class KVNET(nn.Module):
         D-Net pair twice; -1 sentinels when if_refined is False (KVNET.py:136-143,182).
         `dpv_valid` (extension): host-side validity of BV_predict; None = probe the tensor like
         the reference's valid_dpv (one device->host read).
+        `measured` (extension): the record of `measure()` for this window — the D-Net is then not run again.
         """
         has_pred = isinstance(BV_predict, torch.Tensor)
         if has_pred and dpv_valid is None:
@@ -171,19 +185,19 @@ class KVNET(nn.Module):
         # quarter-resolution layers, which alone do not fill the chip
         batch_refine = (self.if_refined and has_pred and bool(dpv_valid) and not torch.is_grad_enabled()
                         and hasattr(self.r_net, "forward_log") and self.r_net.mfma_ok(BV_predict))
+        if measured is None:
+            measured = self.measure(ref_frame, src_frames, src_cam_poses)
+        BV_cur, features = measured["BV_cur"], measured["features"]
         if self.if_refined:
-            BV_cur, features = self.d_net(ref_frame, src_frames, src_cam_poses, BV_predict=None)
-            features.append(ref_frame)
             dmap_cur_refined = None if batch_refine else self._refine(BV_cur, features)
         else:
-            BV_cur = self.d_net(ref_frame, src_frames, src_cam_poses, BV_predict=None)
             dmap_cur_refined = -1
 
         if not has_pred or not dpv_valid:
             return dmap_cur_refined, dmap_cur_refined, BV_cur, BV_cur
 
         # ---- K-Net: warp the 1/4-res RGB of the sources to the reference for every candidate ----
-        texels = self.d_net.texels            # [V+1,h,w,Cp]; channels F..F+2 are the pooled RGB
+        texels = measured["texels"]           # [V+1,h,w,Cp]; channels F..F+2 are the pooled RGB
         V = src_frames.shape[1]
         h, w, Cp = texels.shape[1:]
         F_dim = self.feature_dim
@@ -199,7 +213,7 @@ class KVNET(nn.Module):
         KR, Kt = warp_homo.homography_terms(K, src_cam_poses[0, :, :3, :3], src_cam_poses[0, :, :3, 3])
         # the RGB word of every texel as a compact [V+1,h,w,4] plane: at the texel tensor's 272-B stride every lane of the
         # warp kernel's gathers touched its own cache line; at 16 B per texel four neighbouring taps share one
-        rgb4 = self.d_net.rgb4 if (self.d_net.rgb4 is not None and texels.shape[-1] == F_dim + 4) else texels[..., F_dim:].contiguous()
+        rgb4 = measured["rgb4"] if (measured["rgb4"] is not None and texels.shape[-1] == F_dim + 4) else texels[..., F_dim:].contiguous()
         rgb_src, rgb_ref, Cp = rgb4[:V], rgb4[V], rgb4.shape[-1]
         fused = (not torch.is_grad_enabled()) and self.kv_net.in_channels == 16 and self.KVNet_feature_dim == 64 \
             and not self.kv_net.if_normalize and self.kv_net.up_sample_ratio is None

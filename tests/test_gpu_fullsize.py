@@ -112,3 +112,36 @@ def test_stream_graph_replay_equals_eager():
         err = (a - b).abs()
         print("[parity] graph replay vs eager %-10s max|d|=%.2e mean|d|=%.2e" % (name, err.max().item(), err.mean().item()))
         assert err.mean().item() < 1e-4 and err.max().item() < 5e-3
+
+
+@pytest.mark.parametrize("H,W,D", [(256, 384, 64), (256, 256, 16)])
+def test_pipelined_stream_is_bit_identical_to_the_sequential_one(H, W, D):
+    """DepthStream(pipeline=True): the D-Net of frame t + 1 on a second HIP stream under the K-Net / R-Net / PREDICT of frame t.
+    Same kernels on the same inputs: every frame's refined DPV, DPV and predicted state equal the sequential stream's BIT FOR BIT
+    (eager warm-up frames, the capture frame, replays of both slots), one call later; flush() hands out the last frame."""
+    import neuralrgbd_amd
+    from neuralrgbd_amd.streaming import DepthStream
+    cam = camera.scannet_intrinsics(W // 4, H // 4)
+    d_candi = np.linspace(0.1, 5, D)
+    wins = [tuple(t.to(DEV) for t in synth.noise_window(90 + i, H, W)) for i in range(10)]
+    got = {}
+    for pipe in (False, True):
+        model = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
+        model.load_state_dict(synth.seeded_state_dict(model, 0))
+        stream = DepthStream(model.to(DEV), cam, d_candi, use_graph=True, pipeline=pipe, copy_outputs=True)
+        outs = []
+        for i, (r, s, p) in enumerate(wins):
+            o = stream.step(r, s, p)
+            if o is not None:
+                outs.append((o[0].clone(), o[1].clone()))
+        if pipe:
+            assert len(outs) == len(wins) - 1            # one frame of latency ...
+            outs.append(stream.flush())                  # ... handed out here
+            assert stream.flush() is None
+        assert stream._graph is not None, stream.graph_error
+        torch.cuda.synchronize()
+        got[pipe] = (outs, stream.bv_predict.clone())
+    assert len(got[True][0]) == len(got[False][0]) == len(wins)
+    for i, (a, b) in enumerate(zip(got[True][0], got[False][0])):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "frame %d" % i
+    assert torch.equal(got[True][1], got[False][1])
