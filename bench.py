@@ -19,7 +19,7 @@ The JSON line carries
                 algorithmic bytes 4[(V+1)*67*hw + D*hw] per launch / its mean launch duration, measured
                 with HIP events on the launch stream inside the timed steps (peak 8.0 TB/s);
                 `traffic` = HBM-side bytes per launch from a committed rocprofv3 --pmc measurement of this bench's
-                own windows (tools/pmc_traffic.sh -> profiles/r5_costvol_traffic.json), reported only while the kernel's
+                own windows (tools/pmc_traffic.sh -> profiles/r6_costvol_traffic.json), reported only while the kernel's
                 sources still hash to what the measurement recorded;
   cpu_baseline  the CPU oracle (oracle/kvnet_oracle.py: the reference algorithm restated on torch-CPU
                 + the C sampling oracle) timed on this node's host cores on update frames of the same
@@ -53,7 +53,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (256
 # `bench.py --no-graph` under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) and writes the per-launch mean of
 # the costvol kernel's dispatches to profiles/r2_costvol_traffic.json (FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
 # prescribes for gfx950).  Configs without an entry report null.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r5_costvol_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r6_costvol_traffic.json")
 COSTVOL_SOURCES = ("costvol_quad.hip", "costvol.hip", "costvol.hpp", "common.hpp")   # what the measured kernel is built from
 
 
@@ -326,9 +326,23 @@ def other_configs(skip, timeout_s=240):
             out[cfg] = {"workload": doc["config"]["workload"], "frames_per_s": doc["value"], "ms_per_frame": doc["ms_per_step"],
                         "costvol_kernel_ms": doc["roofline"]["kernel_ms"], "costvol_hbm_frac": doc["roofline"]["frac"],
                         "knet_layer_mfma_frac": doc.get("roofline_mfma", {}).get("frac"), "steps": steps, "warmup": 3,
+                        "sequential_frames_per_s": doc["config"].get("sequential_frames_per_s"),
                         "peak_hbm_gb": doc["config"].get("peak_hbm_gb")}
         except Exception as e:      # a companion must never cost the headline line
             out[cfg] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    # the small grids with several independent videos per GPU (each its own model replica, filter state, hipGraphs and HIP stream):
+    # config S / K launches fill a fraction of the chip, so concurrent streams recover the idle CUs
+    for cfg, ns in (("S", 4), ("K", 3)):
+        if cfg == skip:
+            continue
+        try:
+            r = subprocess.run(base + ["--config", cfg, "--streams", str(ns), "--steps", "20", "--warmup", "6"], capture_output=True, text=True, timeout=timeout_s)
+            doc = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            out["%s_x%d_streams" % (cfg, ns)] = {"workload": doc["config"]["workload"], "streams_per_gpu": ns, "frames_per_s": doc["value"],
+                                                 "ms_per_step_all_streams": doc["ms_per_step"], "steps": 20, "warmup": 6,
+                                                 "note": "whole-GPU throughput over %d concurrent videos; the per-video rate is this / %d" % (ns, ns)}
+        except Exception as e:
+            out["%s_x%d_streams" % (cfg, ns)] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     try:
         r = subprocess.run(base + ["--mode", "train", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=timeout_s)
         doc = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

@@ -1,7 +1,7 @@
 # round-end verification on the GPU box: tests, smoke, default bench (with CPU baseline + parity), other configs, train line,
 # kernel profiles of the bench (B, S, K), PMC traffic of the sampling kernel, PMC counters of the Winograd kernels
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r5final}; mkdir -p $O
+O=gpurun_out/${1:-r6final}; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "amdgpu.ids" > $O/pytest_full.txt; grep -E "passed|failed|error" $O/pytest_full.txt | tail -3 > $O/pytest.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 # the kernels smoke() launches (no miopen / Cijk row may appear): a kernel trace of the same call
@@ -20,9 +20,9 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_T -- python bench.py --mode train --accum 1 --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $O/prof_T.log 2>&1
 cp $(find $O/prof_T -name "*kernel_stats.csv" | head -1) $O/bench_train_kernel_stats.csv; rm -rf $O/prof_T
 if [ -z "$SKIP_PMC" ]; then   # SKIP_PMC=1: the committed PMC files stay valid while the sampling / Winograd kernel sources are unchanged
-bash tools/pmc_traffic.sh ${1:-r5final}/traffic B S K H > /dev/null 2>&1
+bash tools/pmc_traffic.sh ${1:-r6final}/traffic B S K H > /dev/null 2>&1
 cp $O/traffic/costvol_traffic.json $O/costvol_traffic.json; rm -rf $O/traffic/*/fetch $O/traffic/*/write
-bash tools/pmc_wino.sh ${1:-r5final}/pmc_wino B wino-dw > /dev/null 2>&1
+bash tools/pmc_wino.sh ${1:-r6final}/pmc_wino B wino-dw > /dev/null 2>&1
 cp $O/pmc_wino/summary.txt $O/pmc_wino_summary.txt; rm -rf $O/pmc_wino/pmc?
 fi
 cat $O/pytest.txt $O/smoke.txt | tail -8

@@ -3,7 +3,7 @@
 # separate passes (MI355X_MICROARCH.md §HBM: they do not fit one pass; never combined with trace domains) around
 # `bench.py --no-graph` (eager launches, so every costvol dispatch of the frames is visible), for each config given.
 #   bash tools/pmc_traffic.sh <outdir under gpurun_out> [configs...]      e.g.  bash tools/pmc_traffic.sh r2_traffic B S K H
-# Result: gpurun_out/<outdir>/costvol_traffic.json — copy it to profiles/r5_costvol_traffic.json; bench.py reports it as
+# Result: gpurun_out/<outdir>/costvol_traffic.json — copy it to profiles/r6_costvol_traffic.json; bench.py reports it as
 # roofline.traffic (per launch, FETCH_SIZE doubled as the guide prescribes for gfx950 16-B/lane streaming reads).
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
