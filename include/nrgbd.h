@@ -47,7 +47,7 @@ extern "C" {
  * were built for.  0.4 (round 4): nrgbd_costvol_bwd takes (workspace, workspace_bytes) before `stream` (since round 3: query
  * nrgbd_costvol_bwd_workspace first); nrgbd_conv3d_wino_* and nrgbd_conv_wino_dw_bn_f32 are gone; nrgbd_upsample_bilinear_ac
  * is new.  0.5 (round 6): the three BatchNorm finalisers take (collapse_count, batches_tracked) before `stream`; nrgbd_pack_nhwc takes
- * rgb4, nrgbd_conv2d_taps_f32 takes in_stride; nrgbd_avgpool_cl and nrgbd_scatter_channels are new. */
+ * rgb4, nrgbd_conv2d_taps_f32 takes in_stride; nrgbd_avgpool_cl, nrgbd_scatter_channels and nrgbd_conv2d_few_f32 are new. */
 #define NRGBD_INTERFACE_VERSION "0.5"
 const char* nrgbd_version(void);
 const char* nrgbd_strerror(int code);
@@ -359,6 +359,17 @@ int nrgbd_avgpool8(const float* x, float* y, int NC, int H, int W, void* stream)
  * (`torch.cat((dpv, feat), dim=1)`), written straight into the R-Net's channels-last concat buffers for every sample of the batch.
  */
 int nrgbd_avgpool_cl(const float* x, float* y, int N, int H, int W, int C, int k, void* stream);
+/*
+ * nrgbd_conv2d_few_f32 — 3x3 convolution (stride 1, pad 1) + bias + optional LeakyReLU(0.01) with 1..4 OUTPUT channels, on the vector
+ * ALUs.  Replaces: the three output columns beyond the 64-column groups of models/Refine.py:64-66 conv2 (conv2d_leakyRelu(D + 3, D + 3):
+ * 67 = 64 + 3, 131 = 128 + 3 outputs), which otherwise cost a whole extra pass of the matrix-core kernel over the full-resolution buffer.
+ *   x [N][H][W][ldx] channels-last, channels 0 .. Cin-1 read (Cin % 16 == 0 <= ldx, ldx % 4 == 0: padding channels carry zero weights)
+ *   w_packed [Cin/16][9 taps = ky*3 + kx][Cout][16]  = w[co][16*block + lane][ky][kx]     (host mirror: nets.DPVUpsampleNet._rnet_packed)
+ *   y [N][H][W][ldy]: output column co at y[pixel * ldy + ycoff + co]; the rest of the pixel is left alone
+ * Summation per output: bias, then (block, tap, channel) ascending — one fp32 FMA chain.
+ */
+int nrgbd_conv2d_few_f32(const float* x, int ldx, const float* w_packed, const float* bias, int out_lrelu, float* y, int ldy,
+                         int ycoff, int N, int H, int W, int Cin, int Cout, void* stream);
 int nrgbd_scatter_channels(const float* src, long stride_c, long stride_y, long stride_x, int C, int H, int W, float* dst,
                            int ldy, int coff, int n_rep, long rep_stride, void* stream);
 /*

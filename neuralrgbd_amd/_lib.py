@@ -64,6 +64,7 @@ SIGNATURES = {
     "nrgbd_bn2d_partial_floats": (_I, [_I]),
     "nrgbd_bn2d_train_act": (_I, [_P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _L, _P]),
     "nrgbd_avgpool8": (_I, [_P, _P, _I, _I, _I, _P]),
+    "nrgbd_conv2d_few_f32": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nrgbd_avgpool_cl": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_scatter_channels": (_I, [_P, _L, _L, _L, _I, _I, _I, _P, _I, _I, _I, _L, _P]),
     "nrgbd_bias_act_nchw": (_I, [_P, _P, _F, _I, _I, _L, _P]),

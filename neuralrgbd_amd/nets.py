@@ -837,6 +837,14 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
             bp = b.new_zeros(cout_p)
             bp[:w.shape[0]] = b
             extra = w.shape[0] % 64
+            if 0 < extra <= 4 and w.shape[0] > 64:
+                # 67 = 64 + 3 (131 = 128 + 3): the three columns beyond the groups on the vector ALUs (csrc/conv_few.hip: 1,809 FMAs
+                # per pixel from an LDS tile) — as a 32-column HALF pass they cost a whole second input transform of the full-resolution
+                # buffer (0.38 ms per frame at config B)
+                full = w.shape[0] - extra
+                few = wp[full:full + extra].reshape(extra, cin_p // 16, 16, 9).permute(1, 3, 0, 2).contiguous()    # [block][tap][co][16]
+                return (ops.conv_wino_pack(wp[:full].contiguous()), bp[:full].contiguous(), full, full,
+                        ("few", few, bp[full:full + extra].contiguous(), extra, full))
             if 0 < extra <= 32 and w.shape[0] > 64:
                 # a few columns beyond a multiple of 64 (67 = 64 + 3, 131 = 128 + 3): the whole groups in one launch, the rest as a
                 # 32-column slice on the kernel's HALF form (its stream: the 64-column one with the upper half zero) instead of a
@@ -917,7 +925,10 @@ class DPVUpsampleNet(_PackedWeightsMixin, nn.Module):
             out = ops.conv_wino_rnet(x, wt[0], wt[2], bias=wt[1], lrelu=lrelu, out=out, cout_valid=wt[3])
             if len(wt) > 4:
                 t = wt[4]
-                ops.conv_wino_rnet(x, t[0], t[2], bias=t[1], lrelu=lrelu, out=out, ycoff=t[4], cout_valid=t[3])
+                if t[0] == "few":
+                    ops.conv2d_few(x, t[1], bias=t[2], lrelu=lrelu, out=out, ycoff=t[4])
+                else:
+                    ops.conv_wino_rnet(x, t[0], t[2], bias=t[1], lrelu=lrelu, out=out, ycoff=t[4], cout_valid=t[3])
             return out
 
         # level 1/4: cat(exp(dpv), feat) -> conv0 -> conv0_1

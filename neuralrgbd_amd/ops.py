@@ -744,6 +744,27 @@ def conv_wino_rnet(x, w_wino, cout, bias=None, lrelu=True, out=None, ycoff=0, co
     return out
 
 
+def conv2d_few(x, w_few, bias=None, lrelu=True, out=None, ycoff=0):
+    """3x3 convolution with 1-4 output channels on the vector ALUs (nrgbd_conv2d_few_f32): x [N,H,W,ldx] channels-last, w_few
+    [Cin/16, 9, Cout, 16] (= w [Cout, Cin, 3, 3] with ci -> (block, lane) and (ky, kx) -> tap; Cin % 16 == 0 <= ldx) ->
+    out[..., ycoff:ycoff+Cout] of a contiguous [N,H,W,ldy] buffer (allocated [N,H,W,Cout] if None)."""
+    x = _need(x, "x")
+    w_few = _need(w_few, "w_few")
+    N, H, W, ldx = x.shape
+    nblk, taps, cout, lanes = w_few.shape
+    if taps != 9 or lanes != 16 or not 1 <= cout <= 4 or nblk * 16 > ldx:
+        raise ValueError("conv2d_few: w_few %s for an input of %d channels" % (tuple(w_few.shape), ldx))
+    if out is None:
+        out = torch.empty((N, H, W, cout), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape[:3]) != (N, H, W) or not out.is_contiguous() or out.shape[3] < ycoff + cout:
+        raise ValueError("conv2d_few: out must be a contiguous [N,H,W,>= ycoff + Cout] tensor")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().nrgbd_conv2d_few_f32(_p(x), int(ldx), _p(w_few), _p(bias), int(bool(lrelu)), _p(out), int(out.shape[3]), int(ycoff),
+                                               N, H, W, nblk * 16, cout, _stream(x))
+    _lib.check(rc, "nrgbd_conv2d_few_f32")
+    return out
+
+
 def bn_cl_supported(rows, C):
     """Shapes of the channels-last train-mode BatchNorm kernels (bn_train.hip): 16-byte channel quads that tile a 256-lane workgroup."""
     return rows > 0 and 4 <= C <= 1024 and C % 4 == 0 and 256 % (C // 4) == 0

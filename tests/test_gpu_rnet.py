@@ -164,3 +164,29 @@ def test_bias_leaky_relu_fused_forward_and_backward(N, C, H, W, slope):
     assert (y.double() - yd).abs().max().item() < 1e-6
     assert (gx.double() - gxd).abs().max().item() < 1e-6
     assert (gb.double() - gbd).abs().max().item() < 2e-5 * max(1.0, gbd.abs().max().item())
+
+
+@pytest.mark.parametrize("N,H,W,Cin,ldx,Cout", [(2, 37, 53, 67, 80, 3), (1, 16, 16, 16, 16, 1), (1, 40, 24, 131, 144, 3), (1, 21, 19, 32, 48, 4)])
+def test_conv_with_a_few_output_channels_on_the_vector_alus(N, H, W, Cin, ldx, Cout):
+    """csrc/conv_few.hip (the 3 columns beyond the 64-column groups of the R-Net's 67- / 131-wide layer conv2) against F.conv2d in
+    float64: ragged tiles, a pixel stride wider than the channels read, output into a column window of a wider buffer."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + Cin)
+    x = torch.randn(N, H, W, ldx, generator=g)
+    cin_p = (Cin + 15) // 16 * 16
+    x[..., Cin:] = 0.0
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    wp = torch.zeros(Cout, cin_p, 3, 3)
+    wp[:, :Cin] = w
+    few = wp.reshape(Cout, cin_p // 16, 16, 9).permute(1, 3, 0, 2).contiguous().to(DEV)
+    out = torch.full((N, H, W, 64 + 16), 5.0, device=DEV)
+    ops.conv2d_few(x.to(DEV), few, bias=b.to(DEV), lrelu=True, out=out, ycoff=64)
+    want = F.leaky_relu(F.conv2d(x[..., :Cin].permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1), 0.01).permute(0, 2, 3, 1)
+    err = (out[..., 64:64 + Cout].double().cpu() - want).abs().max().item()
+    print("[parity] conv_few %dx%dx%d %d->%d max|d|=%.2e (|y|max %.1f)" % (N, H, W, Cin, Cout, err, want.abs().max().item()))
+    assert err < 1e-5 * max(1.0, want.abs().max().item())
+    assert bool((out[..., :64] == 5.0).all()) and bool((out[..., 64 + Cout:] == 5.0).all())
+    plain = ops.conv2d_few(x.to(DEV), few, bias=None, lrelu=False)
+    want2 = F.conv2d(x[..., :Cin].permute(0, 3, 1, 2).double(), w.double(), None, padding=1).permute(0, 2, 3, 1)
+    assert (plain.double().cpu() - want2).abs().max().item() < 1e-5 * max(1.0, want2.abs().max().item())
