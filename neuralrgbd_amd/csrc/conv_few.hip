@@ -8,8 +8,9 @@
 //
 //   workgroup = 16 x 16 output pixels (256 threads, one pixel each) of one image, all CO <= 4 output channels;
 //   input     = channel blocks of 16 of the 18 x 18 halo in LDS as [pixel][20 floats] (pitch 20: eight consecutive pixels' 16-byte
-//               words fall on eight different bank quads), double-buffered: block c + 1 is fetched into registers while block c is
-//               multiplied, published after it;
+//               words fall on eight different bank quads): ONE 26 KB buffer — six workgroups per CU hide the scalar-load and LDS
+//               latencies of each other (a second buffer halves the occupancy: 0.185 vs 0.13 ms at config B); block c + 1 is
+//               fetched into registers while block c is multiplied and published between two barriers;
 //   weights   = [block][tap][co][16] floats: uniform per wave, so they arrive through the scalar cache (s_load_dwordx16) and enter
 //               the v_fmac_f32 as SGPR operands — no vector register, no LDS;
 //   summation = per output: bias first, then (channel block, tap, channel) ascending: one fp32 FMA chain.
@@ -32,8 +33,8 @@ struct ConvFewArgs {
 };
 
 template <int CO>
-__global__ __launch_bounds__(256, 3) void conv_few_kernel(const ConvFewArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[2][kFewHalo * kFewPitch];
+__global__ __launch_bounds__(256, 6) void conv_few_kernel(const ConvFewArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[1][kFewHalo * kFewPitch];
     const int tid = threadIdx.x, px = tid & 15, py = tid >> 4;
     const int tiles_x = (a.W + kFewT - 1) / kFewT, tiles_y = (a.H + kFewT - 1) / kFewT;
     int t = blockIdx.x;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, 3) void conv_few_kernel(const ConvFewArgs a) {
     for (int co = 0; co < CO; ++co) acc[co] = a.bias ? a.bias[co] : 0.f;
 
     for (int c = 0; c < nblk; ++c) {
-        const int buf = c & 1;
+        constexpr int buf = 0;
         if (c + 1 < nblk) {
 #pragma unroll
             for (int u = 0; u < kFewNPF; ++u) pre[u] = *reinterpret_cast<const f32x4*>(a.x + off[u] + (c + 1) * 16);
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(256, 3) void conv_few_kernel(const ConvFewArgs a) {
                 }
             }
         }
-        if (c + 1 < nblk) publish(buf ^ 1);      // the other buffer: its last readers passed the barrier of the previous iteration
+        __syncthreads();                          // every wave has read block c: the one buffer may take block c + 1
+        if (c + 1 < nblk) publish(0);
         __syncthreads();
     }
     const int gy = y0 + py, gx = x0 + px;
