@@ -439,6 +439,21 @@ int nrgbd_conv_wino_dw_f32(const float* x, const float* x_ss, int x_relu, const 
                            int N, int H, int W, int Cin, int Cout, void* stream);
 int nrgbd_conv_wino_dw_workgroups(int N, int H, int W, int Cout);
 /*
+ * nrgbd_conv_wino_dw4_* — the same 3x3x3 convolution (models/basic.py:71-94: the K-Net's ten 64 -> 64 layers) with F(4, 3) along the
+ * depth axis (interpolation points 0, +-1/2, +-3/2, inf) on top of the in-plane F(2x2, 3x3): 6 multiplies per output voxel instead of 8;
+ * N % 4 == 0 (quadruples of output slices), whole 8x16 tiles.  Numerically 1.24x as far from float64 as the direct convolution on the
+ * whole K-Net (oracle/wino_d4_eval.py; nrgbd_conv_wino_dw_f32: 0.92x).  Input forms: x as it is (x_ss NULL, x_relu 0), act(x * s + t),
+ * or — x_unit = 2^-k > 0, x_ss given, x_relu 1 — relu(x * s + t) as a clamped FMA with w_wino packed from 2^k * w (see
+ * nrgbd_conv_wino_dw_unit_f32).  `workspace`: nrgbd_conv_wino_dw4_workspace() bytes of device scratch, 16-byte aligned, private to the
+ * launch (one third of the depth fold's live values per workgroup goes through it: they do not fit the LDS).
+ *   w_wino: [Cout/64][stage = p * Cin/16 + cb][16 points][4 waves][64 lanes][4], phases p in execution order t = 1, 2, 3, 4, 0, 5
+ *   stats  [2*Cout][nrgbd_conv_wino_tiles(N,H,W,1)] column-major partials for nrgbd_bn_finalize_cm, or NULL
+ */
+int nrgbd_conv_wino_dw4_pack(const float* w, float* w_wino, int Cin, int Cout, void* stream);
+int nrgbd_conv_wino_dw4_workspace(int N, int H, int W, int Cout, size_t* bytes);
+int nrgbd_conv_wino_dw4_f32(const float* x, const float* x_ss, int x_relu, float x_unit, const float* w_wino, float* y, float* stats,
+                            void* workspace, size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
+/*
  * nrgbd_conv_wino_dw_unit_f32 — nrgbd_conv_wino_dw_f32's plain form for an input relu(x * scale + shift) (no residual, no
  * materialise) with the ReLU taken by the producers' FMA itself (its [0, 1] clamp) instead of one v_max_f32 per element:
  *   x_unit = 2^-k: the kernel multiplies (scale, shift) by it; the caller guarantees |x * scale + shift| < 2^k everywhere (for a

@@ -118,6 +118,20 @@ def _packed_wino_dw(owner, conv, mult=1.0):
     return hit[1]
 
 
+def _packed_wino_dw4(owner, conv, mult=1.0):
+    """Weight stream of csrc/wino_dw4.hip (F(4,3) along depth on top of the in-plane Winograd form), of mult * w."""
+    from . import ops
+    cache = owner.__dict__.setdefault("_wp_cache", {})
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device), "wino_dw4", float(mult))
+    hit = cache.get(("wino_dw4", id(conv)))
+    if hit is None or hit[0] != key:
+        wc = w.detach().contiguous()
+        hit = (key, ops.conv_wino_dw4_pack(wc if mult == 1.0 else wc * float(mult)))
+        cache[("wino_dw4", id(conv))] = hit
+    return hit[1]
+
+
 def _relu_unit(owner, bn, count):
     """x_unit = 2^-k of the clamped-FMA convolution forms for an input relu(bn(y)), bn with batch statistics over `count` values
     (ops.relu_unit); 0 when the bound does not apply (running statistics).  Cached per (affine parameters, count): reading
@@ -599,6 +613,7 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 
+    _depth_f43 = True           # the 64 -> 64 layers on csrc/wino_dw4.hip where D % 4 == 0 (False: wino_dw.hip, the A/B and the training path's form)
     _split_residual = True      # measured (tools/knet_ab.py, NO_SPLIT=1): K-Net 25.37 -> 24.67 ms at config B when introduced, 22.74 -> 22.40 after the shared strips; identical bits
 
     def forward_channels_last(self, vol, generation=None):
@@ -640,7 +655,19 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
                 x = ops.nhwc_act(x, x_ss, x_relu, res)
                 y, ss, _ = run(i, x, None, False)
                 return y, ss, x
-            if (generation is None and conv.in_channels in (16, 64) and conv.out_channels == 64
+            if (generation is None and self._depth_f43 and conv.in_channels == 64 and conv.out_channels == 64 and res is None
+                    and ops.conv_wino_dw4_supported(D, H, W, 64, 64)):
+                # the ten 64 -> 64 layers with F(4,3) along depth (csrc/wino_dw4.hip: 6 instead of 8 multiplies per output voxel).  Its two
+                # input forms are x as it is and relu(bn(x)); a layer that also has to KEEP its activated input (dres1.0) materialises it
+                # with one HBM-bound pass first, like the residual layers
+                if materialize:
+                    x = ops.nhwc_act(x, x_ss, x_relu)
+                    y, st = ops.conv_wino_dw4(x, _packed_wino_dw4(self, conv), 64, want_stats=need_stats(bn))
+                    return y, self._bn_scale_shift(bn, st, count, cm=True), x
+                y, st = ops.conv_wino_dw4(x, _packed_wino_dw4(self, conv, 1.0 / unit if unit else 1.0), 64, x_ss=x_ss, x_relu=x_relu,
+                                          want_stats=need_stats(bn), x_unit=unit)
+                mat, cm = None, True
+            elif (generation is None and conv.in_channels in (16, 64) and conv.out_channels == 64
                     and ops.conv_wino_dw_supported(D, H, W, conv.in_channels, 64)):
                 y, st, mat = ops.conv_wino_dw(x, _packed_wino_dw(self, conv, 1.0 / unit if unit else 1.0), 64, x_ss=x_ss, x_relu=x_relu,
                                               res=res, materialize=materialize, want_stats=need_stats(bn), x_unit=unit)

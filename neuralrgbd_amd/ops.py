@@ -498,6 +498,55 @@ def conv_wino_dw(x, w_wino, Cout, x_ss=None, x_relu=False, res=None, res_ss=None
     return y, stats, mat
 
 
+_dw4_scratch = {}
+
+
+def conv_wino_dw4_supported(N, H, W, Cin, Cout):
+    """Shapes nrgbd_conv_wino_dw4_f32 accepts: quadruples of depth slices, whole 8x16 tiles, 32-bit in-plane byte offsets."""
+    return N % 4 == 0 and N >= 4 and H % 8 == 0 and W % 16 == 0 and Cin % 16 == 0 and Cout % 64 == 0 and H * W * Cin < (1 << 30)
+
+
+def conv_wino_dw4_pack(w):
+    """w [Cout, Cin, 3, 3, 3] -> weight stream of nrgbd_conv_wino_dw4_f32 (F(2x2,3x3) in the plane x F(4,3) along depth, points
+    0, +-1/2, +-3/2, inf): U_t = sum_kd Gd[t][kd] (G g_kd G^T) in float64, rounded once, phases in execution order t = 1,2,3,4,0,5."""
+    w = _need(w, "w")
+    if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
+        raise ValueError("conv_wino_dw4_pack expects [Cout, Cin, 3, 3, 3], got %s" % (tuple(w.shape),))
+    Cout, Cin = w.shape[:2]
+    if Cout % 64 or Cin % 16:
+        raise ValueError("conv_wino_dw4_pack: Cout %% 64 and Cin %% 16 required, got Cout=%d Cin=%d" % (Cout, Cin))
+    wp = torch.empty(Cout * Cin * 6 * 16, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.load().nrgbd_conv_wino_dw4_pack(_p(w.detach().contiguous()), _p(wp), Cin, Cout, _stream(w))
+    _lib.check(rc, "nrgbd_conv_wino_dw4_pack")
+    return wp
+
+
+def conv_wino_dw4(x, w_wino, Cout, x_ss=None, x_relu=False, want_stats=True, x_unit=0.0):
+    """Channels-last 3x3x3 stride-1 convolution over x [D,H,W,Cin] with F(4,3) along depth on top of the in-plane F(2x2,3x3)
+    (wino_dw4.hip; D % 4 == 0): -> (y [D,H,W,Cout], stats [2*Cout, tiles] | None).  Input forms: x as it is (x_ss None, x_relu False),
+    act(x * s + t), or — x_unit = 2^-k > 0 — relu(x * s + t) as the clamped FMA with w_wino packed from 2^k * w."""
+    x = _need(x, "x")
+    N, H, W, Cin = x.shape
+    if w_wino.numel() != (Cout // 64) * (Cin // 16) * 6 * 16 * 1024:
+        raise ValueError("conv_wino_dw4: packed weights do not match Cin=%d Cout=%d" % (Cin, Cout))
+    y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2 * Cout, conv_wino_tiles(N, H, W, 1)), dtype=torch.float32, device=x.device) if want_stats else None
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(lib.nrgbd_conv_wino_dw4_workspace(N, H, W, Cout, ctypes.byref(nbytes)), "nrgbd_conv_wino_dw4_workspace")
+        key = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
+        ws = _dw4_scratch.get(key)      # one scratch per (device, stream): launches on a stream are ordered, the scratch is per-launch state
+        if ws is None or ws.numel() < nbytes.value:
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+            _dw4_scratch[key] = ws
+        rc = lib.nrgbd_conv_wino_dw4_f32(_p(x), _p(x_ss), int(x_relu), float(x_unit), _p(w_wino), _p(y), _p(stats), _p(ws),
+                                         ctypes.c_size_t(ws.numel()), N, H, W, Cin, Cout, _stream(x))
+    _lib.check(rc, "nrgbd_conv_wino_dw4_f32")
+    return y, stats
+
+
 def conv3d_wgrad(x, gy):
     """Weight gradient of the channels-last 3x3x3 convolution: x [D,H,W,Cin], gy [D,H,W,64] -> dW [64,Cin,3,3,3]."""
     x = _need(x, "x")

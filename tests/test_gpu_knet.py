@@ -440,3 +440,57 @@ def test_variance_collapse_is_loud_not_saturated():
     torch.cuda.synchronize()
     with pytest.raises(NrgbdError):
         st.step(r, s_, p_)                                                # ... and the following step sees it
+
+
+@pytest.mark.parametrize("D,H,W,Cin", [(4, 16, 32, 64), (8, 24, 48, 64), (40, 40, 80, 64), (64, 8, 16, 64), (8, 16, 32, 16), (4, 16, 32, 128)])
+def test_conv_wino_dw4_plain_vs_torch(D, H, W, Cin):
+    """csrc/wino_dw4.hip: F(2x2,3x3) in the plane + F(4,3) along depth (6 x Cin/16 stages per FOUR output slices; points 0, +-1/2,
+    +-3/2, inf) vs F.conv3d in float64: a single quadruple (both depth borders in one tile: the empty first and last input slices),
+    grids with more tiles than CUs, one stage per phase (Cin = 16), two output channel groups; statistics rows; wino_dw as the A/B."""
+    from neuralrgbd_amd import ops
+    g = torch.Generator().manual_seed(D * 1000 + H + Cin)
+    Cout = 128 if Cin == 128 else 64
+    x = torch.randn(Cin, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    want = F.conv3d(x[None].double(), w.double(), padding=1)[0]
+    assert ops.conv_wino_dw4_supported(D, H, W, Cin, Cout)
+    y, stats = ops.conv_wino_dw4(_cl(x), ops.conv_wino_dw4_pack(w), Cout)
+    err = (y.permute(3, 0, 1, 2).double() - want).abs()
+    scale = want.abs().max().item()
+    y2, _, _ = ops.conv_wino_dw(_cl(x), ops.conv_wino_dw_pack(w), Cout)
+    err2 = (y2.permute(3, 0, 1, 2).double() - want).abs()
+    print("[parity] conv_wino_dw4 %dx%dx%d Cin=%d: max|d vs fp64| %.3e mean %.3e  (wino_dw: %.3e / %.3e; |y|max %.2f)" %
+          (D, H, W, Cin, err.max().item(), err.mean().item(), err2.max().item(), err2.mean().item(), scale))
+    assert err.max().item() < 4e-5 * max(1.0, scale) and err.mean().item() < 3.0 * err2.mean().item() + 1e-9
+    assert stats.shape == (2 * Cout, ops.conv_wino_tiles(D, H, W))
+    s = stats.double().sum(1)
+    assert torch.allclose(s[:Cout], want.sum((1, 2, 3)), rtol=1e-5, atol=2e-3)
+    assert torch.allclose(s[Cout:], (want ** 2).sum((1, 2, 3)), rtol=1e-5, atol=2e-3)
+    y3, _ = ops.conv_wino_dw4(_cl(x), ops.conv_wino_dw4_pack(w), Cout)
+    assert torch.equal(y, y3)                                   # deterministic
+
+
+def test_conv_wino_dw4_input_forms_and_clamped_relu():
+    """The three input forms of wino_dw4.hip against wino_dw.hip's on the same operands (same activation arithmetic, only the depth
+    transform differs): act(x * s + t) with and without ReLU, and the clamped-FMA ReLU — bit-identical to its own plain form."""
+    from neuralrgbd_amd import ops
+    D, H, W, C = 8, 24, 48, 64
+    g = torch.Generator().manual_seed(33)
+    x = (torch.randn(D, H, W, C, generator=g) * 3.0).to(DEV)
+    w = (torch.randn(C, C, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    ss = torch.randn(C, 2, generator=g).to(DEV)
+    wp4, wp2 = ops.conv_wino_dw4_pack(w), ops.conv_wino_dw_pack(w)
+    for relu in (False, True):
+        y4, st4 = ops.conv_wino_dw4(x, wp4, C, x_ss=ss, x_relu=relu)
+        y2, st2, _ = ops.conv_wino_dw(x, wp2, C, x_ss=ss, x_relu=relu)
+        sc = y2.abs().max().item()
+        assert (y4 - y2).abs().max().item() < 3e-5 * max(1.0, sc), relu
+        assert torch.allclose(st4.double().sum(1), st2.double().sum(1), rtol=1e-4, atol=1e-2)
+    y0, st0 = ops.conv_wino_dw4(x, wp4, C, x_ss=ss, x_relu=True)
+    import math
+    act_max = torch.relu(x * ss[:, 0] + ss[:, 1]).max().item()
+    for k in (math.floor(math.log2(act_max)) + 1, 14):
+        y1, st1 = ops.conv_wino_dw4(x, ops.conv_wino_dw4_pack(w * 2.0 ** k), C, x_ss=ss, x_relu=True, x_unit=2.0 ** -k)
+        assert torch.equal(y0, y1) and torch.equal(st0, st1), k
+    with pytest.raises(Exception):
+        ops.conv_wino_dw4(x[:6], wp4, C)                                     # D % 4 != 0
