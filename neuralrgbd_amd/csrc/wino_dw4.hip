@@ -80,7 +80,10 @@ __device__ __forceinline__ D4Tile d4_decode(int t, const WinoPcArgs& a) {
 }
 
 // channel block of the i-th stage of phase position p: odd positions sweep the blocks backwards (see wino_dw.hip dw_cb)
-__device__ __forceinline__ int d4_cb(int p, int i, int ncb) { return (p & 1) ? ncb - 1 - i : i; }
+#ifndef NRGBD_D4_SERP
+#define NRGBD_D4_SERP 1   // 0: experimental A/B builds only (build.build_variant)
+#endif
+__device__ __forceinline__ int d4_cb(int p, int i, int ncb) { return (NRGBD_D4_SERP && (p & 1)) ? ncb - 1 - i : i; }
 
 struct WinoD4Args {
     WinoPcArgs b;       // x, x_ss, wp, y, stats, N, H, W, Cin, Cout, ntiles, rows, x_unit (res / mat / bias unused)
@@ -340,7 +343,11 @@ __global__ __launch_bounds__(512) void conv_wino_dw4_kernel(const WinoD4Args aa)
         // raw words of one unit = (slice z0 - 1 + j, channel block cb) -> registers; nx: of the NEXT tile
         auto issue = [&](bool nx, int j, int cb, Regs& r) __attribute__((always_inline)) {
             const int tz = (nx ? tn.z0 : tl.z0) - 1 + j;
+#ifdef NRGBD_D4_FAKEZ        // timing experiment only (results invalid): every unit reads slices 0..3 -> the input stays in the L2
+            const int z = __builtin_amdgcn_readfirstlane(tz & 3);
+#else
             const int z = __builtin_amdgcn_readfirstlane(min(max(tz, 0), a.N - 1));    // clamped: an outside slice is not used when published
+#endif
             const size_t base = ((size_t)z * plane + (size_t)(__builtin_amdgcn_readfirstlane(cb) * kCB)) * sizeof(float);
             const __amdgpu_buffer_rsrc_t xb = pc_rsrc(reinterpret_cast<const char*>(a.x) + base);
 #pragma unroll
@@ -449,9 +456,14 @@ __global__ __launch_bounds__(512) void conv_wino_dw4_kernel(const WinoD4Args aa)
                     f32x2 lo[kD4NPF], hi[kD4NPF];
                     activate(set0);
                     {
-                        const f32x2 c0 = {c[0], c[0]};
+                        // the first slot's coefficient is 1 (every row of Bd has one) unless its slice is outside the volume (then 0)
+                        if (c[0] != 0.f) {
 #pragma unroll
-                        for (int i = 0; i < kD4NPF; ++i) { lo[i] = set0.pre[i].lo * c0; hi[i] = set0.pre[i].hi * c0; }
+                            for (int i = 0; i < kD4NPF; ++i) { lo[i] = set0.pre[i].lo; hi[i] = set0.pre[i].hi; }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < kD4NPF; ++i) { lo[i] = f32x2{0.f, 0.f}; hi[i] = f32x2{0.f, 0.f}; }
+                        }
                     }
                     issue(nx && has_next, d4_j(tnx, 0), cbne, set0);
                     activate(set1);

@@ -613,6 +613,7 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         sc = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
         return torch.stack((sc, bn.bias.detach() - bn.running_mean * sc), dim=1).contiguous()
 
+    _depth_f43_cin = (16, 64)   # input widths that take the F(4,3) form (the 16 -> 64 first layer: 0.62 -> 0.54 ms at config B)
     _depth_f43 = True           # the 64 -> 64 layers on csrc/wino_dw4.hip where D % 4 == 0 (False: wino_dw.hip, the A/B and the training path's form)
     _split_residual = True      # measured (tools/knet_ab.py, NO_SPLIT=1): K-Net 25.37 -> 24.67 ms at config B when introduced, 22.74 -> 22.40 after the shared strips; identical bits
 
@@ -655,8 +656,8 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
                 x = ops.nhwc_act(x, x_ss, x_relu, res)
                 y, ss, _ = run(i, x, None, False)
                 return y, ss, x
-            if (generation is None and self._depth_f43 and conv.in_channels == 64 and conv.out_channels == 64 and res is None
-                    and ops.conv_wino_dw4_supported(D, H, W, 64, 64)):
+            if (generation is None and self._depth_f43 and conv.in_channels in self._depth_f43_cin and conv.out_channels == 64 and res is None
+                    and ops.conv_wino_dw4_supported(D, H, W, conv.in_channels, 64)):
                 # the ten 64 -> 64 layers with F(4,3) along depth (csrc/wino_dw4.hip: 6 instead of 8 multiplies per output voxel).  Its two
                 # input forms are x as it is and relu(bn(x)); a layer that also has to KEEP its activated input (dres1.0) materialises it
                 # with one HBM-bound pass first, like the residual layers

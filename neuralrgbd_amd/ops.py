@@ -498,9 +498,6 @@ def conv_wino_dw(x, w_wino, Cout, x_ss=None, x_relu=False, res=None, res_ss=None
     return y, stats, mat
 
 
-_dw4_scratch = {}
-
-
 def conv_wino_dw4_supported(N, H, W, Cin, Cout):
     """Shapes nrgbd_conv_wino_dw4_f32 accepts: quadruples of depth slices, whole 8x16 tiles, 32-bit in-plane byte offsets."""
     return N % 4 == 0 and N >= 4 and H % 8 == 0 and W % 16 == 0 and Cin % 16 == 0 and Cout % 64 == 0 and H * W * Cin < (1 << 30)
@@ -536,11 +533,9 @@ def conv_wino_dw4(x, w_wino, Cout, x_ss=None, x_relu=False, want_stats=True, x_u
     with torch.cuda.device(x.device):
         nbytes = ctypes.c_size_t(0)
         _lib.check(lib.nrgbd_conv_wino_dw4_workspace(N, H, W, Cout, ctypes.byref(nbytes)), "nrgbd_conv_wino_dw4_workspace")
-        key = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
-        ws = _dw4_scratch.get(key)      # one scratch per (device, stream): launches on a stream are ordered, the scratch is per-launch state
-        if ws is None or ws.numel() < nbytes.value:
-            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
-            _dw4_scratch[key] = ws
+        # per-launch scratch from the caching allocator (stream-aware: concurrent launches on other streams get other blocks; inside a
+        # hipGraph capture it lives in the graph's pool): 32 KB per workgroup, no kernel is launched for it
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
         rc = lib.nrgbd_conv_wino_dw4_f32(_p(x), _p(x_ss), int(x_relu), float(x_unit), _p(w_wino), _p(y), _p(stats), _p(ws),
                                          ctypes.c_size_t(ws.numel()), N, H, W, Cin, Cout, _stream(x))
     _lib.check(rc, "nrgbd_conv_wino_dw4_f32")

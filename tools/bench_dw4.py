@@ -4,7 +4,11 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neuralrgbd_amd import _lib
+if os.environ.get("NRGBD_EXP_LIB"):
+    _lib.LIB_PATH = os.environ["NRGBD_EXP_LIB"]
 from neuralrgbd_amd import ops
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "B"

@@ -9,6 +9,10 @@ if os.environ.get("NRGBD_EXP_LIB"):
 from neuralrgbd_amd import nets
 if os.environ.get("NO_SPLIT"):          # A/B: the residual layers fused (wino_dw RES variants) instead of nhwc_act + the IDENT form
     nets.KalmanGainNet._split_residual = False
+if os.environ.get("NO_D4"):             # A/B: wino_dw.hip (F(2,3) along depth) for the 64 -> 64 layers instead of wino_dw4.hip
+    nets.KalmanGainNet._depth_f43 = False
+if os.environ.get("D4_L0"):             # A/B: the 16 -> 64 first layer on wino_dw4.hip too
+    nets.KalmanGainNet._depth_f43_cin = (16, 64)
 if os.environ.get("NO_CLAMP"):            # A/B of the clamped-FMA ReLU form: the plain form everywhere
     nets._relu_unit = lambda owner, bn, count: 0.0
 torch.manual_seed(0)
