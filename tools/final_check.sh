@@ -17,13 +17,14 @@ for c in B S K; do
   cp $(find $O/prof_$c -name "*kernel_stats.csv" | head -1) $O/bench_${c}_kernel_stats.csv
   rm -rf $O/prof_$c
 done
+bash tools/r6_trace_frame.sh ${1:-r6final} > $O/trace_frame.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_T -- python bench.py --mode train --accum 1 --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $O/prof_T.log 2>&1
 cp $(find $O/prof_T -name "*kernel_stats.csv" | head -1) $O/bench_train_kernel_stats.csv; rm -rf $O/prof_T
 if [ -z "$SKIP_PMC" ]; then   # SKIP_PMC=1: the committed PMC files stay valid while the sampling / Winograd kernel sources are unchanged
 bash tools/pmc_traffic.sh ${1:-r6final}/traffic B S K H > /dev/null 2>&1
 cp $O/traffic/costvol_traffic.json $O/costvol_traffic.json; rm -rf $O/traffic/*/fetch $O/traffic/*/write
-bash tools/pmc_wino.sh ${1:-r6final}/pmc_wino B wino-dw > /dev/null 2>&1
-cp $O/pmc_wino/summary.txt $O/pmc_wino_summary.txt; rm -rf $O/pmc_wino/pmc?
+bash tools/pmc_dw4.sh ${1:-r6final}/pmc_wino B > /dev/null 2>&1
+cp $O/pmc_wino/summary.txt $O/pmc_wino_summary.txt
 fi
 cat $O/pytest.txt $O/smoke.txt | tail -8
 cut -c1-420 $O/bench_B.json

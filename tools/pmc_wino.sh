@@ -10,5 +10,5 @@ rocprofv3 --pmc SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LD
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -o p -- $CMD > $OUT/pmc3.log 2>&1 || true
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -o p -- $CMD > $OUT/pmc4.log 2>&1 || true
 cd $R
-for k in "conv_wino_pc_kernel<3, 1, false" "conv_wino_pc_kernel<3, 1, true" "conv_wino_dw_kernel<false, false, false, false, false>" "conv_wino_dw_kernel<false, false, false, true, false>" "conv_wino_dw_kernel<true, true, false"; do python tools/pmc_summary.py $OUT "$k"; done > $OUT/summary.txt 2>&1
+for k in "conv_wino_dw_kernel<false, false, false, false, false>" "conv_wino_dw_kernel<false, false, false, true, false>" "conv_wino_dw_kernel<true, true, false"; do python tools/pmc_summary.py $OUT "$k"; done > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
