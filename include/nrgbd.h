@@ -448,8 +448,10 @@ int nrgbd_conv_wino_dw_workgroups(int N, int H, int W, int Cout);
  * launch (one third of the depth fold's live values per workgroup goes through it: they do not fit the LDS).
  *   w_wino: [Cout/64][stage = p * Cin/16 + cb][16 points][4 waves][64 lanes][4], phases p in execution order t = 1, 2, 3, 4, 0, 5
  *   stats  [2*Cout][nrgbd_conv_wino_tiles(N,H,W,1)] column-major partials for nrgbd_bn_finalize_cm, or NULL
+ *   pack: transposed = 1 packs the data-gradient stream (w read as [Cin][Cout][3][3][3], taps flipped), 2 both streams in one launch
+ *         (forward, then data gradient; Cin % 64 == 0) — as nrgbd_conv_wino_dw_pack
  */
-int nrgbd_conv_wino_dw4_pack(const float* w, float* w_wino, int Cin, int Cout, void* stream);
+int nrgbd_conv_wino_dw4_pack(const float* w, float* w_wino, int Cin, int Cout, int transposed, void* stream);
 int nrgbd_conv_wino_dw4_workspace(int N, int H, int W, int Cout, size_t* bytes);
 int nrgbd_conv_wino_dw4_f32(const float* x, const float* x_ss, int x_relu, float x_unit, const float* w_wino, float* y, float* stats,
                             void* workspace, size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, void* stream);

@@ -58,7 +58,7 @@ SIGNATURES = {
     "nrgbd_conv_wino_dw_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_dw_workgroups": (_I, [_I, _I, _I, _I]),
     "nrgbd_conv_wino_dw_unit_f32": (_I, [_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "nrgbd_conv_wino_dw4_pack": (_I, [_P, _P, _I, _I, _P]),
+    "nrgbd_conv_wino_dw4_pack": (_I, [_P, _P, _I, _I, _I, _P]),
     "nrgbd_conv_wino_dw4_workspace": (_I, [_I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_dw4_f32": (_I, [_P, _P, _I, _F, _P, _P, _P, _P, _c.c_size_t, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv3d_wgrad_workgroups": (_I, []),

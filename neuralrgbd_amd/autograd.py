@@ -71,12 +71,25 @@ class Conv3dCL(torch.autograd.Function):
     x [D,H,W,Cin] (Cin in {16, 64}), w [64,Cin,3,3,3] -> y [D,H,W,64].
     """
 
+    depth_f43 = True     # the 64 -> 64 layers (both directions) on wino_dw4.hip where D % 4 == 0; False: wino_dw.hip (A/B)
+
+    @staticmethod
+    def _depth_kind(x):
+        """4: wino_dw4.hip takes the grid, 2: wino_dw.hip does, 0: neither (wino_pc.hip / conv3d.hip)."""
+        D, H, W = x.shape[0], x.shape[1], x.shape[2]
+        if Conv3dCL.depth_f43 and ops.conv_wino_dw4_supported(D, H, W, 64, 64):
+            return 4
+        return 2 if ops.conv_wino_dw_supported(D, H, W, 64, 64) else 0
+
     @staticmethod
     def _conv(x, w, transposed=False, packed=None):
         """y = conv(x, w) (transposed: with w's data-gradient weights): the Winograd-domain kernels (wino_dw.hip / wino_pc.hip) for
         the 64 -> 64 layers, the direct kernel otherwise.  packed: the weight stream of this call if the caller already has it."""
         if w.shape[0] == 64 and w.shape[1] == 64:
-            if ops.conv_wino_dw_supported(x.shape[0], x.shape[1], x.shape[2], 64, 64):   # Winograd along depth too (wino_dw.hip)
+            kind = Conv3dCL._depth_kind(x)
+            if kind == 4:                                                                # F(4,3) along depth (wino_dw4.hip)
+                return ops.conv_wino_dw4(x, ops.conv_wino_dw4_pack(w, transposed) if packed is None else packed, 64, want_stats=False)[0]
+            if kind == 2:                                                                # F(2,3) along depth (wino_dw.hip)
                 return ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w, transposed) if packed is None else packed, 64, want_stats=False)[0]
             return ops.conv_wino(x, ops.conv_wino_pack(w, transposed) if packed is None else packed, 64, 3, want_stats=False)[0]
         if transposed:
@@ -84,13 +97,18 @@ class Conv3dCL(torch.autograd.Function):
             wt = w.transpose(0, 1).flip(2, 3, 4)                      # [Cin, 64, 3,3,3]: correlation with the flipped kernel
             if cin < 64:                                              # the kernels produce 64 outputs: pad, then slice
                 wt = torch.cat((wt, wt.new_zeros(64 - cin, 64, 3, 3, 3)), dim=0)
-            if ops.conv_wino_dw_supported(x.shape[0], x.shape[1], x.shape[2], 64, 64):
+            kind = Conv3dCL._depth_kind(x)
+            if kind == 4:
+                gx = ops.conv_wino_dw4(x, ops.conv_wino_dw4_pack(wt.contiguous()), 64, want_stats=False)[0]
+            elif kind == 2:
                 # data gradient of the first layer (16 -> 64): a 64 -> 64(16 real) layer in the Winograd domain, 0.31 instead of
                 # 0.64 ms on the direct kernel at the training grid
                 gx = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(wt.contiguous()), 64, want_stats=False)[0]
             else:
                 gx = ops.conv3d(x, ops.conv3d_pack_weights(wt.contiguous()), want_stats=False)[0]
             return gx[..., :cin].contiguous() if cin < 64 else gx
+        if w.shape[0] == 64 and w.shape[1] == 16 and Conv3dCL._depth_kind(x) == 4:      # the first layer's forward: one channel block
+            return ops.conv_wino_dw4(x, ops.conv_wino_dw4_pack(w), 64, want_stats=False)[0]
         return ops.conv3d(x, ops.conv3d_pack_weights(w.contiguous()), want_stats=False)[0]
 
     @staticmethod
@@ -99,7 +117,7 @@ class Conv3dCL(torch.autograd.Function):
         fwd = bwd = None
         if w.shape[0] == 64 and w.shape[1] == 64 and ctx.needs_input_grad[0]:
             # both weight streams (forward + data gradient) in one launch: the weights changed since the last iteration anyway
-            fwd, bwd = ops.conv_wino_pack_both(w, dw=ops.conv_wino_dw_supported(x.shape[0], x.shape[1], x.shape[2], 64, 64))
+            fwd, bwd = ops.conv_wino_pack_both(w, dw=Conv3dCL._depth_kind(x))
         y = Conv3dCL._conv(x, w, packed=fwd)
         ctx.save_for_backward(x, w, bwd)
         return y

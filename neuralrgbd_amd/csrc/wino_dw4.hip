@@ -518,8 +518,15 @@ __global__ __launch_bounds__(512) void conv_wino_dw4_kernel(const WinoD4Args aa)
 
 // w [Cout][Cin][3][3][3] -> U_t = sum_kd Gd[t][kd] (G g_kd G^T) (float64, rounded once) in the kernel's B-operand order, phases in
 // EXECUTION order: [cg][stage = p*ncb + cb][xi][wave][lane = kq*16 + j][e], t = d4_t(p), co = cg*64 + 16*wave + j, ci = cb*16 + 4*kq + e
-__global__ __launch_bounds__(256) void conv_wino_dw4_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout) {
+// transposed = 1: the data-gradient stream (w is stored [Cin][Cout][3][3][3] seen from this kernel: its ci is the stored tensor's output
+// channel; taps flipped in every dimension); 2: both streams in one launch (grid.y = 2), the data gradient's behind the forward one.
+__global__ __launch_bounds__(256) void conv_wino_dw4_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
+                                                                 int transposed) {
     const long total = (long)Cout * Cin * 6 * 16;
+    if (transposed == 2) {
+        transposed = blockIdx.y;
+        if (transposed) { const int c = Cin; Cin = Cout; Cout = c; wp += total; }
+    }
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     long t = idx;
@@ -540,12 +547,12 @@ __global__ __launch_bounds__(256) void conv_wino_dw4_pack_kernel(const float* __
     double u = 0.0;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
-        const float* g = w + (((size_t)co * Cin + ci) * 3 + kd) * 9;
+        const float* g = transposed ? w + (((size_t)ci * Cout + co) * 3 + (2 - kd)) * 9 : w + (((size_t)co * Cin + ci) * 3 + kd) * 9;
         double u2 = 0.0;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) u2 += G[aa][ky] * (double)g[ky * 3 + kx] * G[bb][kx];
+            for (int kx = 0; kx < 3; ++kx) u2 += G[aa][ky] * (double)g[transposed ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx] * G[bb][kx];
         u += Gd[td][kd] * u2;
     }
     wp[idx] = (float)u;
@@ -553,12 +560,15 @@ __global__ __launch_bounds__(256) void conv_wino_dw4_pack_kernel(const float* __
 
 }  // namespace nrgbd
 
-extern "C" int nrgbd_conv_wino_dw4_pack(const float* w, float* w_wino, int Cin, int Cout, void* stream) {
+extern "C" int nrgbd_conv_wino_dw4_pack(const float* w, float* w_wino, int Cin, int Cout, int transposed, void* stream) {
     using namespace nrgbd;
     if (!w || !w_wino) return NRGBD_E_NULL;
     if (Cin <= 0 || Cin % kCB || Cout <= 0 || Cout % 64) return NRGBD_E_SHAPE;
+    if (transposed < 0 || transposed > 2) return NRGBD_E_ARG;
+    if (transposed == 2 && Cin % 64) return NRGBD_E_SHAPE;
     const long total = (long)Cout * Cin * 6 * 16;
-    hipLaunchKernelGGL(conv_wino_dw4_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_wino, Cin, Cout);
+    hipLaunchKernelGGL(conv_wino_dw4_pack_kernel, dim3((unsigned)((total + 255) / 256), transposed == 2 ? 2 : 1), dim3(256), 0,
+                       (hipStream_t)stream, w, w_wino, Cin, Cout, transposed);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }

@@ -652,8 +652,10 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
                 # the residual layers as TWO launches: in = bn(x) + res materialised by one HBM-bound pass (nrgbd_nhwc_act), then the
                 # plain form of the convolution on it.  In the fused form the producers of wino_dw.hip load and add the second
                 # operand 2-3 times per tile pair — 10 more vector-memory instructions and ~100 more VALU per stage on SIMDs whose
-                # issue slots are what bounds the kernel (profiles/r4_wino_design_probe.txt)
-                x = ops.nhwc_act(x, x_ss, x_relu, res)
+                # issue slots are what bounds the kernel (profiles/r4_wino_design_probe.txt).  res may be a (tensor, scale/shift, relu)
+                # triple: c0 = relu(bn(z1)) is never written on its own (lazy_c0 below), the pass applies it while it adds
+                r, r_ss, r_relu = res if isinstance(res, tuple) else (res, None, False)
+                x = ops.nhwc_act(x, x_ss, x_relu, r, r_ss, r_relu)
                 y, ss, _ = run(i, x, None, False)
                 return y, ss, x
             if (generation is None and self._depth_f43 and conv.in_channels in self._depth_f43_cin and conv.out_channels == 64 and res is None
@@ -686,7 +688,17 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
 
         z, ss, _ = run(0, vol, None, False)                       # dres0.0
         z, ss, _ = run(1, z, ss, True)                            # dres0.2   in = relu(bn(z))
-        z, ss, skip = run(2, z, ss, True, materialize=True)       # dres1.0   in = c0 (kept as the residual)
+        # dres1.0: in = c0 = relu(bn(z)), which is also the first residual.  Where the layer has a clamped-FMA form that costs what the
+        # plain one costs (wino_dw4.hip, wino_dw.hip) c0 is not materialised: the layer reads the raw tensor with its (scale, shift), and
+        # the first residual pass (dres2.0's input) applies the same FMA + max to it while it adds — the same roundings, one 1.6 GB pass
+        # (0.25 ms at config B) less
+        lazy_c0 = (generation is None and self._split_residual and L[2][0].in_channels == 64 and L[2][0].out_channels == 64
+                   and (ops.conv_wino_dw4_supported(D, H, W, 64, 64) if self._depth_f43 else ops.conv_wino_dw_supported(D, H, W, 64, 64)))
+        if lazy_c0:
+            skip = (z, ss, True)
+            z, ss, _ = run(2, z, ss, True)
+        else:
+            z, ss, skip = run(2, z, ss, True, materialize=True)   # dres1.0   in = c0 (kept as the residual)
         z, ss, _ = run(3, z, ss, True)                            # dres1.2
         for i in (4, 6, 8):                                       # dres2.0, dres3.0, dres4.0: in = bn(z) + c_{i-1}
             z, ss, skip = run(i, z, ss, False, res=skip, materialize=True)

@@ -357,8 +357,8 @@ def conv_wino_pack(w, transposed=False):
 
 def conv_wino_pack_both(w, dw=False):
     """(forward stream, data-gradient stream) of a layer's weight in ONE launch (training re-packs both every iteration).
-    dw: the streams of wino_dw.hip (Winograd along depth too) instead of wino_pc.hip's."""
-    both = (conv_wino_dw_pack if dw else conv_wino_pack)(w, transposed=2)
+    dw: the streams of wino_dw.hip (Winograd along depth too; dw = 4: wino_dw4.hip, F(4,3) along depth) instead of wino_pc.hip's."""
+    both = (conv_wino_dw4_pack if dw == 4 else conv_wino_dw_pack if dw else conv_wino_pack)(w, transposed=2)
     n = both.numel() // 2
     return both[:n], both[n:]
 
@@ -503,18 +503,19 @@ def conv_wino_dw4_supported(N, H, W, Cin, Cout):
     return N % 4 == 0 and N >= 4 and H % 8 == 0 and W % 16 == 0 and Cin % 16 == 0 and Cout % 64 == 0 and H * W * Cin < (1 << 30)
 
 
-def conv_wino_dw4_pack(w):
+def conv_wino_dw4_pack(w, transposed=False):
     """w [Cout, Cin, 3, 3, 3] -> weight stream of nrgbd_conv_wino_dw4_f32 (F(2x2,3x3) in the plane x F(4,3) along depth, points
-    0, +-1/2, +-3/2, inf): U_t = sum_kd Gd[t][kd] (G g_kd G^T) in float64, rounded once, phases in execution order t = 1,2,3,4,0,5."""
+    0, +-1/2, +-3/2, inf): U_t = sum_kd Gd[t][kd] (G g_kd G^T) in float64, rounded once, phases in execution order t = 1,2,3,4,0,5.
+    transposed: True = the data-gradient stream (transposed + flipped weights), 2 = both streams (forward, then data gradient)."""
     w = _need(w, "w")
     if w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3):
         raise ValueError("conv_wino_dw4_pack expects [Cout, Cin, 3, 3, 3], got %s" % (tuple(w.shape),))
-    Cout, Cin = w.shape[:2]
-    if Cout % 64 or Cin % 16:
+    Cout, Cin = (w.shape[1], w.shape[0]) if transposed is True or transposed == 1 else w.shape[:2]
+    if Cout % 64 or Cin % 16 or (transposed == 2 and Cin % 64):
         raise ValueError("conv_wino_dw4_pack: Cout %% 64 and Cin %% 16 required, got Cout=%d Cin=%d" % (Cout, Cin))
-    wp = torch.empty(Cout * Cin * 6 * 16, dtype=torch.float32, device=w.device)
+    wp = torch.empty(Cout * Cin * 6 * 16 * (2 if transposed == 2 else 1), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
-        rc = _lib.load().nrgbd_conv_wino_dw4_pack(_p(w.detach().contiguous()), _p(wp), Cin, Cout, _stream(w))
+        rc = _lib.load().nrgbd_conv_wino_dw4_pack(_p(w.detach().contiguous()), _p(wp), Cin, Cout, int(transposed), _stream(w))
     _lib.check(rc, "nrgbd_conv_wino_dw4_pack")
     return wp
 

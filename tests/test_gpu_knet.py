@@ -335,6 +335,10 @@ def test_both_weight_streams_in_one_launch(shape):
     if w.dim() == 5:
         f, b = ops.conv_wino_pack_both(w, dw=True)
         assert torch.equal(f, ops.conv_wino_dw_pack(w)) and torch.equal(b, ops.conv_wino_dw_pack(w, True))
+        f, b = ops.conv_wino_pack_both(w, dw=4)
+        assert torch.equal(f, ops.conv_wino_dw4_pack(w)) and torch.equal(b, ops.conv_wino_dw4_pack(w, True))
+        # the data-gradient stream = the forward stream of the transposed + flipped weights
+        assert torch.equal(b, ops.conv_wino_dw4_pack(w.transpose(0, 1).flip(2, 3, 4).contiguous()))
     with pytest.raises(ValueError):
         ops.conv_wino_pack(torch.zeros(64, 32, 3, 3, device=DEV), transposed=2)      # 32 inputs cannot be a 64-column output group
 

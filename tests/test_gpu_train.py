@@ -117,9 +117,11 @@ def test_one_training_iteration_updates_weights_and_predicts():
     assert lo.shape == (1, H // 4, W // 4) and hi.shape == (1, H, W)
 
 
-@pytest.mark.parametrize("D,H,W,Cin", [(4, 8, 16, 64), (3, 9, 21, 16), (6, 12, 40, 64)])
+@pytest.mark.parametrize("D,H,W,Cin", [(4, 8, 16, 64), (3, 9, 21, 16), (6, 12, 40, 64), (8, 16, 32, 16), (8, 16, 48, 64), (6, 16, 32, 64)])
 def test_conv3d_backward_kernels_vs_torch_autograd(D, H, W, Cin):
-    """Data gradient (forward kernel on flipped/transposed weights) and weight gradient (conv3d_wgrad.hip)."""
+    """Data gradient (forward kernel on flipped/transposed weights) and weight gradient (conv3d_wgrad.hip); the grids cover every
+    kernel the 64 -> 64 layers can take (wino_dw4.hip: D % 4 == 0 and whole tiles; wino_dw.hip: even D; wino_pc.hip / conv3d.hip)
+    and the first layer's 16-channel forms."""
     from neuralrgbd_amd.autograd import Conv3dCL
     g = torch.Generator().manual_seed(D + W)
     x = torch.randn(Cin, D, H, W, generator=g).to(DEV)
