@@ -318,6 +318,18 @@ int nrgbd_conv3d_3x3x3_cout1_f32(const float* x, const float* x_ss, int x_relu,
                                  const float* w_tap_major, float* y,
                                  int D, int H, int W, int Cin, void* stream);
 /*
+ * nrgbd_conv3d_cout1_{dgrad,wgrad}_f32 — the two gradients of that last layer (training; what autograd computes for
+ * nn.Conv3d(64, 1, 3, padding 1) of models/basic.py:92-94 in train_utils/train_KVNet.py:103-171).  One output channel makes every
+ * direction a 27-tap stencil per voxel (memory bound); until interface 0.5 the layer ran zero-padded to 64 outputs on the 64 -> 64 kernels.
+ *   gy [D][H][W] (gradient of the layer's output), x / gx [D][H][W][64] channels-last, w_tap_major [27][64] as for the forward,
+ *   dw [64][27] = torch's [1][64][3][3][3] (overwritten); workspace: nrgbd_conv3d_cout1_wgrad_workspace() bytes, 16-byte aligned.
+ *   gx[v][ci] = sum_tap gy[v - off(tap)] w[ci][tap];  dw[ci][tap] = sum_v gy[v - off(tap)] x[v][ci];  fixed summation orders.
+ */
+int nrgbd_conv3d_cout1_dgrad_f32(const float* gy, const float* w_tap_major, float* gx, int D, int H, int W, void* stream);
+int nrgbd_conv3d_cout1_wgrad_workspace(int D, int H, int W, size_t* bytes);
+int nrgbd_conv3d_cout1_wgrad_f32(const float* x, const float* gy, float* dw, void* workspace, size_t workspace_bytes, int D, int H, int W,
+                                 void* stream);
+/*
  * nrgbd_conv3d_wgrad_f32 — weight gradient of the 3x3x3 convolution (training):
  *   dW[co][ci][kd][kh][kw] = sum_voxels gy[v][co] * x[v + tap][ci]      (x zero outside the volume)
  * Replaces what autograd/MIOpen compute for nn.Conv3d.weight.grad in models/basic.py:71-94.

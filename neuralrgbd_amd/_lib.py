@@ -48,6 +48,9 @@ SIGNATURES = {
     "nrgbd_conv3d_pack_weights": (_I, [_P, _P, _I, _P]),
     "nrgbd_conv3d_3x3x3_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv3d_3x3x3_cout1_f32": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "nrgbd_conv3d_cout1_dgrad_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "nrgbd_conv3d_cout1_wgrad_workspace": (_I, [_I, _I, _I, _P]),
+    "nrgbd_conv3d_cout1_wgrad_f32": (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _P]),
     "nrgbd_conv_wino_tiles": (_I, [_I, _I, _I, _I]),
     "nrgbd_conv_wino_rnet_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "nrgbd_conv_wino_rnet_ex_f32": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

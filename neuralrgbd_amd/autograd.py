@@ -63,6 +63,40 @@ class DepthWarp(torch.autograd.Function):
         return None, None, None, g_R, g_t, None
 
 
+# Packed weight streams of the training path, valid for ONE optimizer step.  train(..., accum_steps = A) and TrainGraph.step_windows run A
+# windows on the same weights: inside `with pack_cache():` the first window packs every layer's streams (forward + data gradient) and the
+# others read them (0.9 ms of packing launches per window at the training grid: VERDICT r5 item 6).  Keys are (id of the module's weight
+# parameter, what was packed); the scope ends before the optimizer changes the weights.
+_PACK_CACHE = None
+
+
+class pack_cache:
+    """Context manager: weight streams packed inside it are kept and reused until it exits.  `store`: an existing dict (TrainGraph
+    keeps the streams its first-window graph writes so that the graph of the later windows reads the same buffers)."""
+
+    def __init__(self, store=None):
+        self.store = {} if store is None else store
+
+    def __enter__(self):
+        global _PACK_CACHE
+        self.prev, _PACK_CACHE = _PACK_CACHE, self.store
+        return self.store
+
+    def __exit__(self, *exc):
+        global _PACK_CACHE
+        _PACK_CACHE = self.prev
+        return False
+
+
+def _cached(key, tag, fn):
+    if _PACK_CACHE is None or key is None:
+        return fn()
+    hit = _PACK_CACHE.get((key, tag))
+    if hit is None:
+        hit = _PACK_CACHE[(key, tag)] = fn()
+    return hit
+
+
 class Conv3dCL(torch.autograd.Function):
     """3x3x3 convolution (stride 1, padding 1, no bias, 64 outputs) on channels-last activations, both directions on
     the fp32 matrix cores: forward = csrc/wino_dw.hip / wino_pc.hip (64 -> 64 layers, Winograd domain) / csrc/conv3d.hip; data gradient = the
@@ -82,44 +116,58 @@ class Conv3dCL(torch.autograd.Function):
         return 2 if ops.conv_wino_dw_supported(D, H, W, 64, 64) else 0
 
     @staticmethod
-    def _conv(x, w, transposed=False, packed=None):
-        """y = conv(x, w) (transposed: with w's data-gradient weights): the Winograd-domain kernels (wino_dw.hip / wino_pc.hip) for
-        the 64 -> 64 layers, the direct kernel otherwise.  packed: the weight stream of this call if the caller already has it."""
+    def _conv(x, w, transposed=False, packed=None, key=None):
+        """y = conv(x, w) (transposed: with w's data-gradient weights): the Winograd-domain kernels (wino_dw4.hip / wino_dw.hip /
+        wino_pc.hip) for the 64 -> 64 layers, the direct kernel otherwise.  packed: the weight stream of this call if the caller
+        already has it; key: pack_cache key of the layer."""
+        tr = bool(transposed)
         if w.shape[0] == 64 and w.shape[1] == 64:
             kind = Conv3dCL._depth_kind(x)
             if kind == 4:                                                                # F(4,3) along depth (wino_dw4.hip)
-                return ops.conv_wino_dw4(x, ops.conv_wino_dw4_pack(w, transposed) if packed is None else packed, 64, want_stats=False)[0]
+                wp = packed if packed is not None else _cached(key, ("dw4", tr), lambda: ops.conv_wino_dw4_pack(w, transposed))
+                return ops.conv_wino_dw4(x, wp, 64, want_stats=False)[0]
             if kind == 2:                                                                # F(2,3) along depth (wino_dw.hip)
-                return ops.conv_wino_dw(x, ops.conv_wino_dw_pack(w, transposed) if packed is None else packed, 64, want_stats=False)[0]
-            return ops.conv_wino(x, ops.conv_wino_pack(w, transposed) if packed is None else packed, 64, 3, want_stats=False)[0]
+                wp = packed if packed is not None else _cached(key, ("dw", tr), lambda: ops.conv_wino_dw_pack(w, transposed))
+                return ops.conv_wino_dw(x, wp, 64, want_stats=False)[0]
+            wp = packed if packed is not None else _cached(key, ("pc3", tr), lambda: ops.conv_wino_pack(w, transposed))
+            return ops.conv_wino(x, wp, 64, 3, want_stats=False)[0]
         if transposed:
             cin = w.shape[1]
-            wt = w.transpose(0, 1).flip(2, 3, 4)                      # [Cin, 64, 3,3,3]: correlation with the flipped kernel
-            if cin < 64:                                              # the kernels produce 64 outputs: pad, then slice
-                wt = torch.cat((wt, wt.new_zeros(64 - cin, 64, 3, 3, 3)), dim=0)
+
+            def wt():
+                t = w.transpose(0, 1).flip(2, 3, 4)                   # [Cin, 64, 3,3,3]: correlation with the flipped kernel
+                if cin < 64:                                          # the kernels produce 64 outputs: pad, then slice
+                    t = torch.cat((t, t.new_zeros(64 - cin, 64, 3, 3, 3)), dim=0)
+                return t.contiguous()
             kind = Conv3dCL._depth_kind(x)
             if kind == 4:
-                gx = ops.conv_wino_dw4(x, ops.conv_wino_dw4_pack(wt.contiguous()), 64, want_stats=False)[0]
+                gx = ops.conv_wino_dw4(x, _cached(key, ("dw4t", cin), lambda: ops.conv_wino_dw4_pack(wt())), 64, want_stats=False)[0]
             elif kind == 2:
                 # data gradient of the first layer (16 -> 64): a 64 -> 64(16 real) layer in the Winograd domain, 0.31 instead of
                 # 0.64 ms on the direct kernel at the training grid
-                gx = ops.conv_wino_dw(x, ops.conv_wino_dw_pack(wt.contiguous()), 64, want_stats=False)[0]
+                gx = ops.conv_wino_dw(x, _cached(key, ("dwt", cin), lambda: ops.conv_wino_dw_pack(wt())), 64, want_stats=False)[0]
             else:
-                gx = ops.conv3d(x, ops.conv3d_pack_weights(wt.contiguous()), want_stats=False)[0]
+                gx = ops.conv3d(x, _cached(key, ("d3t", cin), lambda: ops.conv3d_pack_weights(wt())), want_stats=False)[0]
             return gx[..., :cin].contiguous() if cin < 64 else gx
         if w.shape[0] == 64 and w.shape[1] == 16 and Conv3dCL._depth_kind(x) == 4:      # the first layer's forward: one channel block
-            return ops.conv_wino_dw4(x, ops.conv_wino_dw4_pack(w), 64, want_stats=False)[0]
-        return ops.conv3d(x, ops.conv3d_pack_weights(w.contiguous()), want_stats=False)[0]
+            return ops.conv_wino_dw4(x, _cached(key, ("dw4", False), lambda: ops.conv_wino_dw4_pack(w)), 64, want_stats=False)[0]
+        return ops.conv3d(x, _cached(key, ("d3", False), lambda: ops.conv3d_pack_weights(w.contiguous())), want_stats=False)[0]
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, key=None, grad_channel=None):
+        """grad_channel = c: only input channel c carries a gradient (the K-Net's first layer: 15 of its 16 input channels are warped
+        images, KVNET.py:163-166) — the data gradient is then ONE output channel, a 27-tap stencil over gy on conv3d.hip's depth-marching
+        kernel instead of a 64 -> 64 Winograd launch of which 63 output channels would be discarded."""
         x = x.contiguous()
         fwd = bwd = None
+        ctx.grad_channel = grad_channel
         if w.shape[0] == 64 and w.shape[1] == 64 and ctx.needs_input_grad[0]:
             # both weight streams (forward + data gradient) in one launch: the weights changed since the last iteration anyway
-            fwd, bwd = ops.conv_wino_pack_both(w, dw=Conv3dCL._depth_kind(x))
-        y = Conv3dCL._conv(x, w, packed=fwd)
+            kind = Conv3dCL._depth_kind(x)
+            fwd, bwd = _cached(key, ("both3", kind), lambda: ops.conv_wino_pack_both(w, dw=kind))
+        y = Conv3dCL._conv(x, w, packed=fwd, key=key)
         ctx.save_for_backward(x, w, bwd)
+        ctx.key = key
         return y
 
     @staticmethod
@@ -130,8 +178,38 @@ class Conv3dCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = ops.conv3d_wgrad(x.contiguous(), gy)
         if ctx.needs_input_grad[0]:
-            gx = Conv3dCL._conv(gy, w, transposed=True, packed=bwd)
-        return gx, gw
+            c = ctx.grad_channel
+            if c is not None and w.shape[0] == 64:
+                # gx[v][c] = sum_co sum_tap gy[v - off(tap)][co] w[co][c][tap]: the 64 -> 1 kernel on gy with the taps mirrored
+                w_tm = _cached(ctx.key, ("c1t", c), lambda: w.detach()[:, c].reshape(64, 27).flip(1).t().contiguous())
+                gx = gy.new_zeros(gy.shape[:3] + (w.shape[1],))
+                gx[..., c] = ops.conv3d_cout1(gy, w_tm)
+            else:
+                gx = Conv3dCL._conv(gy, w, transposed=True, packed=bwd, key=ctx.key)
+        return gx, gw, None, None
+
+
+class Conv3dCout1CL(torch.autograd.Function):
+    """The K-Net's last layer Conv3d(64, 1, 3, padding 1, no bias; models/basic.py:92-94) on a channels-last activation, all three
+    directions as memory-bound 27-tap stencils: forward = csrc/conv3d.hip's depth-marching kernel, data and weight gradient =
+    csrc/conv3d_c1_bwd.hip (until round 6: the layer zero-padded to 64 outputs on three 64 -> 64 matrix-core launches).
+
+    x [D,H,W,64], w [1,64,3,3,3] -> y [D,H,W]."""
+
+    @staticmethod
+    def forward(ctx, x, w, key=None):
+        x = x.contiguous()
+        w_tm = _cached(key, ("c1", 0), lambda: w.detach()[0].reshape(64, 27).t().contiguous())    # [27, 64] tap-major
+        ctx.save_for_backward(x, w_tm)
+        return ops.conv3d_cout1(x, w_tm)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w_tm = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = ops.conv3d_cout1_dgrad(gy, w_tm) if ctx.needs_input_grad[0] else None
+        gw = ops.conv3d_cout1_wgrad(x, gy) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
 
 
 class BatchNormActCL(torch.autograd.Function):
@@ -265,28 +343,32 @@ class Conv2dCL(torch.autograd.Function):
         return fwd(cin, cout) and (fwd(cout, cin) or not need_dgrad) and cin % 16 == 0 and cout % 16 == 0
 
     @staticmethod
-    def _conv(x_cl, w, dil, transposed=False, packed=None):
+    def _conv(x_cl, w, dil, transposed=False, packed=None, key=None):
         cout, cin = (w.shape[1], w.shape[0]) if transposed else w.shape[:2]
+        tr = bool(transposed)
         if cin % 32 == 0 and cout % 64 == 0:
-            return ops.conv_wino(x_cl, ops.conv_wino_pack(w, transposed) if packed is None else packed, cout, 1, dil, want_stats=False)[0]
+            wp = packed if packed is not None else _cached(key, ("pc", tr), lambda: ops.conv_wino_pack(w, transposed))
+            return ops.conv_wino(x_cl, wp, cout, 1, dil, want_stats=False)[0]
         if cout == 32 and cin % 32 == 0 and dil == 1 and ops.conv_wino_supported(x_cl.shape[0], x_cl.shape[1], x_cl.shape[2], cin, 32, 1):
             # the HALF form of wino_pc.hip (the trunk's 32 -> 32 layers): its stream is the 64-column one, upper half zero
-            wp = ops.conv_wino_pack(torch.cat((w, torch.zeros_like(w)), 1 if transposed else 0), transposed)
+            wp = _cached(key, ("half", tr), lambda: ops.conv_wino_pack(torch.cat((w, torch.zeros_like(w)), 1 if transposed else 0), transposed))
             return ops.conv_wino(x_cl, wp, 32, 1, 1, want_stats=False)[0]
-        if transposed:
-            w = w.transpose(0, 1).flip(2, 3)                          # [Cin, Cout, 3, 3]: correlation with the flipped kernel
-        return ops.conv2d(x_cl, ops.conv_pack_weights(w.contiguous()), cout, dil, want_stats=False)[0]
+
+        def direct():
+            return ops.conv_pack_weights((w.transpose(0, 1).flip(2, 3) if transposed else w).contiguous())   # transposed: [Cin, Cout, 3, 3], flipped
+        return ops.conv2d(x_cl, _cached(key, ("direct", tr), direct), cout, dil, want_stats=False)[0]
 
     @staticmethod
-    def forward(ctx, x, w, dil):
+    def forward(ctx, x, w, dil, key=None):
         x_cl = x.permute(0, 2, 3, 1).contiguous()                 # free when x is channels_last
         cout, cin = w.shape[:2]
         fwd = bwd = None
         if cin % 64 == 0 and cout % 64 == 0 and ctx.needs_input_grad[0]:
-            fwd, bwd = ops.conv_wino_pack_both(w)                 # both directions run on wino_pc.hip: one packing launch for the two streams
-        y = Conv2dCL._conv(x_cl, w, dil, packed=fwd)
+            # both directions run on wino_pc.hip: one packing launch for the two streams
+            fwd, bwd = _cached(key, ("both", 0), lambda: ops.conv_wino_pack_both(w))
+        y = Conv2dCL._conv(x_cl, w, dil, packed=fwd, key=key)
         ctx.save_for_backward(x_cl, w, bwd)
-        ctx.dil = dil
+        ctx.dil, ctx.key = dil, key
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -297,8 +379,8 @@ class Conv2dCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = ops.conv2d_wgrad(x_cl, gy_cl, ctx.dil)
         if ctx.needs_input_grad[0]:
-            gx = Conv2dCL._conv(gy_cl, w, ctx.dil, transposed=True, packed=bwd).permute(0, 3, 1, 2)
-        return gx, gw, None
+            gx = Conv2dCL._conv(gy_cl, w, ctx.dil, transposed=True, packed=bwd, key=ctx.key).permute(0, 3, 1, 2)
+        return gx, gw, None, None
 
 
 def _padded_widths(cin, cout, dil, need_dgrad):
@@ -354,7 +436,7 @@ def _tap_select(kind, device):
     return hit
 
 
-def _conv3x3_cl(x, w, dil, bias, keep_width=False, act_slope=None):
+def _conv3x3_cl(x, w, dil, bias, keep_width=False, act_slope=None, key=None):
     """3x3 stride-1 convolution through Conv2dCL, the channel counts zero-padded to widths the kernels have (67 -> 96 for the
     R-Net's full-resolution layers, 12 -> 16 for the space-to-depth image).  None if no width fits.
     x may already carry MORE channels than w reads (the padded output of the previous layer: its extra channels are zero).
@@ -373,7 +455,7 @@ def _conv3x3_cl(x, w, dil, bias, keep_width=False, act_slope=None):
         w = F.pad(w, (0, 0, 0, 0, 0, ci - cin))
     if co != cout:
         w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, co - cout))
-    y = Conv2dCL.apply(x, w, dil)
+    y = Conv2dCL.apply(x, w, dil, key)
     # bias (+ LeakyReLU) on the full-width channels-last tensor (the padded channels stay exactly zero: zero weights, zero bias)
     y = _bias_act(y, None if bias is None else (bias if co == cout else F.pad(bias, (0, co - cout))), act_slope)
     if co != cout and not keep_width:
@@ -406,16 +488,16 @@ def conv2d_module(conv, x, _any_device=False, keep_width=False, act_slope=None):
         return module_forward()
     w, y = conv.weight, None
     if k == (3, 3) and st == (1, 1) and pd == d:
-        y = _conv3x3_cl(x, w, d[0], conv.bias, keep_width, act_slope)
+        y = _conv3x3_cl(x, w, d[0], conv.bias, keep_width, act_slope, key=id(conv.weight))
     elif k == (1, 1) and pd == (0, 0) and st[0] in (1, 2):
         xs = x if st[0] == 1 else x[:, :, ::2, ::2]
-        y = _conv3x3_cl(xs, F.pad(w, (1, 1, 1, 1)), 1, conv.bias, False, act_slope)
+        y = _conv3x3_cl(xs, F.pad(w, (1, 1, 1, 1)), 1, conv.bias, False, act_slope, key=id(conv.weight))
     elif k == (3, 3) and st == (2, 2) and pd == (1, 1) and d == (1, 1) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
         idx, msk = _tap_select("s2", w.device)
         cout, cin = w.shape[:2]
         # pixel_unshuffle orders its channels c * 4 + py * 2 + px
         w2 = (w.reshape(cout, cin, 9).index_select(2, idx) * msk).reshape(cout, cin * 4, 3, 3)
-        y = _conv3x3_cl(F.pixel_unshuffle(x, 2), w2, 1, conv.bias, False, act_slope)
+        y = _conv3x3_cl(F.pixel_unshuffle(x, 2), w2, 1, conv.bias, False, act_slope, key=id(conv.weight))
     if y is None:
         return module_forward()
     return y
@@ -444,7 +526,7 @@ def conv_transpose2d_module(conv, x, _any_device=False, act_slope=None):
     # bias + LeakyReLU commute with the interleave: applied to the four phases at once BEFORE it, on the channels-last tensor
     # the convolution wrote
     b4 = None if conv.bias is None else conv.bias.repeat(4)
-    y = _conv3x3_cl(x, w4, 1, b4, False, act_slope)
+    y = _conv3x3_cl(x, w4, 1, b4, False, act_slope, key=id(conv.weight))
     if y is None:
         return module_forward()
     # sub-pixel interleave on the channels-last tensor: pixel (Y, X) holds its four output pixels as four runs of Cout channels,

@@ -228,7 +228,8 @@ class KVNET(nn.Module):
             warped = ops.warp_volume(*warp_args, align_corners=self.d_net.align_corners)   # [15,D,h,w]
             volume = torch.cat((warped, BV_cur - BV_predict), dim=0)                       # [16,D,h,w]
             if self.kv_net.in_channels == 16 and self.KVNet_feature_dim == 64 and torch.is_grad_enabled():
-                gain = self.kv_net.forward_channels_last_autograd(volume.permute(1, 2, 3, 0).contiguous()).unsqueeze(0)
+                gain = self.kv_net.forward_channels_last_autograd(volume.permute(1, 2, 3, 0).contiguous(),
+                                                                  grad_channel=volume.shape[0] - 1).unsqueeze(0)   # only BV_cur - BV_predict
             elif volume.is_cuda:
                 # a K-Net the kernels have no form for (KVNet_feature_dim != 64, a window other than 5 frames, depth up-sampling:
                 # no script of the reference selects one): an error, never a silent hand-over to MIOpen

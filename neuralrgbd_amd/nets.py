@@ -707,30 +707,34 @@ class KalmanGainNet(_PackedWeightsMixin, nn.Module):
         conv, _ = L[11]
         return ops.conv3d_cout1(z, self._packed(conv), x_ss=ss, x_relu=True)  # classify.2
 
-    def forward_channels_last_autograd(self, vol):
+    def forward_channels_last_autograd(self, vol, grad_channel=None):
         """Training path: same graph on channels-last activations with the convolutions (forward, data gradient and
         weight gradient) on the hand-written matrix-core kernels (autograd.Conv3dCL); BatchNorm3d / ReLU / adds are
-        ordinary torch autograd ops applied in place of the layout (no NCDHW round trips).  vol [D,H,W,Cin] -> [D,H,W]."""
-        from .autograd import Conv3dCL, batch_norm_act_cl
+        ordinary torch autograd ops applied in place of the layout (no NCDHW round trips).  vol [D,H,W,Cin] -> [D,H,W].
+        grad_channel: the ONE input channel whose gradient the caller needs (KVNET: the last, BV_cur - BV_predict; the others are
+        warped images) — the other channels' gradient is then returned as zeros; None: all of them."""
+        from .autograd import Conv3dCL, Conv3dCout1CL, batch_norm_act_cl
         L = self._layers()
 
         def cbr(x_cl, i, relu, res=None):
             """conv -> BatchNorm3d -> [ReLU] -> [+ res].  [D,H,W,C] viewed as (voxels, C) is exactly the (N, C) form of batch_norm:
             same statistics, same running-statistics update; csrc/bn_train.hip in both directions."""
             conv, bn = L[i]
-            return batch_norm_act_cl(Conv3dCL.apply(x_cl, conv.weight), bn, relu, res)
+            return batch_norm_act_cl(Conv3dCL.apply(x_cl, conv.weight, id(conv.weight), grad_channel if i == 0 else None), bn, relu, res)
 
         x = cbr(vol, 0, True)
         x = cbr(x, 1, True)
         for i in (2, 4, 6, 8):
             x = cbr(cbr(x, i, True), i + 1, False, x)
         y = cbr(x, 10, True)
-        # classify.2 = Conv3d(64, 1): zero-padded to 64 outputs so that forward, data gradient and weight gradient
-        # all run on the matrix-core kernels (the vendor weight-gradient of this layer alone costs 58 ms at the
-        # ScanNet grid); autograd's slice / cat backward route the gradients of the single real output channel
+        # classify.2 = Conv3d(64, 1): a 27-tap stencil per voxel in all three directions (autograd.Conv3dCout1CL; the vendor
+        # weight-gradient of this layer alone costs 58 ms at the ScanNet grid, the layer zero-padded to 64 outputs on the matrix-core
+        # kernels — rounds 2-5 — 1.0 ms, of which 63/64 multiplies zeros)
         w1 = L[11][0].weight
+        if w1.shape[1] == 64 and y.is_cuda:
+            return Conv3dCout1CL.apply(y, w1, id(w1))
         w_pad = torch.cat((w1, w1.new_zeros(63, *w1.shape[1:])), dim=0)
-        return Conv3dCL.apply(y, w_pad)[..., 0]
+        return Conv3dCL.apply(y, w_pad, id(w1))[..., 0]
 
     def forward(self, volume):
         if volume.shape[1] != self.in_channels:

@@ -570,6 +570,36 @@ def conv3d_cout1(x, w_tap_major, x_ss=None, x_relu=False, res=None, res_ss=None,
     return y
 
 
+def conv3d_cout1_dgrad(gy, w_tap_major):
+    """Data gradient of the K-Net's last layer Conv3d(64, 1): gy [D,H,W], w_tap_major [27,64] -> gx [D,H,W,64] (conv3d_c1_bwd.hip)."""
+    gy = _need(gy, "gy")
+    D, H, W = gy.shape
+    w_tap_major = _need(w_tap_major, "w_tap_major", (27, 64))
+    gx = torch.empty((D, H, W, 64), dtype=torch.float32, device=gy.device)
+    with torch.cuda.device(gy.device):
+        rc = _lib.load().nrgbd_conv3d_cout1_dgrad_f32(_p(gy), _p(w_tap_major), _p(gx), D, H, W, _stream(gy))
+    _lib.check(rc, "nrgbd_conv3d_cout1_dgrad_f32")
+    return gx
+
+
+def conv3d_cout1_wgrad(x, gy):
+    """Weight gradient of the K-Net's last layer Conv3d(64, 1): x [D,H,W,64], gy [D,H,W] -> dW [1,64,3,3,3] (conv3d_c1_bwd.hip)."""
+    x = _need(x, "x")
+    D, H, W, Cin = x.shape
+    if Cin != 64:
+        raise ValueError("conv3d_cout1_wgrad: 64 input channels, got %d" % Cin)
+    gy = _need(gy, "gy", (D, H, W))
+    lib = _lib.load()
+    dw = torch.empty((1, 64, 3, 3, 3), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(lib.nrgbd_conv3d_cout1_wgrad_workspace(D, H, W, ctypes.byref(nbytes)), "nrgbd_conv3d_cout1_wgrad_workspace")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+        rc = lib.nrgbd_conv3d_cout1_wgrad_f32(_p(x), _p(gy), _p(dw), _p(ws), ctypes.c_size_t(ws.numel()), D, H, W, _stream(x))
+    _lib.check(rc, "nrgbd_conv3d_cout1_wgrad_f32")
+    return dw
+
+
 def _status_ptr(status, like):
     if status is None:
         return ctypes.c_void_p(0)

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from . import homography as warp_homo
 from . import ops
-from .autograd import nll_loss_d
+from .autograd import nll_loss_d, pack_cache
 from .misc import depth_val_regression, valid_dpv
 
 
@@ -42,6 +42,34 @@ def _predict(kv, pose_next, cam, d_candi):
     rel_Rt = ops.pose_inverse(pose_next.to(dtype=torch.float32).contiguous())
     return warp_homo.resample_vol_cuda(src_vol=kv, rel_extM=rel_Rt, cam_intrinsic=cam, d_candi=d_candi,
                                        padding_value=math.log(1. / float(len(d_candi))), clamp=(-1000., 0.)).unsqueeze(0)
+
+
+def _train_windows(A, dev, model_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, poses_all, BVs_predict, Cam_Intrinsics):
+    """Forward, losses and backward of the A windows of one optimizer step (train() below); gradients accumulate in .grad."""
+    outs = []
+    for b in range(A):
+        ref_frame = Ref_Dats[b]['img'].to(dev)
+        src_frames = torch.cat(tuple(f['img'] for f in Src_Dats[b]), dim=0).unsqueeze(0).to(dev)
+        poses = poses_all[b:b + 1]
+        bv = BVs_predict[b] if isinstance(BVs_predict, (list, tuple)) else (
+            BVs_predict[b:b + 1] if isinstance(BVs_predict, torch.Tensor) and A > 1 else BVs_predict)
+        if isinstance(bv, torch.Tensor) and bv.dim() == 3:
+            bv = bv.unsqueeze(0)
+        cam = Cam_Intrinsics[b] if len(Cam_Intrinsics) == A else Cam_Intrinsics[0]
+        valid = valid_dpv(bv) if isinstance(bv, torch.Tensor) else False
+        dmap_cur_refined, dmap_refined, d_dpv, kv_dpv = model_KV(
+            ref_frame=ref_frame, src_frames=src_frames, src_cam_poses=poses, BatchIdx=torch.zeros(1),
+            cam_intrinsics=[cam], BV_predict=bv if valid else None, dpv_valid=True if valid else None)
+        depth_ref = Ref_Dats[b]['dmap'].to(dev)                        # [1,h,w] int64 bin indices, 0 = ignore
+        depth_ref_imgsize = Ref_Dats[b]['dmap_imgsize_digit'].to(dev)  # [1,H,W]
+        loss = _nll_terms(d_dpv, dmap_cur_refined, kv_dpv, dmap_refined, depth_ref, depth_ref_imgsize, valid)
+        loss.backward()                # accumulates: the mean over the A windows is taken once, after the all-reduce
+        with torch.no_grad():
+            kv = kv_dpv.detach()
+            outs.append((dmap_cur_refined.detach(), _predict(kv, poses[0, t_win_r], cam, d_candi), loss.detach(),
+                         depth_val_regression(kv, d_candi, BV_log=True),
+                         depth_val_regression(dmap_refined.detach(), d_candi, BV_log=True)))
+    return outs
 
 
 def train(nGPU, model_KV, optimizer_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, Src_CamPoses, BVs_predict,
@@ -71,29 +99,8 @@ def train(nGPU, model_KV, optimizer_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, Sr
     else:
         optimizer_KV.zero_grad()
 
-    outs = []
-    for b in range(A):
-        ref_frame = Ref_Dats[b]['img'].to(dev)
-        src_frames = torch.cat(tuple(f['img'] for f in Src_Dats[b]), dim=0).unsqueeze(0).to(dev)
-        poses = poses_all[b:b + 1]
-        bv = BVs_predict[b] if isinstance(BVs_predict, (list, tuple)) else (
-            BVs_predict[b:b + 1] if isinstance(BVs_predict, torch.Tensor) and A > 1 else BVs_predict)
-        if isinstance(bv, torch.Tensor) and bv.dim() == 3:
-            bv = bv.unsqueeze(0)
-        cam = Cam_Intrinsics[b] if len(Cam_Intrinsics) == A else Cam_Intrinsics[0]
-        valid = valid_dpv(bv) if isinstance(bv, torch.Tensor) else False
-        dmap_cur_refined, dmap_refined, d_dpv, kv_dpv = model_KV(
-            ref_frame=ref_frame, src_frames=src_frames, src_cam_poses=poses, BatchIdx=torch.zeros(1),
-            cam_intrinsics=[cam], BV_predict=bv if valid else None, dpv_valid=True if valid else None)
-        depth_ref = Ref_Dats[b]['dmap'].to(dev)                        # [1,h,w] int64 bin indices, 0 = ignore
-        depth_ref_imgsize = Ref_Dats[b]['dmap_imgsize_digit'].to(dev)  # [1,H,W]
-        loss = _nll_terms(d_dpv, dmap_cur_refined, kv_dpv, dmap_refined, depth_ref, depth_ref_imgsize, valid)
-        loss.backward()                # accumulates: the mean over the A windows is taken once, after the all-reduce
-        with torch.no_grad():
-            kv = kv_dpv.detach()
-            outs.append((dmap_cur_refined.detach(), _predict(kv, poses[0, t_win_r], cam, d_candi), loss.detach(),
-                         depth_val_regression(kv, d_candi, BV_log=True),
-                         depth_val_regression(dmap_refined.detach(), d_candi, BV_log=True)))
+    with pack_cache():                # the A windows run on the same weights: their packed streams are built by the first one
+        outs = _train_windows(A, dev, model_KV, t_win_r, d_candi, Ref_Dats, Src_Dats, poses_all, BVs_predict, Cam_Intrinsics)
 
     if grad_reducer is not None:
         grad_reducer()                 # RCCL all-reduce (sum / (A * world)) of the 21 MB fp32 gradient: buckets whose gradients
@@ -145,6 +152,7 @@ class TrainGraph:
             raise ValueError("accum_steps must be >= 1")
         self.split = grad_reducer is not None or self.accum > 1
         self._g_opt = None
+        self._g_rest = None
         self._grads = None
 
     def _optimizer_ready(self):
@@ -278,7 +286,8 @@ class TrainGraph:
         keys = ("ref", "src", "poses", "dmap", "dmap_full", "bv")
         if self._needs_eager():
             self._zero_grads()
-            outs = [self._fwd_bwd(dict(zip(keys, w), inv=inv)) for w, inv in zip(windows, invs)]
+            with pack_cache():
+                outs = [self._fwd_bwd(dict(zip(keys, w), inv=inv)) for w, inv in zip(windows, invs)]
             self._reduce_grads()
             self.opt.step()
             self._eager_steps += 1
@@ -290,22 +299,34 @@ class TrainGraph:
             self._zero_grads()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
+            packed = {}                               # the weight streams the first window's graph writes (autograd.pack_cache)
+            with torch.cuda.graph(g, capture_error_mode=_capture_mode()), pack_cache(packed):
                 st["out"] = self._fwd_bwd(st)         # accumulates into the persistent gradients
+            g_rest = None
+            if self.accum > 1 and packed:
+                # windows 2 .. A of a step run on the same weights: a second capture of the same iteration with the cache filled holds
+                # no packing launch and reads the streams the first graph wrote (same pool; replay order = capture order)
+                g_rest = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_rest, pool=g.pool(), capture_error_mode=_capture_mode()), pack_cache(packed):
+                    st["out_rest"] = self._fwd_bwd(st)
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode=_capture_mode()):
                 self.opt.step()
             st["consts"] = warp_homo.cache_snapshot()
-            self._graph, self._g_opt, self._st = g, g2, st
+            st["packed"] = packed
+            self._graph, self._g_rest, self._g_opt, self._st = g, g_rest, g2, st
         st = self._st
         self._zero_grads()
         losses, preds = [], []
-        for w, inv in zip(windows, invs):
+        for i, (w, inv) in enumerate(zip(windows, invs)):
             for k, t in zip(keys, w):
                 st[k].copy_(t)
             st["inv"].copy_(inv)
-            self._graph.replay()
-            losses.append(st["out"][0].clone()); preds.append(st["out"][1].clone())
+            if i == 0 or self._g_rest is None:
+                self._graph.replay(); out = st["out"]
+            else:
+                self._g_rest.replay(); out = st["out_rest"]
+            losses.append(out[0].clone()); preds.append(out[1].clone())
         self._reduce_grads()
         self._g_opt.replay()
         self._mark_updated()

@@ -139,6 +139,59 @@ def test_conv3d_backward_kernels_vs_torch_autograd(D, H, W, Cin):
     assert ew < 1e-4 * max(1.0, w1.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("D,H,W", [(4, 8, 16), (5, 11, 21), (8, 24, 48)])
+def test_conv3d_cout1_three_directions_vs_torch_autograd(D, H, W):
+    """The K-Net's last layer Conv3d(64, 1) under autograd (autograd.Conv3dCout1CL): forward on conv3d.hip's depth-marching kernel, data and
+    weight gradient on conv3d_c1_bwd.hip — against float64 autograd of F.conv3d; ragged grids (partial tiles), run-to-run identical bits."""
+    from neuralrgbd_amd.autograd import Conv3dCout1CL
+    g = torch.Generator().manual_seed(D * 100 + W)
+    x = torch.randn(64, D, H, W, generator=g).to(DEV)
+    w = (torch.randn(1, 64, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    gy = torch.randn(D, H, W, generator=g).to(DEV)
+    x1, w1 = x.double().clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+    y1 = F.conv3d(x1[None], w1, padding=1)[0, 0]
+    (y1 * gy.double()).sum().backward()
+    outs = []
+    for _ in range(2):
+        x2, w2 = x.permute(1, 2, 3, 0).contiguous().requires_grad_(True), w.clone().requires_grad_(True)
+        y2 = Conv3dCout1CL.apply(x2, w2)
+        (y2 * gy).sum().backward()
+        outs.append((y2.detach(), x2.grad, w2.grad))
+    y2, gx, gw = outs[0]
+    ey = (y2.double() - y1).abs().max().item()
+    ex = (gx.permute(3, 0, 1, 2).double() - x1.grad).abs().max().item()
+    ew = (gw.double() - w1.grad).abs().max().item()
+    print("[parity] conv3d 64->1 %dx%dx%d: max|d y|=%.2e max|d gx|=%.2e max|d gw|=%.2e (|gw|max %.1f)" %
+          (D, H, W, ey, ex, ew, w1.grad.abs().max().item()))
+    assert ey < 2e-5 * max(1.0, y1.abs().max().item())
+    assert ex < 2e-6 * max(1.0, x1.grad.abs().max().item())
+    assert ew < 2e-5 * max(1.0, w1.grad.abs().max().item())
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+def test_first_layer_single_channel_data_gradient():
+    """Conv3dCL(grad_channel=c): the first K-Net layer's data gradient for the one input channel that needs it (BV_cur - BV_predict) as a
+    64 -> 1 stencil over gy equals channel c of the full data gradient; the other channels come back as zeros."""
+    from neuralrgbd_amd.autograd import Conv3dCL
+    g = torch.Generator().manual_seed(5)
+    D, H, W = 8, 16, 32
+    x = torch.randn(D, H, W, 16, generator=g).to(DEV)
+    w = (torch.randn(64, 16, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    gy = torch.randn(D, H, W, 64, generator=g).to(DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    wa, wb = w.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    (Conv3dCL.apply(xa, wa) * gy).sum().backward()
+    (Conv3dCL.apply(xb, wb, None, 15) * gy).sum().backward()
+    x64, w64 = x.permute(3, 0, 1, 2).double().requires_grad_(True), w.double().requires_grad_(True)
+    (F.conv3d(x64[None], w64, padding=1)[0] * gy.permute(3, 0, 1, 2).double()).sum().backward()
+    want = x64.grad[15]
+    print("[parity] first-layer dgrad, channel 15 only: max|d vs fp64| %.2e (full Winograd dgrad: %.2e; |g|max %.1f)" %
+          ((xb.grad[..., 15].double() - want).abs().max().item(), (xa.grad[..., 15].double() - want).abs().max().item(), want.abs().max().item()))
+    assert (xb.grad[..., 15].double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert float(xb.grad[..., :15].abs().max()) == 0.0
+    assert torch.equal(wa.grad, wb.grad)
+
+
 def test_knet_training_path_vs_fp64_autograd():
     """forward_channels_last_autograd (hand-written conv kernels under autograd: Winograd-domain forward and data gradient for
     the 64 -> 64 layers, direct kernels for the rest, conv3d_wgrad) — output and every parameter gradient against float64 CPU
