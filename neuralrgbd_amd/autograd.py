@@ -335,15 +335,38 @@ class Conv2dCL(torch.autograd.Function):
     DIRECT = {(32, 1), (64, 1), (96, 1), (128, 1), (128, 2)}    # (Cout, dilation) instantiated in conv2d.hip
 
     @staticmethod
-    def eligible(cin, cout, dil, need_dgrad=True):
-        """Forward, data gradient (roles of Cin / Cout swapped; not needed when the input is an image) and weight gradient all
-        have a kernel."""
-        def fwd(ci, co):
-            return (ci % 32 == 0 and co % 64 == 0 and dil in (1, 2)) or (ci % 16 == 0 and (co, dil) in Conv2dCL.DIRECT)
-        return fwd(cin, cout) and (fwd(cout, cin) or not need_dgrad) and cin % 16 == 0 and cout % 16 == 0
+    def _rnet_plan(cin, cout, dil, real_cout=None):
+        """How wino_pc.hip's R-Net form (any stage count >= 2) covers a cin -> cout layer whose output width is not a multiple of 64 —
+        the R-Net's 96-wide half-resolution and 67-wide (80 with padding) full-resolution layers, models/Refine.py:51-77 — instead of
+        the direct kernel at 9 multiplies per output: (columns on whole 64-column groups, tail) with tail = ("half", n <= 32 columns on
+        the kernel's 32-column form) | ("few", n <= 4 columns on csrc/conv_few.hip) | None; None if it does not apply.
+        real_cout: output channels that are not zero padding (the padded columns are never computed: they stay zero)."""
+        rc = cout if real_cout is None else min(real_cout, cout)
+        full = (rc // 64) * 64
+        extra = rc - full
+        if dil != 1 or cin % 16 or cin < 32 or full == 0 or (cin % 32 == 0 and cout % 64 == 0):
+            return None
+        if extra == 0:
+            return (full, None)
+        if extra <= 4:
+            return (full, ("few", extra))
+        if extra <= 32 and cout >= full + extra:
+            return (full, ("half", extra))
+        return None
 
     @staticmethod
-    def _conv(x_cl, w, dil, transposed=False, packed=None, key=None):
+    def eligible(cin, cout, dil, need_dgrad=True, real=None):
+        """Forward, data gradient (roles of Cin / Cout swapped; not needed when the input is an image) and weight gradient all
+        have a kernel.  real = (cin, cout) before zero padding."""
+        rci, rco = real if real is not None else (cin, cout)
+
+        def fwd(ci, co, rc):
+            return ((ci % 32 == 0 and co % 64 == 0 and dil in (1, 2)) or Conv2dCL._rnet_plan(ci, co, dil, rc) is not None
+                    or (ci % 16 == 0 and (co, dil) in Conv2dCL.DIRECT))
+        return fwd(cin, cout, rco) and (fwd(cout, cin, rci) or not need_dgrad) and cin % 16 == 0 and cout % 16 == 0
+
+    @staticmethod
+    def _conv(x_cl, w, dil, transposed=False, packed=None, key=None, real_out=None):
         cout, cin = (w.shape[1], w.shape[0]) if transposed else w.shape[:2]
         tr = bool(transposed)
         if cin % 32 == 0 and cout % 64 == 0:
@@ -353,22 +376,42 @@ class Conv2dCL(torch.autograd.Function):
             # the HALF form of wino_pc.hip (the trunk's 32 -> 32 layers): its stream is the 64-column one, upper half zero
             wp = _cached(key, ("half", tr), lambda: ops.conv_wino_pack(torch.cat((w, torch.zeros_like(w)), 1 if transposed else 0), transposed))
             return ops.conv_wino(x_cl, wp, 32, 1, 1, want_stats=False)[0]
+        plan = Conv2dCL._rnet_plan(cin, cout, dil, real_out)
+        if plan is not None:
+            full, tail = plan
+
+            def we():                                             # the weights as a forward layer [cout, cin, 3, 3] of THIS call
+                return (w.detach().transpose(0, 1).flip(2, 3) if transposed else w.detach())
+            done = full + (tail[1] if tail else 0)
+            out = (x_cl.new_zeros if done < cout else x_cl.new_empty)(x_cl.shape[:3] + (cout,))     # padding columns: exactly zero
+            ops.conv_wino_rnet(x_cl, _cached(key, ("rg", tr), lambda: ops.conv_wino_pack(we()[:full].contiguous())), full, None, False,
+                               out=out, ycoff=0, cout_valid=full)
+            if tail is not None and tail[0] == "few":
+                n = tail[1]
+                wf = _cached(key, ("rf", tr), lambda: we()[full:full + n].reshape(n, cin // 16, 16, 9).permute(1, 3, 0, 2).contiguous())
+                ops.conv2d_few(x_cl, wf, None, False, out=out, ycoff=full)
+            elif tail is not None:
+                n = tail[1]
+                th = _cached(key, ("rh", tr), lambda: ops.conv_wino_pack(torch.cat((we()[full:full + n], w.new_zeros(64 - n, cin, 3, 3)), 0).contiguous()))
+                ops.conv_wino_rnet(x_cl, th, 32, None, False, out=out, ycoff=full, cout_valid=n)
+            return out
 
         def direct():
             return ops.conv_pack_weights((w.transpose(0, 1).flip(2, 3) if transposed else w).contiguous())   # transposed: [Cin, Cout, 3, 3], flipped
         return ops.conv2d(x_cl, _cached(key, ("direct", tr), direct), cout, dil, want_stats=False)[0]
 
     @staticmethod
-    def forward(ctx, x, w, dil, key=None):
+    def forward(ctx, x, w, dil, key=None, real=None):
+        """real = (cin, cout) of the layer before the caller's zero padding (None: w's own widths)."""
         x_cl = x.permute(0, 2, 3, 1).contiguous()                 # free when x is channels_last
         cout, cin = w.shape[:2]
         fwd = bwd = None
         if cin % 64 == 0 and cout % 64 == 0 and ctx.needs_input_grad[0]:
             # both directions run on wino_pc.hip: one packing launch for the two streams
             fwd, bwd = _cached(key, ("both", 0), lambda: ops.conv_wino_pack_both(w))
-        y = Conv2dCL._conv(x_cl, w, dil, packed=fwd, key=key)
+        y = Conv2dCL._conv(x_cl, w, dil, packed=fwd, key=key, real_out=None if real is None else real[1])
         ctx.save_for_backward(x_cl, w, bwd)
-        ctx.dil, ctx.key = dil, key
+        ctx.dil, ctx.key, ctx.real = dil, key, real
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -379,16 +422,19 @@ class Conv2dCL(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = ops.conv2d_wgrad(x_cl, gy_cl, ctx.dil)
         if ctx.needs_input_grad[0]:
-            gx = Conv2dCL._conv(gy_cl, w, ctx.dil, transposed=True, packed=bwd, key=ctx.key).permute(0, 3, 1, 2)
-        return gx, gw, None, None
+            gx = Conv2dCL._conv(gy_cl, w, ctx.dil, transposed=True, packed=bwd, key=ctx.key,
+                                real_out=None if ctx.real is None else ctx.real[0]).permute(0, 3, 1, 2)
+        return gx, gw, None, None, None
 
 
-def _padded_widths(cin, cout, dil, need_dgrad):
-    """Smallest (cin_p, cout_p) >= (cin, cout), multiples of 16, for which Conv2dCL has every kernel it will need."""
+def _padded_widths(cin, cout, dil, need_dgrad, real=None):
+    """Smallest (cin_p, cout_p) >= (cin, cout), multiples of 16, for which Conv2dCL has every kernel it will need.
+    real: the layer's own (cin, cout) when `cin` already counts padding channels of the incoming tensor."""
+    real = (cin, cout) if real is None else real
     best = None
     for co in range(-(-cout // 16) * 16, cout + 129, 16):
         for ci in range(-(-cin // 16) * 16, cin + 129, 16):
-            if Conv2dCL.eligible(ci, co, dil, need_dgrad) and (best is None or ci * co < best[0] * best[1]):
+            if Conv2dCL.eligible(ci, co, dil, need_dgrad, real) and (best is None or ci * co < best[0] * best[1]):
                 best = (ci, co)
     return best
 
@@ -445,7 +491,7 @@ def _conv3x3_cl(x, w, dil, bias, keep_width=False, act_slope=None, key=None):
     F = torch.nn.functional
     cout, cin = w.shape[:2]
     have = x.shape[1]
-    pw = _padded_widths(max(cin, have), cout, dil, x.requires_grad)
+    pw = _padded_widths(max(cin, have), cout, dil, x.requires_grad, real=(cin, cout))
     if pw is None:
         return None
     ci, co = pw
@@ -455,7 +501,7 @@ def _conv3x3_cl(x, w, dil, bias, keep_width=False, act_slope=None, key=None):
         w = F.pad(w, (0, 0, 0, 0, 0, ci - cin))
     if co != cout:
         w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, co - cout))
-    y = Conv2dCL.apply(x, w, dil, key)
+    y = Conv2dCL.apply(x, w, dil, key, (cin, cout))
     # bias (+ LeakyReLU) on the full-width channels-last tensor (the padded channels stay exactly zero: zero weights, zero bias)
     y = _bias_act(y, None if bias is None else (bias if co == cout else F.pad(bias, (0, co - cout))), act_slope)
     if co != cout and not keep_width:

@@ -363,7 +363,8 @@ def test_training_iterations_vs_reference_golden():
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,dil", [(2, 24, 40, 64, 64, 1), (1, 17, 33, 32, 32, 1), (2, 20, 28, 128, 128, 2),
-                                                (1, 16, 32, 320, 128, 1), (2, 12, 20, 64, 128, 1), (1, 22, 30, 96, 96, 1)])
+                                                (1, 16, 32, 320, 128, 1), (2, 12, 20, 64, 128, 1), (1, 22, 30, 96, 96, 1),
+                                                (1, 24, 32, 80, 80, 1), (1, 16, 48, 80, 64, 1), (2, 16, 16, 96, 160, 1)])
 def test_conv2d_autograd_function_vs_fp64(N, H, W, Cin, Cout, dil):
     """autograd.Conv2dCL (forward, data gradient = forward kernel on flipped weights, weight gradient = conv2d_wgrad.hip) against
     float64 autograd of F.conv2d, for every layer form of the trunk / R-Net it serves."""
@@ -386,6 +387,33 @@ def test_conv2d_autograd_function_vs_fp64(N, H, W, Cin, Cout, dil):
     print("[parity] Conv2dCL N%d %dx%d %d->%d dil%d: y %.1e  dx %.1e  dw %.1e (relative to the largest element, vs fp64)"
           % (N, H, W, Cin, Cout, dil, e_y, e_x, e_w))
     assert e_y < 5e-6 and e_x < 5e-6 and e_w < 5e-6
+
+
+def test_conv2d_autograd_padded_67_wide_layer_on_the_rnet_winograd_form():
+    """The R-Net's full-resolution 67 -> 67 layer (models/Refine.py:64-66) under autograd, zero-padded to 80 channels: 64 columns on
+    wino_pc.hip's R-Net form (5 stages), 3 on conv_few.hip, the 13 padding columns never computed and exactly zero, in both directions
+    (until round 6: a 96 -> 96 direct convolution)."""
+    from neuralrgbd_amd.autograd import Conv2dCL, _padded_widths
+    assert _padded_widths(67, 67, 1, True) == (80, 80) and Conv2dCL._rnet_plan(80, 80, 1, 67) == (64, ("few", 3))
+    g = torch.Generator().manual_seed(67)
+    N, H, W = 2, 24, 48
+    x = torch.randn(N, 67, H, W, generator=g)
+    w = torch.randn(67, 67, 3, 3, generator=g) * 0.05
+    gy = torch.randn(N, 67, H, W, generator=g)
+    xd, wd = x.double().requires_grad_(), w.double().requires_grad_()
+    want = F.conv2d(xd, wd, padding=1)
+    want.backward(gy.double())
+    pad = lambda t, dims: F.pad(t, dims)
+    xg = pad(x, (0, 0, 0, 0, 0, 13)).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    wg = pad(w, (0, 0, 0, 0, 0, 13, 0, 13)).to(DEV).requires_grad_()
+    y = Conv2dCL.apply(xg, wg, 1, None, (67, 67))
+    y.backward(pad(gy, (0, 0, 0, 0, 0, 13)).to(DEV))
+    e_y = (y[:, :67].detach().cpu().double() - want.detach()).abs().max().item() / want.abs().max().item()
+    e_x = (xg.grad[:, :67].cpu().double() - xd.grad).abs().max().item() / xd.grad.abs().max().item()
+    e_w = (wg.grad[:67, :67].cpu().double() - wd.grad).abs().max().item() / wd.grad.abs().max().item()
+    print("[parity] Conv2dCL 67 -> 67 as 80 -> 80 (R-Net Winograd form + conv_few): y %.1e  dx %.1e  dw %.1e" % (e_y, e_x, e_w))
+    assert e_y < 5e-6 and e_x < 5e-6 and e_w < 5e-6
+    assert float(y[:, 67:].abs().max()) == 0.0 and float(xg.grad[:, 67:].abs().max()) == 0.0
 
 
 def test_feature_cnn_training_path_vs_fp64_module_autograd():

@@ -259,11 +259,11 @@ def test_conv_embeddings_of_the_training_path_are_exact(monkeypatch):
         calls = []
 
         @staticmethod
-        def eligible(cin, cout, dil, need_dgrad=True):
+        def eligible(cin, cout, dil, need_dgrad=True, real=None):
             return cin % 16 == 0 and cout % 16 == 0
 
         @staticmethod
-        def apply(x, w, dil, key=None):
+        def apply(x, w, dil, key=None, real=None):
             FakeConv2dCL.calls.append((tuple(x.shape), tuple(w.shape), dil))
             return F.conv2d(x, w, None, 1, dil, dil)
     monkeypatch.setattr(ag, "Conv2dCL", FakeConv2dCL)
