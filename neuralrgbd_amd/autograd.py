@@ -333,6 +333,7 @@ class Conv2dCL(torch.autograd.Function):
     """
 
     DIRECT = {(32, 1), (64, 1), (96, 1), (128, 1), (128, 2)}    # (Cout, dilation) instantiated in conv2d.hip
+    rnet_route = True    # False: the direct kernel for those widths (A/B, tools/)
 
     @staticmethod
     def _rnet_plan(cin, cout, dil, real_cout=None):
@@ -341,6 +342,8 @@ class Conv2dCL(torch.autograd.Function):
         the direct kernel at 9 multiplies per output: (columns on whole 64-column groups, tail) with tail = ("half", n <= 32 columns on
         the kernel's 32-column form) | ("few", n <= 4 columns on csrc/conv_few.hip) | None; None if it does not apply.
         real_cout: output channels that are not zero padding (the padded columns are never computed: they stay zero)."""
+        if not Conv2dCL.rnet_route:
+            return None
         rc = cout if real_cout is None else min(real_cout, cout)
         full = (rc // 64) * 64
         extra = rc - full

@@ -19,6 +19,9 @@
         if (e__ != hipSuccess) return (int)e__;      \
     } while (0)
 
+#include <map>
+#include <mutex>
+#include <utility>
 #ifdef NRGBD_DEV
 #include <cstdlib>
 #endif
@@ -181,6 +184,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Opt-in of a kernel for more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize): set ONCE per (function, device),
+// to the largest size the function is ever launched with — never per call.  The attribute belongs to the FUNCTION, and a launch recorded
+// in a hipGraph is replayed under whatever value it has at that moment: a later eager call with a smaller size (the Winograd kernels'
+// size depends on Cin) must not shrink it under a captured launch that needs more.  (Round 6 looked here first for the replay hazard
+// described in neuralrgbd_amd/__init__.py; it was not the cause, the rule is kept because it is the correct use of the attribute.)
+inline hipError_t set_max_dynamic_lds(const void* func, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> done;      // (function, device) -> bytes set
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    int& have = done[std::make_pair(func, dev)];
+    if (have >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 // Last step of every batch-statistics finaliser (conv2d.hip, conv3d.hip, wino_pc.hip): (sum, sum of squares) over `count`
 // values, reduced in fp64 from the convolution epilogues' fp32 per-tile partials -> BatchNorm (scale, shift) + running statistics.

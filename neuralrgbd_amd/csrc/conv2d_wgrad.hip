@@ -168,11 +168,11 @@ extern "C" int nrgbd_conv2d_wgrad_f32(const float* x, const float* gy, float* pa
     const size_t lds = (size_t)((kGH + 2 * dilation) * (kGW + 2 * dilation) + kGH * kGW) * kGSV * sizeof(float);   // 98.6 / 117.8 KB
     hipError_t e;
     if (dilation == 1) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<1>), (int)lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(conv2d_wgrad_kernel<1>, dim3(nwg, blocks), dim3(1024), lds, (hipStream_t)stream, a);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv2d_wgrad_kernel<2>), (int)lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(conv2d_wgrad_kernel<2>, dim3(nwg, blocks), dim3(1024), lds, (hipStream_t)stream, a);
     }

@@ -579,8 +579,7 @@ extern "C" int nrgbd_conv3d_3x3x3_cout1_f32(const float* x, const float* x_ss, i
     nz = ceil_div(D, dz);
     // > 64 KB of dynamic LDS needs the opt-in; it is idempotent and costs ~1 us, so it is simply repeated per call
     // (no process-global flag: re-entrant from any thread on any device)
-    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_cout1_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC1Lds);
+    hipError_t ea = set_max_dynamic_lds(reinterpret_cast<const void*>(conv3d_cout1_kernel), (int)kC1Lds);
     if (ea != hipSuccess) return (int)ea;
     hipLaunchKernelGGL(conv3d_cout1_kernel, dim3(cols * nz), dim3(256), kC1Lds, (hipStream_t)stream, a, w_tap_major, dz);
     NRGBD_CHECK_LAUNCH();

@@ -279,11 +279,11 @@ extern "C" int nrgbd_conv3d_wgrad_f32(const float* x, const float* gy, float* pa
     const size_t lds = (size_t)kWHalo * ((Cin < 32 ? Cin : 32) + 8) * sizeof(float);  // 69,120 B (Cin = 64): two workgroups per CU
     hipError_t e;
     if (Cin >= 64) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv3d_wgrad_kernel<32>), (int)lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(conv3d_wgrad_kernel<32>, dim3(kWRanges, 4), dim3(kWThreads), lds, (hipStream_t)stream, a);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv3d_wgrad_kernel<16>), (int)lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(conv3d_wgrad_kernel<16>, dim3(kWRanges, 2), dim3(kWThreads), lds, (hipStream_t)stream, a);
     }

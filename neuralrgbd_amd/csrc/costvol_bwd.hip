@@ -284,8 +284,8 @@ extern "C" int nrgbd_costvol_bwd(const float* ref_nhwc, const float* src_nhwc, c
                          dist, align_corners, V, C, Cp, D, h, w, lds_kc, dev_env_int("NRGBD_BWD_ABL")};
         const size_t lds = hw * 16;
         hipError_t e = hipSuccess;
-        if (lds > 64 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&costvol_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024)   // the function's opt-in: always the maximum, never this call's size (a hipGraph replay runs under the current value)
+            e = set_max_dynamic_lds(reinterpret_cast<const void*>(&costvol_bwd_lds_kernel), 160 * 1024);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(costvol_bwd_lds_kernel, dim3(lds_kc, Cp >> 2, V), dim3(kBwdThreads), lds, s, a, part_src, part_ref);
         NRGBD_CHECK_LAUNCH();

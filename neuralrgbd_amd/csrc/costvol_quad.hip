@@ -659,8 +659,8 @@ int launch_costvol_quad(const CostvolArgs& args, hipStream_t stream, bool* did_s
 #define NRGBD_QUAD_CFG(DIST, TL, AL)                                                                                           \
     do {                                                                                                                       \
         if (lds > 64 * 1024) {                                                                                                 \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&costvol_quad<DIST, TL, AL, kQPatch3, 3>),                   \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+            e = set_max_dynamic_lds(reinterpret_cast<const void*>(&costvol_quad<DIST, TL, AL, kQPatch3, 3>),                   \
+                                    (int)lds);                                     \
             if (e != hipSuccess) return (int)e;                                                                                \
         }                                                                                                                      \
         hipLaunchKernelGGL((costvol_quad<DIST, TL, AL, kQPatch3, 3>), grid, dim3(256), lds, stream, a);                        \

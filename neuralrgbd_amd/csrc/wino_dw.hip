@@ -679,26 +679,26 @@ static int conv_wino_dw_launch(const float* x, const float* x_ss, int x_relu, co
     if (ncu <= 0) return NRGBD_E_ARG;
     const int nwg = nt < ncu ? (int)nt : ncu;   // persistent: one workgroup per CU
     const size_t lds = (size_t)(kDwNBuf * kPcV + kDwStrips + 4 * kDwStashWave + 4 * Cin) * sizeof(float);   // 64 + 25.6 (20) + 64 KB + tables
+    // the function's opt-in is set to the form's maximum, not to this call's size (see nrgbd_conv_wino_f32: hipGraph replays read it)
+    const int lds_attr = 160 * 1024;
     hipStream_t st = (hipStream_t)stream;
 #define NRGBD_WINO_DW_LAUNCH(RES_, MAT_, RSID_)                                                                               \
     do {                                                                                                                      \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw_kernel<RES_, MAT_, RSID_>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                        \
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_dw_kernel<RES_, MAT_, RSID_>),                       \
+                                lds_attr);                                        \
         if (e != hipSuccess) return (int)e;                                                                                   \
         hipLaunchKernelGGL((conv_wino_dw_kernel<RES_, MAT_, RSID_>), dim3(nwg), dim3(512), lds, st, a);                        \
     } while (0)
     const bool rsid = res && !res_ss && !res_relu;
     if (x_unit != 0.f) {            // the CLAMP instantiation (nrgbd_conv_wino_dw_unit_f32 checked its preconditions)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw_kernel<false, false, false, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_dw_kernel<false, false, false, false, true>), lds_attr);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((conv_wino_dw_kernel<false, false, false, false, true>), dim3(nwg), dim3(512), lds, st, a);
     } else if (res && rsid) { if (materialized) NRGBD_WINO_DW_LAUNCH(true, true, true); else NRGBD_WINO_DW_LAUNCH(true, false, true); }
     else if (res) { if (materialized) NRGBD_WINO_DW_LAUNCH(true, true, false); else NRGBD_WINO_DW_LAUNCH(true, false, false); }
     else if (materialized) NRGBD_WINO_DW_LAUNCH(false, true, false);
     else if (NRGBD_DW_IDENT && !x_ss && !x_relu) {   // the IDENT instantiation: nothing to apply to x
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw_kernel<false, false, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_dw_kernel<false, false, false, true>), lds_attr);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((conv_wino_dw_kernel<false, false, false, true>), dim3(nwg), dim3(512), lds, st, a);
     } else NRGBD_WINO_DW_LAUNCH(false, false, false);

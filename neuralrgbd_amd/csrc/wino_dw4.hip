@@ -621,12 +621,14 @@ extern "C" int nrgbd_conv_wino_dw4_f32(const float* x, const float* x_ss, int x_
                       nullptr, 0, 0, 0, 0, 0, x_unit};
     aa.scratch = static_cast<float*>(workspace);
     const size_t lds = (size_t)(kD4NBuf * kPcV + 2 * kD4ShStrip + 4 * kD4StashWave + 2 * Cin) * sizeof(float);
+    // the function's opt-in is set to the form's maximum, not to this call's size (see nrgbd_conv_wino_f32: hipGraph replays read it)
+    const int lds_attr = (int)((size_t)(kD4NBuf * kPcV + 2 * kD4ShStrip + 4 * kD4StashWave + 2 * kD4MaxCin) * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
 #define NRGBD_D4_LAUNCH(ID_, CL_)                                                                                          \
     do {                                                                                                                   \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_dw4_kernel<ID_, CL_>),                            \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_dw4_kernel<ID_, CL_>),                            \
+                                lds_attr);                                     \
         if (e != hipSuccess) return (int)e;                                                                                \
         hipLaunchKernelGGL((conv_wino_dw4_kernel<ID_, CL_>), dim3(nwg), dim3(512), lds, st, aa);                           \
     } while (0)

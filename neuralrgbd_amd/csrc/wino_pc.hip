@@ -758,14 +758,19 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     if (ncu <= 0) return NRGBD_E_ARG;
     const int nwg = nt < ncu ? (int)nt : ncu;   // persistent: one workgroup per CU
     const size_t lds = (size_t)(kPcNBuf * kPcV + kPcStrips + 4 * Cin) * sizeof(float);   // 96 KB V + 25.6 (20) KB strips + (scale, shift) tables
+    // The opt-in for > 64 KB of dynamic LDS is a property of the FUNCTION, and a launch recorded in a hipGraph is replayed under whatever
+    // value the function carries at that moment: it is therefore always set to the form's maximum (Cin = 2048), never to this call's size —
+    // a later eager call with fewer channels would otherwise shrink it under a captured launch with more (round 6: a training graph
+    // replayed after an eager iteration ran with part of its (scale, shift) tables cut off)
+    const int lds_attr = (int)((size_t)(kPcNBuf * kPcV + kPcStrips + 4 * 2048) * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
 #define NRGBD_WINO_PC_LAUNCH(KD_, DIL_, RES_)                                                                       \
     do { if (materialized) NRGBD_WINO_PC_LAUNCH_M(KD_, DIL_, RES_, true); else NRGBD_WINO_PC_LAUNCH_M(KD_, DIL_, RES_, false); } while (0)
 #define NRGBD_WINO_PC_LAUNCH_M(KD_, DIL_, RES_, MAT_)                                                               \
     do {                                                                                                            \
-        /* > 64 KB of dynamic LDS needs the opt-in; idempotent and ~1 us, so simply repeated per call (re-entrant) */ \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<KD_, DIL_, RES_, false, 0, MAT_>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        /* > 64 KB of dynamic LDS needs the opt-in: once per function and device (common.hpp set_max_dynamic_lds)       */ \
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_pc_kernel<KD_, DIL_, RES_, false, 0, MAT_>), \
+                                lds_attr);                              \
         if (e != hipSuccess) return (int)e;                                                                         \
         hipLaunchKernelGGL((conv_wino_pc_kernel<KD_, DIL_, RES_, false, 0, MAT_>), dim3(nwg), dim3(512), lds, st, a); \
     } while (0)
@@ -773,8 +778,8 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
     if (odd && (kd != 3 || res || materialized)) return NRGBD_E_SHAPE;   // an odd stage count is instantiated for the K-Net's first layer only
 #define NRGBD_WINO_PC_LAUNCH_H(RES_, MAT_)                                                                          \
     do {                                                                                                            \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, RES_, false, 0, MAT_, true>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, RES_, false, 0, MAT_, true>), \
+                                lds_attr);                              \
         if (e != hipSuccess) return (int)e;                                                                         \
         hipLaunchKernelGGL((conv_wino_pc_kernel<1, 1, RES_, false, 0, MAT_, true>), dim3(nwg), dim3(512), lds, st, a); \
     } while (0)
@@ -784,8 +789,7 @@ extern "C" int nrgbd_conv_wino_f32(const float* x, const float* x_ss, int x_relu
         else if (materialized) NRGBD_WINO_PC_LAUNCH_H(false, true);
         else NRGBD_WINO_PC_LAUNCH_H(false, false);
     } else if (kd == 3 && odd) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<3, 1, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_pc_kernel<3, 1, false, true>), lds_attr);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL((conv_wino_pc_kernel<3, 1, false, true>), dim3(nwg), dim3(512), lds, st, a);
     } else if (kd == 3) {
@@ -827,8 +831,8 @@ extern "C" int nrgbd_conv_wino_rnet_ex_f32(const float* x, const float* w_wino, 
     const size_t lds = (size_t)(kPcNBuf * kPcV + kPcStrips) * sizeof(float);
 #define NRGBD_WINO_RNET_LAUNCH(ODD_, HALF_)                                                                              \
     do {                                                                                                                 \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, false, ODD_, 1, false, HALF_>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+        e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_wino_pc_kernel<1, 1, false, ODD_, 1, false, HALF_>), \
+                                (int)lds);                                   \
         if (e != hipSuccess) return (int)e;                                                                              \
         hipLaunchKernelGGL((conv_wino_pc_kernel<1, 1, false, ODD_, 1, false, HALF_>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a); \
     } while (0)
