@@ -544,9 +544,9 @@ def test_batch_norm_module_glue_vs_torch_batch_norm():
         assert torch.allclose(x.grad, x2.grad, atol=1e-6, rtol=1e-6)
 
 
-def _accum_setup(seed, lr=1e-4, capturable=False):
+def _accum_setup(seed, lr=1e-4, capturable=False, D=8):
     import neuralrgbd_amd
-    H, W, D = 256, 256, 8
+    H, W = 256, 256
     cam = camera.scannet_intrinsics(W // 4, H // 4)
     d_candi = np.linspace(0.1, 5, D)
     model = neuralrgbd_amd.KVNET(64, cam, d_candi, 10.0, 64, None, if_refined=True, refineNet_name="DPV", t_win_r=2)
@@ -622,15 +622,18 @@ def test_train_accumulates_four_windows_into_one_optimizer_step():
         assert float((q.grad - want_by_name[n]).abs().max()) <= 1e-2 * scale, n
 
 
-def test_split_train_graph_with_accumulation_equals_eager_accumulation():
+@pytest.mark.parametrize("D", [8, 16])
+def test_split_train_graph_with_accumulation_equals_eager_accumulation(D):
     """the hipGraph is kept when a gradient reducer / accumulation is in play — graph 1 (forward +
-    backward + PREDICT of one window) replayed per window into persistent gradients, the reducer between the graphs, graph 2
-    (Adam).  Against train(accum_steps=2) on a twin: same loss, predicted states and updated weights."""
+    backward + PREDICT of one window; round 6: a second capture without the weight-packing launches for windows 2 .. A) replayed per
+    window into persistent gradients, the reducer between the graphs, graph 2 (Adam).  Against train(accum_steps=2) on a twin that
+    trains EAGERLY between the replays: same loss, predicted states and updated weights.  (The interleaving is what exposed the
+    runtime's replay hazard, profiles/r6_graph_replay_hazard.txt: D = 16 failed on the new R-Net route, D = 8 on the old one.)"""
     import copy
     from neuralrgbd_amd import distributed as nd
     from neuralrgbd_amd.test_step import test as infer
     from neuralrgbd_amd.train_step import TrainGraph, train
-    model, cam, d_candi, window, (H, W, D) = _accum_setup(6)
+    model, cam, d_candi, window, (H, W, D) = _accum_setup(6, D=D)
     A = 2
     wins = [window(i) for i in range(4 * A)]
     preds = []
