@@ -34,6 +34,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the first HIP call: see neuralrgbd_amd/__init__.py (hipGraph replay hazard)
+
 import numpy as np
 import torch
 

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the first HIP call: see neuralrgbd_amd/__init__.py (hipGraph replay hazard)
+
 import numpy as np
 import pytest
 
