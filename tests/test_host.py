@@ -388,3 +388,49 @@ def test_fused_adam_loads_a_reference_era_checkpoint():
     with pytest.raises(NrgbdError):
         fresh.load_state_dict(ams)
     assert fresh.param_groups[0]["lr"] == 1e-3 and not fresh.state      # refused before anything was replaced
+
+
+def test_rnet_route_plan_and_padded_widths_of_the_training_convolutions():
+    """Host logic of autograd.Conv2dCL (round 6): which 3x3 layers of the training path run on wino_pc.hip's R-Net form and at which
+    zero-padded widths — the R-Net's 67-wide layers at 80 (64 columns + 3 on conv_few.hip), its 96-wide ones as 64 + a 32-column slice,
+    every trunk layer where it was."""
+    from neuralrgbd_amd.autograd import Conv2dCL, _padded_widths
+    plan = Conv2dCL._rnet_plan
+    assert plan(80, 80, 1, 67) == (64, ("few", 3)) and plan(80, 64, 1, 64) == (64, None) and plan(64, 80, 1, 67) == (64, ("few", 3))
+    assert plan(96, 96, 1) == (64, ("half", 32)) and plan(80, 80, 1, 72) == (64, ("half", 8)) and plan(144, 144, 1, 131) == (128, ("few", 3))
+    assert plan(64, 64, 1) is None and plan(128, 128, 2) is None          # whole 64-column groups with Cin % 32 == 0: the plain form
+    assert plan(80, 80, 2, 67) is None and plan(16, 80, 1, 67) is None and plan(80, 48, 1) is None and plan(80, 112, 1, 104) is None
+    assert _padded_widths(67, 67, 1, True) == (80, 80) and _padded_widths(80, 64, 1, True, real=(67, 64)) == (80, 64)
+    assert _padded_widths(96, 96, 1, True) == (96, 96) and _padded_widths(72, 72, 1, True) == (80, 80)
+    for shape in ((64, 64, 1), (32, 32, 1), (128, 128, 2), (320, 128, 1), (64, 128, 1), (128, 128, 1)):
+        assert _padded_widths(shape[0], shape[1], shape[2], True) == shape[:2], shape
+    assert _padded_widths(12, 32, 1, False) == (16, 32)                    # the space-to-depth image of firstconv: no data gradient
+    Conv2dCL.rnet_route = False
+    try:
+        assert plan(80, 80, 1, 67) is None and _padded_widths(67, 67, 1, True) == (96, 96)       # the direct 96-wide kernel (rounds 2-5)
+    finally:
+        Conv2dCL.rnet_route = True
+
+
+def test_pack_cache_scopes():
+    """autograd.pack_cache: streams are computed once per (layer key, what) inside a scope, never outside one, never without a key;
+    nested scopes restore the outer one (TrainGraph captures under its own store while train() may hold another)."""
+    from neuralrgbd_amd import autograd as ag
+    calls = []
+
+    def make(v):
+        def fn():
+            calls.append(v)
+            return v
+        return fn
+    assert ag._cached(1, ("a", 0), make("x")) == "x" and ag._cached(1, ("a", 0), make("x")) == "x" and calls == ["x", "x"]     # no scope
+    with ag.pack_cache() as outer:
+        assert ag._cached(1, ("a", 0), make("y")) == "y" and ag._cached(1, ("a", 0), make("z")) == "y"
+        assert ag._cached(None, ("a", 0), make("k")) == "k" and ag._cached(None, ("a", 0), make("k")) == "k"                    # no key
+        assert ag._cached(1, ("a", 1), make("t")) == "t" and ag._cached(2, ("a", 0), make("u")) == "u"
+        store = {}
+        with ag.pack_cache(store):
+            assert ag._cached(1, ("a", 0), make("w")) == "w" and store == {(1, ("a", 0)): "w"}
+        assert ag._cached(1, ("a", 0), make("q")) == "y" and len(outer) == 3
+    assert ag._PACK_CACHE is None
+    assert calls == ["x", "x", "y", "k", "k", "t", "u", "w"]
