@@ -22,42 +22,87 @@ struct SppArgs {
 
 typedef float sf32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void spp_concat_kernel(const SppArgs a) {
+// grid (ceil(w / kSppPix), h, N), block = kSppPix pixels x ctot4 16-byte words (320 threads at the path's 64 + 128 + 4 x 32 channels),
+// ordered BY SOURCE: first the strip's quarter words, then its deep words, then its branch words — at the path's widths every wave
+// takes ONE of the three code paths (64 = 4 pixels x 16 quarter words, 128 deep, 128 branch).  Round 6: the first version walked a flat
+// index (pixel, word), so most waves ran all three paths one after the other, each with its own memory latency in front of the one
+// store: 2.4 TB/s; and it divided a 64-bit index three times per thread.
+constexpr int kSppPix = 4;
+
+constexpr int kSppRows = 2;      // image rows per workgroup: a thread keeps the loads of both rows in flight before it stores
+
+__global__ __launch_bounds__(512) void spp_concat_kernel(const SppArgs a) {
     const int cq4 = a.Cq >> 2, cd4 = a.Cd >> 2, cb4 = a.Cb >> 2, ctot4 = cq4 + cd4 + 4 * cb4;
-    const long total = (long)a.N * a.h * a.w * ctot4;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long pix = idx / ctot4;
-        const int g = (int)(idx - pix * ctot4);
-        sf32x4 v;
-        if (g < cq4) {
-            v = reinterpret_cast<const sf32x4*>(a.quarter)[pix * cq4 + g];
-        } else if (g < cq4 + cd4) {
-            v = reinterpret_cast<const sf32x4*>(a.deep)[pix * cd4 + (g - cq4)];
-        } else {
-            const int gb = g - cq4 - cd4, b = gb / cb4, c4 = gb - b * cb4;
-            const int x = (int)(pix % a.w);
-            const long t = pix / a.w;
-            const int y = (int)(t % a.h), n = (int)(t / a.h);
-            const int bh = a.bh[b], bw = a.bw[b];
-            const float sch = a.h > 1 ? (float)(bh - 1) / (float)(a.h - 1) : 0.f;
-            const float scw = a.w > 1 ? (float)(bw - 1) / (float)(a.w - 1) : 0.f;
-            const float h1r = sch * (float)y, w1r = scw * (float)x;
-            const int h1 = min((int)h1r, bh - 1), w1 = min((int)w1r, bw - 1);
-            const int h1p = h1 < bh - 1 ? 1 : 0, w1p = w1 < bw - 1 ? 1 : 0;
-            const float h1l = fminf(fmaxf(h1r - (float)h1, 0.f), 1.f), h0l = 1.f - h1l;
-            const float w1l = fminf(fmaxf(w1r - (float)w1, 0.f), 1.f), w0l = 1.f - w1l;
-            const sf32x4* z = reinterpret_cast<const sf32x4*>(a.bz[b]) + ((long)n * bh * bw) * cb4 + c4;
-            const float* ss = a.bss[b] + 8 * c4;               // (scale, shift) of channels 4 c4 .. 4 c4 + 3
-            const sf32x4 sc = {ss[0], ss[2], ss[4], ss[6]}, sh = {ss[1], ss[3], ss[5], ss[7]};
-            auto tap = [&](int yy, int xx) -> sf32x4 {
-                sf32x4 r = z[((long)yy * bw + xx) * cb4] * sc + sh;   // BatchNorm (batch statistics) of the tiny map ...
-                r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);   // ... and its ReLU
-                return r;
-            };
-            const sf32x4 v00 = tap(h1, w1), v01 = tap(h1, w1 + w1p), v10 = tap(h1 + h1p, w1), v11 = tap(h1 + h1p, w1 + w1p);
-            v = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
-        }
-        reinterpret_cast<sf32x4*>(a.out)[idx] = v;
+    const int tid = threadIdx.x;
+    const int nq = kSppPix * cq4, nd = kSppPix * cd4, nb = kSppPix * 4 * cb4;
+    if (tid >= nq + nd + nb) return;
+    // (pixel of the strip, word inside the source): compare instead of dividing by a run-time width
+    auto split = [&](int t, int per, int& pl, int& g) {
+        pl = 0; g = t;
+#pragma unroll
+        for (int i = 1; i < kSppPix; ++i)
+            if (t >= i * per) { pl = i; g = t - i * per; }
+    };
+    const int y0 = blockIdx.y * kSppRows, n = blockIdx.z;
+    const int nrow = min(kSppRows, a.h - y0);
+    int pl, g;
+    sf32x4 v[kSppRows];
+    if (tid < nq + nd) {
+        const bool q = tid < nq;
+        split(q ? tid : tid - nq, q ? cq4 : cd4, pl, g);
+        const int x = blockIdx.x * kSppPix + pl;
+        if (x >= a.w) return;
+        const sf32x4* src = reinterpret_cast<const sf32x4*>(q ? a.quarter : a.deep);
+        const int c4n = q ? cq4 : cd4, goff = q ? g : cq4 + g;
+        const size_t pix = ((size_t)n * a.h + y0) * a.w + x;
+#pragma unroll
+        for (int r = 0; r < kSppRows; ++r)
+            if (r < nrow) v[r] = src[(pix + (size_t)r * a.w) * c4n + g];
+#pragma unroll
+        for (int r = 0; r < kSppRows; ++r)
+            if (r < nrow) reinterpret_cast<sf32x4*>(a.out)[(pix + (size_t)r * a.w) * ctot4 + goff] = v[r];
+        return;
+    }
+    split(tid - nq - nd, 4 * cb4, pl, g);
+    const int x = blockIdx.x * kSppPix + pl;
+    if (x >= a.w) return;
+    const size_t pix = ((size_t)n * a.h + y0) * a.w + x;
+    int gb = g, b = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (gb >= cb4) { gb -= cb4; b = i; }
+    const int c4 = gb;
+    const int bh = a.bh[b], bw = a.bw[b];
+    const float sch = a.h > 1 ? (float)(bh - 1) / (float)(a.h - 1) : 0.f;
+    const float scw = a.w > 1 ? (float)(bw - 1) / (float)(a.w - 1) : 0.f;
+    const float w1r = scw * (float)x;
+    const int w1 = min((int)w1r, bw - 1), w1p = w1 < bw - 1 ? 1 : 0;
+    const float w1l = fminf(fmaxf(w1r - (float)w1, 0.f), 1.f), w0l = 1.f - w1l;
+    const sf32x4* z = reinterpret_cast<const sf32x4*>(a.bz[b]) + ((size_t)n * bh * bw) * cb4 + c4;
+    const float* ss = a.bss[b] + 8 * c4;                   // (scale, shift) of channels 4 c4 .. 4 c4 + 3
+    const sf32x4 sc = {ss[0], ss[2], ss[4], ss[6]}, sh = {ss[1], ss[3], ss[5], ss[7]};
+    auto act = [&](sf32x4 r) -> sf32x4 {
+        r = r * sc + sh;                                    // BatchNorm (batch statistics) of the tiny map ...
+        r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);   // ... and its ReLU
+        return r;
+    };
+    // the taps of both rows are requested together, then normalised and blended: one memory latency per thread
+    sf32x4 r00[kSppRows], r01[kSppRows], r10[kSppRows], r11[kSppRows];
+    float h0l[kSppRows], h1l[kSppRows];
+#pragma unroll
+    for (int r = 0; r < kSppRows; ++r) {
+        const int y = min(y0 + r, a.h - 1);
+        const float h1r = sch * (float)y;
+        const int h1 = min((int)h1r, bh - 1), h1p = h1 < bh - 1 ? 1 : 0;
+        h1l[r] = fminf(fmaxf(h1r - (float)h1, 0.f), 1.f); h0l[r] = 1.f - h1l[r];
+        r00[r] = z[(h1 * bw + w1) * cb4]; r01[r] = z[(h1 * bw + w1 + w1p) * cb4];
+        r10[r] = z[((h1 + h1p) * bw + w1) * cb4]; r11[r] = z[((h1 + h1p) * bw + w1 + w1p) * cb4];
+    }
+#pragma unroll
+    for (int r = 0; r < kSppRows; ++r) {
+        const sf32x4 v00 = act(r00[r]), v01 = act(r01[r]), v10 = act(r10[r]), v11 = act(r11[r]);
+        v[r] = h0l[r] * (w0l * v00 + w1l * v01) + h1l[r] * (w0l * v10 + w1l * v11);
+        if (r < nrow) reinterpret_cast<sf32x4*>(a.out)[(pix + (size_t)r * a.w) * ctot4 + cq4 + cd4 + g] = v[r];
     }
 }
 
@@ -169,9 +214,11 @@ extern "C" int nrgbd_spp_concat(const float* quarter, int Cq, const float* deep,
     if ((Cq | Cd | Cb) & 3) return NRGBD_E_ALIGN;
     SppArgs a{quarter, deep, {bz0, bz1, bz2, bz3}, {bss0, bss1, bss2, bss3}, {bh0, bh1, bh2, bh3}, {bw0, bw1, bw2, bw3}, out,
               N, h, w, Cq, Cd, Cb};
-    const long total = (long)N * h * w * ((Cq + Cd + 4 * Cb) >> 2);
-    const long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(spp_concat_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, a);
+    const int ctot4 = (Cq + Cd + 4 * Cb) >> 2;
+    if (kSppPix * ctot4 > 512 || h > 65535 || N > 65535) return NRGBD_E_SHAPE;        // one workgroup = kSppPix pixels of a row
+    const int threads = (kSppPix * ctot4 + 63) / 64 * 64;
+    hipLaunchKernelGGL(spp_concat_kernel, dim3((unsigned)((w + kSppPix - 1) / kSppPix), (unsigned)((h + kSppRows - 1) / kSppRows), (unsigned)N), dim3(threads), 0,
+                       (hipStream_t)stream, a);
     NRGBD_CHECK_LAUNCH();
     return NRGBD_OK;
 }
