@@ -572,7 +572,8 @@ int nrgbd_bn_finalize(const float* stats, int num_workgroups, int C, long count,
  * bilinear, align_corners=True) (:153-158), and the torch.cat of (output_raw, output_skip, branch4, branch3, branch2, branch1)
  * (:160).  out[pixel] = [ quarter (Cq) | deep (Cd) | up(relu(bz0 * s + t)) | up(.. bz1) | up(.. bz2) | up(.. bz3) ].
  *   quarter [N][h][w][Cq], deep [N][h][w][Cd]; branch i: raw 1x1-conv output bz_i [N][bh_i][bw_i][Cb] and the (scale, shift)
- *   [Cb][2] of its BatchNorm (nrgbd_bn_finalize); out [N][h][w][Cq + Cd + 4 Cb]; all channel counts % 4 == 0.
+ *   [Cb][2] of its BatchNorm (nrgbd_bn_finalize); out [N][h][w][Cq + Cd + 4 Cb]; all channel counts % 4 == 0,
+ *   Cq + Cd + 4 Cb <= 512 (a workgroup = four pixels' 16-byte words: 320 channels in models/psm_submodule.py), h, N <= 65535.
  * Interpolation arithmetic = ATen upsample_bilinear2d (fp32 scale (in-1)/(out-1), lambda clamped to [0,1]).
  */
 int nrgbd_spp_concat(const float* quarter, int Cq, const float* deep, int Cd,
