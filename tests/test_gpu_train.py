@@ -657,6 +657,8 @@ def test_split_train_graph_with_accumulation_equals_eager_accumulation(D):
         loss_g, pg = tg.step_windows(windows)
         torch.cuda.synchronize()
         assert (tg._graph is None) == (it == 0)
+        if it >= 1:      # round 6: windows 2 .. A replay a second capture that holds no weight-packing launch and reads the first one's streams
+            assert tg._g_rest is not None and len(tg._st["packed"]) > 50
         d_pred = max(float((a - b).abs().max()) for a, b in zip(pe, pg))
         print("[parity] split train graph step %d: loss %.6f vs eager %.6f, max|d BV_predict| %.2e" % (it, float(loss_g), float(loss_e), d_pred))
         assert abs(float(loss_g) - float(loss_e)) < 1e-3 * abs(float(loss_e)) and d_pred < 5e-2
