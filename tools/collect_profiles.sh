@@ -8,3 +8,4 @@ cp $S/frame_B_dispatches.txt $P/r6_frame_B_dispatches.txt
 cp $S/pmc_wino_summary.txt $P/r6_pmc_wino.txt
 cp $S/pytest.txt $P/r6_pytest_gpu.txt
 cp $S/smoke_kernel_stats.csv $P/r6_smoke_kernel_stats.csv
+python tools/summary.py r6 > /dev/null

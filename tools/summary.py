@@ -19,7 +19,7 @@ for c in "BSKH":
     if "valu_frac" in rf:
         out.append("                   its SQ counters: VALU issue busy %.0f %%, LDS array busy %.0f %%, %.2f of 3 waves resident per SIMD, %.0f %% of the wave-cycles parked" %
                    (100 * rf["valu_frac"], 100 * rf["lds_frac"], rf["mean_waves_per_simd"], 100 * rf["waves_waiting_frac"]))
-    out.append("                   K-Net layer (wino_dw plain) %.3f ms = %.1f TFLOP/s issued = %.1f %% of the fp32 matrix peak (%.0f TFLOP/s direct-conv equivalent)" %
+    out.append("                   K-Net layer (wino_dw4 clamped-FMA form) %.3f ms = %.1f TFLOP/s issued = %.1f %% of the fp32 matrix peak (%.0f TFLOP/s direct-conv equivalent)" %
                (rm["kernel_ms"], rm["achieved"], 100 * rm["frac"], rm["direct_conv_equivalent_tflops"]))
     out.append("                   parity vs oracle: L1 refined/DPV/BV_cur/BV_predict %.1e / %.1e / %.1e / %.1e; max DPV %.1e, BV_predict %.1e; arg-max flips %d/%d/%d (beyond a tie: %d); pass %s, pass_strict %s" %
                (p["refined"]["mean"], p["dpv"]["mean"], p["bv_cur"]["mean"], p["bv_predict"]["mean"], p["dpv"]["max"], p["bv_predict"]["max"],
